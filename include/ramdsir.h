@@ -1,0 +1,246 @@
+/* ramdsir.h -- C ABI of libramdsir_hip.so: the MI355X (gfx950) hot path of RAM-DSIR training.
+ *
+ * The reference (zzzqzhou/RAM-DSIR) is pure Python on top of PyTorch; it has no FFI.  The boundary a
+ * maintainer binds is therefore the set of ATen/cuDNN operators its nn.Modules dispatch to
+ *  plus the numpy RAM trio.  Every entry point below names the reference site(s) it
+ * replaces (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes stub that
+ * plugs them under code/networks/unet.py and code/dataset/fundus.py.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the library never allocates
+ *     tensors (the caller owns all memory; workspaces are passed in);
+ *   - activations/gradients are NHWC, element type `dtype` (RD_F32 or RD_BF16); parameters, BN
+ *     statistics, losses and Adam state are always fp32, OIHW like torch;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), returns 0 or a
+ *     hipError_t value, and is hipGraph-capturable (no allocation, no sync inside);
+ *   - a "group" is a set of consecutive images that share BatchNorm statistics: the two encoder /
+ *     seg-decoder passes of one step (img, img_freq) are two groups of one launch; the per-domain
+ *     slices of the restoration decoder are one group per domain (DomainSpecificBatchNorm2d).
+ */
+#ifndef RAMDSIR_H
+#define RAMDSIR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_F32 0
+#define RD_BF16 1
+#define RD_MAX_GROUPS_C 8
+
+/* how a conv reads one of its (virtual) input tensors -- the producer's BatchNorm + activation
+ * (+ max-pool / bilinear x2) are applied while the tile is staged into LDS ("normalise on read") */
+enum {
+    RD_SRC_RAW = 0,    /* v = x                                             (image, dlogits)             */
+    RD_SRC_AFF = 1,    /* v = x*scale+shift                                 (ConvD.bn1: no activation)   */
+    RD_SRC_AFFACT = 2, /* v = act(x*scale+shift)                            (BN+ReLU, unet.py:64-70)     */
+    RD_SRC_POOL = 3,   /* v = max2x2(act(x*scale+shift)), stored at 2H x 2W (unet.py:56 MaxPool2d(2))    */
+    RD_SRC_UP = 4,     /* v = act(bilerp2x(x)*scale+shift), stored at H/2 x W/2 (unet.py:84-86, 1x1 conv
+                          commuted below the upsample: conv1x1(up(a)) == up(conv1x1(a)))                 */
+    RD_SRC_BNBWD = 5   /* v = P*g + Q*z + R  (BatchNorm backward folded into the read; ptr=g, ptr2=z)    */
+};
+
+typedef struct {
+    const void* ptr;     /* NHWC tensor [N][Hs][Ws][C]                                   */
+    const void* ptr2;    /* RD_SRC_BNBWD: the raw forward tensor z                        */
+    const float* scale;  /* [G][C]  (BNBWD: P)                                            */
+    const float* shift;  /* [G][C]  (BNBWD: R)                                            */
+    const float* q;      /* [G][C]  BNBWD only                                            */
+    int32_t mode;
+    int32_t C;
+    float slope;         /* 0 = ReLU, 0.01 = LeakyReLU (unet.py:47-50)                    */
+    int32_t n_off;       /* image offset into ptr (rec decoder reads images 8.. of x5)    */
+    int32_t g_fixed;     /* >=0: use this group row of scale/shift instead of the image's */
+    int32_t pad_;
+} rd_src_t;
+
+/* where a dgrad launch puts the gradient w.r.t. its (virtual) input, i.e. w.r.t. the producer's
+ * BN output: masks by the activation, scatters through max-pool, and accumulates the two
+ * per-channel BN-backward sums (sum g, sum g*z) */
+enum { RD_DST_PLAIN = 0, RD_DST_POOL = 1, RD_DST_UPY = 2, RD_DST_NONE = 3 };
+
+typedef struct {
+    void* g;             /* gradient tensor to write, NHWC [*][Hd][Wd][Cd]                          */
+    const void* z;       /* producer's raw tensor (PLAIN/POOL: same dims as g; UPY: t_lo, half res) */
+    const float* scale;  /* producer BN scale/shift [G][Cd] (mask needs the sign of the BN output)  */
+    const float* shift;
+    float* bstats;       /* [G][Cd][2] += (sum g, sum g*z)  or NULL                                 */
+    int32_t kind;
+    int32_t act;         /* 1: an activation follows the producer BN                                */
+    int32_t accumulate;  /* 1: g += (skip connection / second consumer)                             */
+    int32_t Cd;
+    float slope;
+    int32_t n_off;       /* image offset into g / z                                                 */
+    int32_t g_fixed;     /* >=0: producer group row                                                 */
+    int32_t pad_;
+} rd_dst_t;
+
+/* rd_conv: replaces F.conv2d forward (unet.py:37-43,81-88,124-131,281,307) and, with flipped /
+ * transposed packed weights, cudnn's dgrad; fused: bias add, BN batch statistics of the output
+ * (nn.BatchNorm2d train mode), and on the read side the producer's BN+act+pool/upsample+concat. */
+typedef struct {
+    rd_src_t src[2];     /* 2 sources = torch.cat([prev, y], 1) (unet.py:110), never materialised */
+    int32_t nsrc;
+    int32_t taps;        /* 9 (3x3, pad 1) or 1 (1x1) */
+    const void* w;       /* packed weights [taps][CoutPad][CinPad], dtype, zero padded */
+    const float* bias;   /* [Cout] or NULL */
+    int32_t CinPad, CoutPad;
+    int32_t N, H, W, Cin, Cout;
+    int32_t G;
+    int32_t gstart[RD_MAX_GROUPS_C + 1];
+    int32_t emode;       /* 0 forward: write out (+stats); 1 gradient: write through dst[] */
+    void* out;           /* forward: NHWC [N][H][W][Cout] */
+    float* stats;        /* forward: [G][Cout][2] += (sum, sum of squares) or NULL */
+    rd_dst_t dst[2];     /* gradient: channels [0,c_split) -> dst[0], [c_split,Cout) -> dst[1] */
+    int32_t c_split;
+    int32_t pad_;
+} rd_conv_t;
+
+int rd_conv(const rd_conv_t* p, int dtype, void* stream);
+
+/* rd_wgrad: replaces cudnn's wgrad for the same convs.  partial is a caller workspace of
+ * rd_wgrad_workspace() bytes; the result is accumulated (beta=1) or stored (beta=0) into dW, fp32
+ * OIHW [Cout][Cin][kh][kw]. */
+typedef struct {
+    rd_src_t a[2];       /* the conv's forward input, described exactly as for rd_conv */
+    int32_t na;
+    int32_t taps;
+    rd_src_t dz;         /* gradient w.r.t. the conv output (RD_SRC_BNBWD or RD_SRC_RAW) */
+    int32_t N, H, W, Cin, Cout;
+    int32_t G;
+    int32_t gstart[RD_MAX_GROUPS_C + 1];
+    float* partial;
+    float* dW;
+    float beta;
+    int32_t pad_;
+} rd_wgrad_t;
+
+int64_t rd_wgrad_workspace(const rd_wgrad_t* p, int dtype);
+int rd_wgrad(const rd_wgrad_t* p, int dtype, void* stream);
+
+/* rd_pack_weights: OIHW fp32 master weights -> the packed operand rd_conv reads.
+ * transpose=0: forward  [tap][CoutPad][CinPad]  (tap = kh*3+kw)
+ * transpose=1: dgrad    [tap'][CinPad'][CoutPad'] with tap' = 8-tap (180-degree flip), i.e. the conv
+ *              that maps dz (Cout channels) to da (Cin channels). */
+int rd_pack_weights(const float* w_oihw, void* packed, int Cout, int Cin, int taps, int transpose,
+                    int dtype, void* stream);
+int64_t rd_packed_elems(int Cout, int Cin, int taps, int transpose, int dtype);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (train: batch statistics; eval: running statistics) split into "finalize" launches
+ * around the convs.  nn.BatchNorm2d / DomainSpecificBatchNorm2d: code/networks/unet.py:17-28,
+ * code/networks/dsbn.py:24-27.  Per-group parameter pointers: the two passes of the encoder share one
+ * BN (same pointers in both groups -> running stats updated twice, in order); DSBN gives each domain
+ * group its own bns[d]. */
+typedef struct {
+    const float* stats;   /* [G][C][2] sum, sum of squares of the conv output */
+    float* scale;         /* [G][C] out: gamma*invstd          */
+    float* shift;         /* [G][C] out: beta - mean*scale     */
+    float* mean;          /* [G][C] out (saved for backward)   */
+    float* invstd;        /* [G][C] out                        */
+    const float* gamma[RD_MAX_GROUPS_C];
+    const float* beta[RD_MAX_GROUPS_C];
+    float* running_mean[RD_MAX_GROUPS_C];
+    float* running_var[RD_MAX_GROUPS_C];
+    int64_t* num_batches_tracked[RD_MAX_GROUPS_C];
+    float count[RD_MAX_GROUPS_C];   /* elements per channel in the group: N_g*H*W */
+    int32_t C, G;
+    float eps, momentum;
+    int32_t training;     /* 0: eval -- scale/shift from the running statistics, nothing updated */
+    int32_t pad_;
+} rd_bn_fwd_t;
+int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream);
+
+/* BatchNorm backward, second half: from (sum g, sum g*z) produce the per-channel coefficients
+ * dz = P*g + Q*z + R that the next dgrad / wgrad fold into their reads, and accumulate dgamma, dbeta. */
+typedef struct {
+    const float* bstats;  /* [G][C][2] */
+    const float* mean;    /* [G][C] */
+    const float* invstd;  /* [G][C] */
+    const float* gamma[RD_MAX_GROUPS_C];
+    float* dgamma[RD_MAX_GROUPS_C];   /* += */
+    float* dbeta[RD_MAX_GROUPS_C];    /* += */
+    float* P; float* Q; float* R;     /* [G][C] out */
+    float count[RD_MAX_GROUPS_C];
+    int32_t C, G;
+} rd_bn_bwd_t;
+int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream);
+
+/* statistics of y = bilinear_x2(t) (nn.Upsample(scale_factor=2, 'bilinear', align_corners=False),
+ * unet.py:84) without materialising y: stats[G][C][2] += (sum y, sum y^2).  t: NHWC [N][h][w][C]. */
+int rd_up_stats(const void* t, float* stats, int N, int h, int w, int C, int G, const int32_t* gstart_host,
+                int dtype, void* stream);
+
+/* backward of y = up2(t) followed by BN: dt = up2^T( P*g + Q*up2(t) + R ), g: NHWC [N][2h][2w][C],
+ * dt/t: NHWC [N][h][w][C]. */
+int rd_up_bwd(const void* g, const void* t, void* dt, const float* P, const float* Q, const float* R, int N, int h,
+              int w, int C, int G, const int32_t* gstart_host, int dtype, void* stream);
+
+/* layout / materialisation at the module boundary (torch NCHW fp32 <-> NHWC dtype) */
+int rd_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int N, int C, int H, int W, int dtype, void* stream);
+/* y_nchw = act(z*scale+shift)  (act: 0 none, 1 activation with `slope`); scale==NULL -> identity */
+int rd_nhwc_to_nchw(const void* z_nhwc, float* y_nchw, const float* scale, const float* shift, int act, float slope,
+                    int N, int C, int H, int W, int G, const int32_t* gstart_host, int dtype, void* stream);
+/* gradient entering a module from torch: g_nhwc (+)= mask(dy_nchw), bstats += (sum g, sum g*z) */
+int rd_grad_in(const float* dy_nchw, const void* z_nhwc, void* g_nhwc, const float* scale, const float* shift,
+               float* bstats, int act, float slope, int accumulate, int N, int C, int H, int W, int G,
+               const int32_t* gstart_host, int dtype, void* stream);
+/* column sums of an NHWC tensor: out[c] (+)= sum over pixels (bias gradient of the two out1 convs) */
+int rd_colsum(const void* x_nhwc, float* out, float* partial_ws /* >= 8192 floats */, int64_t npix, int C, float beta,
+              int dtype, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused segmentation + consistency losses, forward and backward in two passes over the logits.
+ * Fundus  (code/train.py:246-259,283): p=sigmoid(l); BCELoss + dice_loss (utils/losses.py:8-16) for
+ *          both passes + 0.5*KD|MSE(p2,p1) (train.py:85-88).  mask: NCHW fp32 [B][K][H][W].
+ * Prostate (train.py:412-427,451): p=softmax(l); CrossEntropyLoss + dice_loss_multi(ignore_index=0)
+ *          (utils/losses.py:18-33) + 0.5*KD|MSE.  target: int64 [B][H][W].
+ * logits/dlogits: NHWC [2B][H][W][K] (pass 0 = images [0,B), pass 1 = [B,2B)).
+ * losses_out[8] = {seg1, dice1, seg2, dice2, consistency, seg1+seg2+dice1+dice2+w*consistency, 0, 0}. */
+typedef struct {
+    const void* logits;
+    const void* target;     /* fundus: const float* mask NCHW; prostate: const int64_t* */
+    void* dlogits;
+    float* partial;         /* workspace: rd_seg_loss_workspace() bytes */
+    float* losses_out;      /* [8] device */
+    int32_t B, H, W, K;
+    int32_t kind;           /* 0 fundus (sigmoid/BCE/dice), 1 prostate (softmax/CE/dice_multi) */
+    int32_t consistency;    /* 0 none, 1 kd, 2 mse */
+    float cons_weight;      /* 0.5 (train.py:283) */
+    int32_t pad_;
+} rd_seg_loss_t;
+int64_t rd_seg_loss_workspace(const rd_seg_loss_t* p);
+int rd_seg_loss(const rd_seg_loss_t* p, int dtype, void* stream);
+
+/* Restoration loss (train.py:265-276): per domain group d, MSELoss(tanh(rec_logits[d]), img[d]);
+ * loss += lambda_rec * mse_d.  rec_logits / target / dlogits: NHWC [B][H][W][C].  mse_out[G] device. */
+int rd_rec_loss(const void* rec_logits, const void* target, void* dlogits, float* mse_out, float* partial_ws,
+                int B, int H, int W, int C, int G, const int32_t* gstart_host, float lambda_rec, int dtype,
+                void* stream);
+int64_t rd_rec_loss_workspace(int B, int H, int W, int C);
+
+/* ------------------------------------------------------------------------------------------------
+ * Adam over the flat parameter arena (torch.optim.Adam, betas (0.9,0.999), eps 1e-8, no weight decay;
+ * code/train.py:573-576) with the reference's 3 param groups (encoder at lr/2) and poly LR
+ * lr*(1-iter/total)^0.9 written after the step (train.py:289-293).  `iter` is a device counter that
+ * the call increments, so a captured hipGraph replays the schedule without host involvement.
+ * hyper_out[4] = {lr used for group 1/2, bias_correction1, bias_correction2, iter used}. */
+typedef struct {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n;              /* total elements */
+    int64_t n_half_lr;      /* the first n_half_lr elements (encoder) use lr/2 */
+    int32_t* iter;          /* device, incremented */
+    float* hyper_out;       /* device [4] */
+    float base_lr;
+    int32_t total_iters;
+    float beta1, beta2, eps;
+    int32_t pad_;
+} rd_adam_t;
+int rd_adam_step(const rd_adam_t* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,383 @@
+// bn.hip -- BatchNorm finalize (forward / backward), upsample-side statistics and backward, and the
+// NCHW fp32 <-> NHWC layout kernels at the module boundary.
+//
+// Reference sites: nn.BatchNorm2d via normalization('bn') code/networks/unet.py:17-28,
+// DomainSpecificBatchNorm2d code/networks/dsbn.py:24-27, nn.Upsample(bilinear, x2) unet.py:84,127.
+#include "common.h"
+#include "../../include/ramdsir.h"
+
+namespace {
+
+__global__ void bn_finalize_fwd_kernel(const rd_bn_fwd_t p) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    for (int g = 0; g < p.G; ++g) {                       // in order: shared BNs see pass 0 then pass 1
+        const float gam = p.gamma[g][c], bet = p.beta[g][c];
+        float mean, invstd;
+        if (p.training) {
+            const float cnt = p.count[g];
+            const float s1 = p.stats[(g * p.C + c) * 2 + 0], s2 = p.stats[(g * p.C + c) * 2 + 1];
+            mean = s1 / cnt;
+            float var = s2 / cnt - mean * mean;
+            if (var < 0.f) var = 0.f;
+            invstd = 1.0f / sqrtf(var + p.eps);
+            if (p.running_mean[g]) {
+                const float unb = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
+                p.running_mean[g][c] = (1.f - p.momentum) * p.running_mean[g][c] + p.momentum * mean;
+                p.running_var[g][c] = (1.f - p.momentum) * p.running_var[g][c] + p.momentum * unb;
+            }
+            if (c == 0 && p.num_batches_tracked[g]) *p.num_batches_tracked[g] += 1;
+        } else {
+            mean = p.running_mean[g][c];
+            invstd = 1.0f / sqrtf(p.running_var[g][c] + p.eps);
+        }
+        const float sc = gam * invstd;
+        p.scale[g * p.C + c] = sc;
+        p.shift[g * p.C + c] = bet - mean * sc;
+        p.mean[g * p.C + c] = mean;
+        p.invstd[g * p.C + c] = invstd;
+    }
+}
+
+__global__ void bn_finalize_bwd_kernel(const rd_bn_bwd_t p) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    for (int g = 0; g < p.G; ++g) {
+        const float cnt = p.count[g];
+        const float s1 = p.bstats[(g * p.C + c) * 2 + 0], sgz = p.bstats[(g * p.C + c) * 2 + 1];
+        const float mu = p.mean[g * p.C + c], is = p.invstd[g * p.C + c], gam = p.gamma[g][c];
+        const float s2 = is * (sgz - mu * s1);            // sum g * zhat
+        const float P = gam * is;
+        const float Q = -gam * is * is * s2 / cnt;
+        p.P[g * p.C + c] = P;
+        p.Q[g * p.C + c] = Q;
+        p.R[g * p.C + c] = -P * s1 / cnt - Q * mu;
+        if (p.dgamma[g]) p.dgamma[g][c] += s2;
+        if (p.dbeta[g]) p.dbeta[g][c] += s1;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void ldv(const T* p, float* f) {
+    Slot<T>::unpack(*reinterpret_cast<const uint4*>(p), f);
+}
+
+// sum / sum of squares of the virtual upsampled tensor; grid (blocks, N)
+template <typename T>
+__global__ __launch_bounds__(256) void up_stats_kernel(const T* t, float* stats, int h, int w, int C, GroupMap gm) {
+    constexpr int S = Slot<T>::N;
+    extern __shared__ float s_red[];                       // [C][2]
+    const int n = blockIdx.y, g = group_of(gm, n);
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_red[i] = 0.f;
+    __syncthreads();
+    const int SL = C / S;
+    const int H = 2 * h, W = 2 * w;
+    const int items = H * W * SL;
+    const int sl = threadIdx.x % SL;                       // constant per thread (256 % SL == 0, stride % SL == 0)
+    float a1[S], a2[S];
+#pragma unroll
+    for (int e = 0; e < S; ++e) a1[e] = a2[e] = 0.f;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < items; idx += gridDim.x * blockDim.x) {
+        const int pix = idx / SL;
+        const int Y = pix / W, X = pix - Y * W;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        up2_coord(Y, h, y0, y1, ly);
+        up2_coord(X, w, x0, x1, lx);
+        float t00[S], t01[S], t10[S], t11[S];
+        const T* b = t + (size_t)n * h * w * C + sl * S;
+        ldv<T>(b + ((size_t)y0 * w + x0) * C, t00);
+        ldv<T>(b + ((size_t)y0 * w + x1) * C, t01);
+        ldv<T>(b + ((size_t)y1 * w + x0) * C, t10);
+        ldv<T>(b + ((size_t)y1 * w + x1) * C, t11);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const float top = t00[e] + lx * (t01[e] - t00[e]), bot = t10[e] + lx * (t11[e] - t10[e]);
+            const float u = top + ly * (bot - top);
+            a1[e] += u;
+            a2[e] += u * u;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        atomicAdd(&s_red[(sl * S + e) * 2 + 0], a1[e]);
+        atomicAdd(&s_red[(sl * S + e) * 2 + 1], a2[e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&stats[(size_t)g * C * 2 + i], s_red[i]);
+}
+
+// weights of the (up to 4) hi-res rows 2y-1..2y+2 on lo-res row y, and the 3 coefficients of row y of U^T U
+__device__ __forceinline__ void up_adjoint_1d(int y, int h, float* wy, float* A) {
+    A[0] = A[1] = A[2] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int Y = 2 * y - 1 + j;
+        wy[j] = 0.f;
+        if (Y < 0 || Y >= 2 * h) continue;
+        int i0, i1;
+        float lam;
+        up2_coord(Y, h, i0, i1, lam);
+        const float wgt = (i0 == y ? 1.f - lam : 0.f) + (i1 == y ? lam : 0.f);
+        wy[j] = wgt;
+        if (wgt != 0.f) {
+            A[i0 - y + 1] += wgt * (1.f - lam);
+            A[i1 - y + 1] += wgt * lam;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void up_bwd_kernel(const T* g2, const T* t, T* dt, const float* P, const float* Q,
+                                                     const float* R, int h, int w, int C, GroupMap gm) {
+    constexpr int S = Slot<T>::N;
+    const int n = blockIdx.y, gi = group_of(gm, n);
+    const int SL = C / S;
+    const int items = h * w * SL;
+    const int H = 2 * h, W = 2 * w;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < items; idx += gridDim.x * blockDim.x) {
+        const int sl = idx % SL, pix = idx / SL;
+        const int y = pix / w, x = pix - y * w;
+        float wy[4], wx[4], Ay[3], Ax[3];
+        up_adjoint_1d(y, h, wy, Ay);
+        up_adjoint_1d(x, w, wx, Ax);
+        float G[S], TU[S];
+#pragma unroll
+        for (int e = 0; e < S; ++e) G[e] = TU[e] = 0.f;
+        const T* gb = g2 + (size_t)n * H * W * C + sl * S;
+        const T* tb = t + (size_t)n * h * w * C + sl * S;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (wy[j] == 0.f) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float wgt = wy[j] * wx[k];
+                if (wgt == 0.f) continue;
+                float v[S];
+                ldv<T>(gb + ((size_t)(2 * y - 1 + j) * W + (2 * x - 1 + k)) * C, v);
+#pragma unroll
+                for (int e = 0; e < S; ++e) G[e] += wgt * v[e];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (Ay[a] == 0.f) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float cf = Ay[a] * Ax[b];
+                if (cf == 0.f) continue;
+                float v[S];
+                ldv<T>(tb + ((size_t)(y + a - 1) * w + (x + b - 1)) * C, v);
+#pragma unroll
+                for (int e = 0; e < S; ++e) TU[e] += cf * v[e];
+            }
+        }
+        const float Wsum = (wy[0] + wy[1] + wy[2] + wy[3]) * (wx[0] + wx[1] + wx[2] + wx[3]);
+        float o[S];
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const int c = gi * C + sl * S + e;
+            o[e] = P[c] * G[e] + Q[c] * TU[e] + R[c] * Wsum;
+        }
+        *reinterpret_cast<uint4*>(dt + ((size_t)(n * h + y) * w + x) * C + sl * S) = Slot<T>::pack(o);
+    }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int N, int C, int H, int W) {
+    const size_t total = (size_t)N * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        const size_t pix = i / C;
+        const int xw = pix % W, yh = (pix / W) % H, n = pix / ((size_t)W * H);
+        y[i] = from_f<T>(x[(((size_t)n * C + c) * H + yh) * W + xw]);
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* z, float* y, const float* scale, const float* shift, int act, float slope,
+                                    int N, int C, int H, int W, GroupMap gm) {
+    const size_t total = (size_t)N * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xw = i % W, yh = (i / W) % H, c = (i / ((size_t)W * H)) % C, n = i / ((size_t)W * H * C);
+        float v = to_f<T>(z[(((size_t)n * H + yh) * W + xw) * C + c]);
+        if (scale) {
+            const int g = group_of(gm, n);
+            v = v * scale[g * C + c] + shift[g * C + c];
+            if (act) v = act_fn(v, slope);
+        }
+        y[i] = v;
+    }
+}
+
+// one block = 64 consecutive pixels of one image; per-channel partial sums through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void grad_in_kernel(const float* dy, const T* z, T* gout, const float* scale,
+                                                      const float* shift, float* bstats, int act, float slope,
+                                                      int accumulate, int C, int H, int W, GroupMap gm) {
+    extern __shared__ float s_red[];                       // [C][2]
+    const int n = blockIdx.y, g = group_of(gm, n);
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_red[i] = 0.f;
+    __syncthreads();
+    const int HW = H * W;
+    const int p0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * C; i += blockDim.x) {
+        const int c = i / 64, pp = p0 + (i % 64);          // consecutive lanes -> consecutive pixels of a NCHW plane
+        float gn = 0.f, zz = 0.f;
+        if (pp < HW) {
+            const size_t zi = ((size_t)n * HW + pp) * C + c;
+            zz = z ? to_f<T>(z[zi]) : 0.f;
+            float m = 1.f;
+            if (act && scale) m = act_grad(zz * scale[g * C + c] + shift[g * C + c], slope);
+            gn = dy[((size_t)n * C + c) * HW + pp] * m;
+            gout[zi] = from_f<T>(accumulate ? to_f<T>(gout[zi]) + gn : gn);
+        }
+        float a = wave_sum(gn), b = wave_sum(gn * zz);     // 64 lanes share channel c
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&s_red[c * 2 + 0], a);
+            atomicAdd(&s_red[c * 2 + 1], b);
+        }
+    }
+    __syncthreads();
+    if (bstats)
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&bstats[(size_t)g * C * 2 + i], s_red[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial, int64_t npix, int C) {
+    // C <= 8; partial[block][C]
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) acc[c] += to_f<T>(x[i * C + c]);
+    __shared__ float s[4][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float v = wave_sum(acc[c]);
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) partial[blockIdx.x * 8 + threadIdx.x] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
+__global__ void colsum_final_kernel(const float* partial, float* out, int nblocks, int C, float beta) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[b * 8 + c];
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
+}
+
+GroupMap host_gm(int G, const int32_t* gs) {
+    GroupMap gm;
+    gm.G = G;
+    for (int i = 0; i <= RD_MAX_GROUPS; ++i) gm.gs[i] = (gs && i <= G) ? gs[i] : 0;
+    return gm;
+}
+
+int grid_for(size_t total, int per_block = 256, int cap = 4096) {
+    size_t b = (total + per_block - 1) / per_block;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream) {
+    if (!p || p->G < 1 || p->G > RD_MAX_GROUPS) return -1;
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((p->C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+
+int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
+    if (!p || p->G < 1 || p->G > RD_MAX_GROUPS) return -1;
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((p->C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+
+int rd_up_stats(const void* t, float* stats, int N, int h, int w, int C, int G, const int32_t* gstart_host, int dtype,
+                void* stream) {
+    const int S = dtype == RD_BF16 ? 8 : 4;
+    if (C % S || 256 % (C / S)) return -2;
+    const GroupMap gm = host_gm(G, gstart_host);
+    const int items = 4 * h * w * (C / S);
+    int bx = grid_for(items, 256 * 8, 512);
+    dim3 grid(bx, N);
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(up_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+                           (const bf16_t*)t, stats, h, w, C, gm);
+    else
+        hipLaunchKernelGGL(up_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+                           (const float*)t, stats, h, w, C, gm);
+    return (int)hipGetLastError();
+}
+
+int rd_up_bwd(const void* g, const void* t, void* dt, const float* P, const float* Q, const float* R, int N, int h, int w,
+              int C, int G, const int32_t* gstart_host, int dtype, void* stream) {
+    const int S = dtype == RD_BF16 ? 8 : 4;
+    if (C % S) return -2;
+    const GroupMap gm = host_gm(G, gstart_host);
+    dim3 grid(grid_for((size_t)h * w * (C / S), 256, 1024), N);
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(up_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)t,
+                           (bf16_t*)dt, P, Q, R, h, w, C, gm);
+    else
+        hipLaunchKernelGGL(up_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)t,
+                           (float*)dt, P, Q, R, h, w, C, gm);
+    return (int)hipGetLastError();
+}
+
+int rd_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int dtype, void* stream) {
+    const size_t total = (size_t)N * C * H * W;
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, N, C, H, W);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (float*)y, N, C, H, W);
+    return (int)hipGetLastError();
+}
+
+int rd_nhwc_to_nchw(const void* z, float* y, const float* scale, const float* shift, int act, float slope, int N, int C,
+                    int H, int W, int G, const int32_t* gstart_host, int dtype, void* stream) {
+    const size_t total = (size_t)N * C * H * W;
+    const GroupMap gm = host_gm(G, gstart_host);
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, y,
+                           scale, shift, act, slope, N, C, H, W, gm);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)z, y,
+                           scale, shift, act, slope, N, C, H, W, gm);
+    return (int)hipGetLastError();
+}
+
+int rd_grad_in(const float* dy, const void* z, void* g, const float* scale, const float* shift, float* bstats, int act,
+               float slope, int accumulate, int N, int C, int H, int W, int G, const int32_t* gstart_host, int dtype,
+               void* stream) {
+    const GroupMap gm = host_gm(G, gstart_host);
+    dim3 grid((H * W + 63) / 64, N);
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(grad_in_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, dy, (const bf16_t*)z,
+                           (bf16_t*)g, scale, shift, bstats, act, slope, accumulate, C, H, W, gm);
+    else
+        hipLaunchKernelGGL(grad_in_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, dy, (const float*)z,
+                           (float*)g, scale, shift, bstats, act, slope, accumulate, C, H, W, gm);
+    return (int)hipGetLastError();
+}
+
+int rd_colsum(const void* x, float* out, float* partial_ws, int64_t npix, int C, float beta, int dtype, void* stream) {
+    if (C > 8) return -2;
+    const int nb = grid_for((size_t)npix, 256 * 4, 1024);
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial_ws, npix, C);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, partial_ws, npix, C);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, out, nb, C, beta);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// common.h -- device-side helpers shared by every kernel file (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define RD_MAX_GROUPS 8
+
+#define RD_CHECK(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            fprintf(stderr, "[ramdsir] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr,         \
+                    hipGetErrorString(_e));                                                 \
+            return (int)_e;                                                                 \
+        }                                                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------- element types
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }   // RNE (v_cvt_pk_bf16_f32)
+
+__device__ __forceinline__ unsigned bf16_bits(float v) {
+    bf16_t b = (bf16_t)v;
+    return (unsigned)__builtin_bit_cast(unsigned short, b);
+}
+
+// A "slot" is 16 bytes of one pixel's channel vector: 4 fp32 or 8 bf16 channels.
+template <typename T> struct Slot;
+template <> struct Slot<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y);
+        f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Slot<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+        f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+        f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(bf16_bits(f[0]) | (bf16_bits(f[1]) << 16), bf16_bits(f[2]) | (bf16_bits(f[3]) << 16),
+                          bf16_bits(f[4]) | (bf16_bits(f[5]) << 16), bf16_bits(f[6]) | (bf16_bits(f[7]) << 16));
+    }
+};
+
+__device__ __forceinline__ float act_fn(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float act_grad(float v, float slope) { return v > 0.f ? 1.f : slope; }
+
+// group of image n given group start offsets gs[0..G] (gs[G] == N)
+struct GroupMap {
+    int G;
+    int gs[RD_MAX_GROUPS + 1];
+};
+__device__ __forceinline__ int group_of(const GroupMap& gm, int n) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < RD_MAX_GROUPS; ++i)
+        if (i < gm.G && n >= gm.gs[i]) g = i;
+    return g;
+}
+
+// bilinear x2, align_corners=False (torch upsample_bilinear2d, scale 0.5):  src = (dst+0.5)/2-0.5 clamped at 0
+__device__ __forceinline__ void up2_coord(int d, int n_src, int& i0, int& i1, float& lam) {
+    float s = ((float)d + 0.5f) * 0.5f - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    i1 = i0 + (i0 < n_src - 1 ? 1 : 0);
+    lam = s - (float)i0;
+}
+
+// block-wide sum of one float per thread (blockDim.x multiple of 64, <= 1024); result valid in thread 0
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,758 @@
+// conv.hip -- direct (im2col-free) 3x3 / 1x1 convolution on gfx950 MFMA: forward, dgrad, wgrad.
+//
+// Replaces the ATen/cuDNN conv2d forward/dgrad/wgrad the reference reaches through nn.Conv2d
+// (code/networks/unet.py:37-43,81-88,124-131,281,307) together with everything that sits between two
+// convs in the reference graph -- BatchNorm apply, ReLU/LeakyReLU, MaxPool2d(2), bilinear x2,
+// torch.cat -- which is folded into the tile loader (forward) or the epilogue (backward).
+//
+// Implicit GEMM, M = pixels, N = output channels, K = taps x input channels:
+//   workgroup  = 256 threads = 4 wave64, output tile 8 rows x 32 columns of one image x NT channels
+//   wave w     = tile rows 2w, 2w+1  -> two 32-pixel M-blocks; NB = NT/32 N-blocks
+//   LDS        = halo tile (10 x 34 pixels) x 64 B of channels (16 fp32 / 32 bf16 per chunk),
+//                16-byte slots XOR-swizzled by (pixel>>2)&3 so that ds_read_b128 of 16 consecutive
+//                pixels is bank-conflict free; the weight chunk [tap][n][64 B] swizzled the same way
+//   MFMA       = v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, bit-exact fmaf chain)
+#include "common.h"
+#include "../../include/ramdsir.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32;
+
+// ------------------------------------------------------------------------------------ tile loader
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, int cvalid, bool vec_ok, float* f) {
+    constexpr int S = Slot<T>::N;
+    if (vec_ok && cvalid >= S) {
+        uint4 u = *reinterpret_cast<const uint4*>(p);
+        Slot<T>::unpack(u, f);
+    } else {
+#pragma unroll
+        for (int e = 0; e < S; ++e) f[e] = (e < cvalid) ? to_f<T>(p[e]) : 0.f;
+    }
+}
+
+// One 16-byte slot (channels c .. c+S-1 of source s) of conv-input pixel (n, y, x), transformed.
+// (y, x) are in the conv's H x W frame and already known to be inside the image.
+template <typename T>
+__device__ __forceinline__ void load_slot(const rd_src_t& s, int g_img, int n, int y, int x, int H, int W, int c,
+                                          float* v) {
+    constexpr int S = Slot<T>::N;
+    const int C = s.C;
+    const int cvalid = C - c;                     // > 0 guaranteed by caller
+    const bool vec_ok = (C % S) == 0;
+    const int g = s.g_fixed >= 0 ? s.g_fixed : g_img;
+    const T* base = reinterpret_cast<const T*>(s.ptr);
+    n += s.n_off;
+    float sc[S], sh[S];
+    if (s.mode != RD_SRC_RAW) {
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            bool ok = e < cvalid;
+            sc[e] = ok ? s.scale[g * C + c + e] : 0.f;
+            sh[e] = ok ? s.shift[g * C + c + e] : 0.f;
+        }
+    }
+    switch (s.mode) {
+    case RD_SRC_RAW: {
+        load_vec<T>(base + ((size_t)(n * H + y) * W + x) * C + c, cvalid, vec_ok, v);
+    } break;
+    case RD_SRC_AFF: {
+        load_vec<T>(base + ((size_t)(n * H + y) * W + x) * C + c, cvalid, vec_ok, v);
+#pragma unroll
+        for (int e = 0; e < S; ++e) v[e] = v[e] * sc[e] + sh[e];
+    } break;
+    case RD_SRC_AFFACT: {
+        load_vec<T>(base + ((size_t)(n * H + y) * W + x) * C + c, cvalid, vec_ok, v);
+#pragma unroll
+        for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * sc[e] + sh[e], s.slope);
+    } break;
+    case RD_SRC_POOL: {
+        const int Hs = 2 * H, Ws = 2 * W;
+        float t[S];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yy = 2 * y + (k >> 1), xx = 2 * x + (k & 1);
+            load_vec<T>(base + ((size_t)(n * Hs + yy) * Ws + xx) * C + c, cvalid, vec_ok, t);
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                float a = act_fn(t[e] * sc[e] + sh[e], s.slope);
+                v[e] = (k == 0) ? a : fmaxf(v[e], a);
+            }
+        }
+    } break;
+    case RD_SRC_UP: {
+        const int Hs = H >> 1, Ws = W >> 1;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        up2_coord(y, Hs, y0, y1, ly);
+        up2_coord(x, Ws, x0, x1, lx);
+        float t00[S], t01[S], t10[S], t11[S];
+        load_vec<T>(base + ((size_t)(n * Hs + y0) * Ws + x0) * C + c, cvalid, vec_ok, t00);
+        load_vec<T>(base + ((size_t)(n * Hs + y0) * Ws + x1) * C + c, cvalid, vec_ok, t01);
+        load_vec<T>(base + ((size_t)(n * Hs + y1) * Ws + x0) * C + c, cvalid, vec_ok, t10);
+        load_vec<T>(base + ((size_t)(n * Hs + y1) * Ws + x1) * C + c, cvalid, vec_ok, t11);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            float top = t00[e] + lx * (t01[e] - t00[e]);
+            float bot = t10[e] + lx * (t11[e] - t10[e]);
+            float u = top + ly * (bot - top);
+            v[e] = act_fn(u * sc[e] + sh[e], s.slope);
+        }
+    } break;
+    case RD_SRC_BNBWD: {
+        const T* zb = reinterpret_cast<const T*>(s.ptr2);
+        const size_t off = ((size_t)(n * H + y) * W + x) * C + c;
+        float gz[S], zz[S];
+        load_vec<T>(base + off, cvalid, vec_ok, gz);
+        load_vec<T>(zb + off, cvalid, vec_ok, zz);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            float q = (e < cvalid) ? s.q[g * C + c + e] : 0.f;
+            v[e] = sc[e] * gz[e] + q * zz[e] + sh[e];
+        }
+    } break;
+    default:
+#pragma unroll
+        for (int e = 0; e < S; ++e) v[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < S; ++e)
+        if (e >= cvalid) v[e] = 0.f;
+}
+
+// slot of concatenated-channel index c of conv-input pixel (n,y,x); zero outside the image / channels
+template <typename T>
+__device__ __forceinline__ uint4 gather_slot(const rd_src_t* src, int nsrc, int Cin, int g, int n, int y, int x, int H,
+                                             int W, int c) {
+    constexpr int S = Slot<T>::N;
+    float v[S];
+#pragma unroll
+    for (int e = 0; e < S; ++e) v[e] = 0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && c < Cin) {
+        if (nsrc == 1 || c < src[0].C)
+            load_slot<T>(src[0], g, n, y, x, H, W, c, v);
+        else
+            load_slot<T>(src[1], g, n, y, x, H, W, c - src[0].C, v);
+    }
+    return Slot<T>::pack(v);
+}
+
+__device__ __forceinline__ GroupMap make_gm(const int32_t* gstart, int G) {
+    GroupMap gm;
+    gm.G = G;
+#pragma unroll
+    for (int i = 0; i <= RD_MAX_GROUPS; ++i) gm.gs[i] = gstart[i];
+    return gm;
+}
+
+// ------------------------------------------------------------------------------------ MFMA atoms
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // one 64-byte chunk = 32 channels = 2 k-steps of 16; lane-half h owns 8 channels per k-step
+    static __device__ __forceinline__ void chunk(const uint4* a_rec, int a_sw, const uint4* b_rec, int b_sw, int h,
+                                                 f32x16& acc) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = ks * 2 + h;
+            uint4 au = a_rec[slot ^ a_sw];
+            uint4 bu = b_rec[slot ^ b_sw];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, au), __builtin_bit_cast(bf16x8, bu),
+                                                          acc, 0, 0, 0);
+        }
+    }
+};
+template <> struct Mma<float> {
+    // one 64-byte chunk = 16 channels; lane-half h owns channels 8h..8h+7 (k order is a permutation,
+    // identical for A and B); 8 x v_mfma_f32_32x32x2_f32
+    static __device__ __forceinline__ void chunk(const uint4* a_rec, int a_sw, const uint4* b_rec, int b_sw, int h,
+                                                 f32x16& acc) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int slot = 2 * h + q;
+            uint4 au = a_rec[slot ^ a_sw];
+            uint4 bu = b_rec[slot ^ b_sw];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au.x), __uint_as_float(bu.x), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au.y), __uint_as_float(bu.y), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au.z), __uint_as_float(bu.z), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au.w), __uint_as_float(bu.w), acc, 0, 0, 0);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------ gradient epilogue
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const float* v, int cvalid, bool vec_ok) {
+    constexpr int S = Slot<T>::N;
+    if (vec_ok && cvalid >= S) {
+        *reinterpret_cast<uint4*>(p) = Slot<T>::pack(v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < S; ++e)
+            if (e < cvalid) p[e] = from_f<T>(v[e]);
+    }
+}
+
+// S channels (one slot) of the gradient w.r.t. a conv input pixel -> gradient w.r.t. the producer's BN
+// output: activation mask, max-pool scatter or upsample-side mask; b1 += g, b2 += g*z per channel.
+template <typename T>
+__device__ __forceinline__ void grad_item(const rd_dst_t& d, int g_img, int n, int y, int x, int H, int W, int cd,
+                                          const float* da, float* b1, float* b2) {
+    constexpr int S = Slot<T>::N;
+    T* gp = reinterpret_cast<T*>(d.g);
+    const T* zp = reinterpret_cast<const T*>(d.z);
+    const int Cd = d.Cd;
+    const int cvalid = Cd - cd;
+    const bool vec_ok = (Cd % S) == 0;
+    const int gd = d.g_fixed >= 0 ? d.g_fixed : g_img;
+    n += d.n_off;
+    float sc[S], sh[S];
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        const bool ok = (e < cvalid) && d.scale;
+        sc[e] = ok ? d.scale[gd * Cd + cd + e] : 1.f;
+        sh[e] = ok ? d.shift[gd * Cd + cd + e] : 0.f;
+    }
+    if (d.kind == RD_DST_PLAIN) {
+        const size_t idx = ((size_t)(n * H + y) * W + x) * Cd + cd;
+        float z[S], gw[S];
+#pragma unroll
+        for (int e = 0; e < S; ++e) z[e] = 0.f;
+        if (zp) load_vec<T>(zp + idx, cvalid, vec_ok, z);
+        if (d.accumulate) load_vec<T>(gp + idx, cvalid, vec_ok, gw);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const float m = (d.act && zp) ? act_grad(z[e] * sc[e] + sh[e], d.slope) : 1.f;
+            const float gn = da[e] * m;
+            b1[e] += gn;
+            b2[e] += gn * z[e];
+            gw[e] = d.accumulate ? gw[e] + gn : gn;
+        }
+        store_vec<T>(gp + idx, gw, cvalid, vec_ok);
+    } else if (d.kind == RD_DST_POOL) {
+        const int Hd = 2 * H, Wd = 2 * W;
+        float zz[4][S], best[S];
+        int arg[S];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t idx = ((size_t)(n * Hd + 2 * y + (k >> 1)) * Wd + 2 * x + (k & 1)) * Cd + cd;
+            load_vec<T>(zp + idx, cvalid, vec_ok, zz[k]);
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                const float a = act_fn(zz[k][e] * sc[e] + sh[e], d.slope);
+                if (k == 0 || a > best[e]) { best[e] = a; arg[e] = k; }      // first max wins (ATen max_pool2d)
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t idx = ((size_t)(n * Hd + 2 * y + (k >> 1)) * Wd + 2 * x + (k & 1)) * Cd + cd;
+            float gw[S];
+            if (d.accumulate) load_vec<T>(gp + idx, cvalid, vec_ok, gw);
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                float gn = 0.f;
+                if (arg[e] == k) {
+                    gn = da[e] * (d.act ? act_grad(zz[k][e] * sc[e] + sh[e], d.slope) : 1.f);
+                    b1[e] += gn;
+                    b2[e] += gn * zz[k][e];
+                }
+                gw[e] = d.accumulate ? gw[e] + gn : gn;
+            }
+            store_vec<T>(gp + idx, gw, cvalid, vec_ok);
+        }
+    } else if (d.kind == RD_DST_UPY) {
+        const int Hs = H >> 1, Ws = W >> 1;
+        int yy0, yy1, xx0, xx1;
+        float ly, lx;
+        up2_coord(y, Hs, yy0, yy1, ly);
+        up2_coord(x, Ws, xx0, xx1, lx);
+        float t00[S], t01[S], t10[S], t11[S], gw[S];
+        load_vec<T>(zp + ((size_t)(n * Hs + yy0) * Ws + xx0) * Cd + cd, cvalid, vec_ok, t00);
+        load_vec<T>(zp + ((size_t)(n * Hs + yy0) * Ws + xx1) * Cd + cd, cvalid, vec_ok, t01);
+        load_vec<T>(zp + ((size_t)(n * Hs + yy1) * Ws + xx0) * Cd + cd, cvalid, vec_ok, t10);
+        load_vec<T>(zp + ((size_t)(n * Hs + yy1) * Ws + xx1) * Cd + cd, cvalid, vec_ok, t11);
+        const size_t idx = ((size_t)(n * H + y) * W + x) * Cd + cd;
+        if (d.accumulate) load_vec<T>(gp + idx, cvalid, vec_ok, gw);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const float top = t00[e] + lx * (t01[e] - t00[e]), bot = t10[e] + lx * (t11[e] - t10[e]);
+            const float u = top + ly * (bot - top);
+            const float m = d.act ? act_grad(u * sc[e] + sh[e], d.slope) : 1.f;
+            const float gn = da[e] * m;
+            b1[e] += gn;
+            b2[e] += gn * u;
+            gw[e] = d.accumulate ? gw[e] + gn : gn;
+        }
+        store_vec<T>(gp + idx, gw, cvalid, vec_ok);
+    }
+}
+
+// picks dst[0] or dst[1] field by field (lane-varying di): keeps the kernarg struct out of scratch
+__device__ __forceinline__ rd_dst_t select_dst(const rd_conv_t& p, int di) {
+    rd_dst_t d;
+    d.g = di ? p.dst[1].g : p.dst[0].g;
+    d.z = di ? p.dst[1].z : p.dst[0].z;
+    d.scale = di ? p.dst[1].scale : p.dst[0].scale;
+    d.shift = di ? p.dst[1].shift : p.dst[0].shift;
+    d.bstats = di ? p.dst[1].bstats : p.dst[0].bstats;
+    d.kind = di ? p.dst[1].kind : p.dst[0].kind;
+    d.act = di ? p.dst[1].act : p.dst[0].act;
+    d.accumulate = di ? p.dst[1].accumulate : p.dst[0].accumulate;
+    d.Cd = di ? p.dst[1].Cd : p.dst[0].Cd;
+    d.slope = di ? p.dst[1].slope : p.dst[0].slope;
+    d.n_off = di ? p.dst[1].n_off : p.dst[0].n_off;
+    d.g_fixed = di ? p.dst[1].g_fixed : p.dst[0].g_fixed;
+    d.pad_ = 0;
+    return d;
+}
+
+// ------------------------------------------------------------------------------------ conv kernel
+template <typename T, int TAPS, int NB>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
+    constexpr int S = Slot<T>::N;
+    constexpr int CK = 4 * S;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int NT = NB * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* s_in = reinterpret_cast<uint4*>(smem);          // [PH*PW][4]
+    uint4* s_w = s_in + PH * PW * 4;                       // [TAPS][NT][4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int x0 = (blockIdx.x % tiles_x) * TW, y0 = (blockIdx.x / tiles_x) * TH;
+    const int n0 = blockIdx.y * NT;
+    const int n = blockIdx.z;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+    const int g = group_of(gm, n);
+    const int H = p.H, W = p.W;
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    const T* wbase = reinterpret_cast<const T*>(p.w);
+    for (int c0 = 0; c0 < p.CinPad; c0 += CK) {
+        __syncthreads();
+        for (int idx = tid; idx < PH * PW * 4; idx += 256) {
+            const int pix = idx >> 2, s = idx & 3;
+            const int py = pix / PW, px = pix - py * PW;
+            const uint4 u = gather_slot<T>(p.src, p.nsrc, p.Cin, g, n, y0 - HALO + py, x0 - HALO + px, H, W, c0 + s * S);
+            s_in[pix * 4 + (s ^ ((pix >> 2) & 3))] = u;
+        }
+        for (int idx = tid; idx < TAPS * NT * 4; idx += 256) {
+            const int s = idx & 3, rec = idx >> 2;
+            const int nn = rec % NT, tap = rec / NT;
+            const uint4 u = *reinterpret_cast<const uint4*>(wbase + ((size_t)(tap * p.CoutPad + n0 + nn) * p.CinPad + c0 + s * S));
+            s_w[rec * 4 + (s ^ ((nn >> 2) & 3))] = u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int pix = (wave * 2 + mb + kh) * PW + li + kw;
+                const uint4* a_rec = s_in + pix * 4;
+                const int a_sw = (pix >> 2) & 3;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int nn = nb * 32 + li;
+                    Mma<T>::chunk(a_rec, a_sw, s_w + (tap * NT + nn) * 4, (nn >> 2) & 3, h, acc[mb][nb]);
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // C/D layout of the 32x32 MFMA: column (N, channel) = lane&31, row (M, pixel) = (r&3)+8*(r>>2)+4*(lane>>5).
+    // Each 32-channel block is staged through LDS as fp32 [256 pixels][32 ch] so that the global side runs
+    // on 16-byte slots (coalesced stores; vector reads of z / old gradients in the backward epilogues).
+    constexpr int SL = 32 / S;                             // slots per 32 channels
+    float* s_out = reinterpret_cast<float*>(smem);         // [TH*TW][32]
+    float* s_red = s_out + TH * TW * 32;                   // [32][2]
+    T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        __syncthreads();
+        const int cb = n0 + nb * 32;
+        if (tid < 64) s_red[tid] = 0.f;
+        {
+            const int cch = cb + li;
+            const bool cok = cch < p.Cout;
+            const float bsv = (p.emode == 0 && cok && p.bias) ? p.bias[cch] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int y = y0 + wave * 2 + mb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = acc[mb][nb][r] + bsv;
+                    s_out[((wave * 2 + mb) * TW + col) * 32 + li] = v;
+                    if (cok && y < H && x0 + col < W) { s1 += v; s2 += v * v; }
+                }
+            }
+            __syncthreads();
+            if (p.emode == 0 && p.stats) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0 && cok) {
+                    atomicAdd(&s_red[li * 2 + 0], s1);
+                    atomicAdd(&s_red[li * 2 + 1], s2);
+                }
+            }
+        }
+        const int sl = tid % SL;                           // constant per thread: 256 % SL == 0
+        const int c = cb + sl * S;
+        float b1[S], b2[S];
+#pragma unroll
+        for (int e = 0; e < S; ++e) b1[e] = b2[e] = 0.f;
+        const int di = (p.emode == 1 && c >= p.c_split) ? 1 : 0;
+        const rd_dst_t d = select_dst(p, di);
+        const int cd = c - (di ? p.c_split : 0);
+        if (c < p.Cout) {
+            for (int idx = tid; idx < TH * TW * SL; idx += 256) {
+                const int pix = idx / SL;
+                const int y = y0 + pix / TW, x = x0 + pix % TW;
+                if (y >= H || x >= W) continue;
+                float v[S];
+#pragma unroll
+                for (int e = 0; e < S; e += 4) {
+                    const float4 f = *reinterpret_cast<const float4*>(s_out + pix * 32 + sl * S + e);
+                    v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
+                }
+                if (p.emode == 0)
+                    store_vec<T>(out + ((size_t)(n * H + y) * W + x) * p.Cout + c, v, p.Cout - c, (p.Cout % S) == 0);
+                else if (d.kind != RD_DST_NONE)
+                    grad_item<T>(d, g, n, y, x, H, W, cd, v, b1, b2);
+            }
+            if (p.emode == 1 && d.kind != RD_DST_NONE && d.bstats) {
+#pragma unroll
+                for (int e = 0; e < S; ++e) {
+                    atomicAdd(&s_red[(sl * S + e) * 2 + 0], b1[e]);
+                    atomicAdd(&s_red[(sl * S + e) * 2 + 1], b2[e]);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 32 && cb + tid < p.Cout) {
+            if (p.emode == 0) {
+                if (p.stats) {
+                    atomicAdd(&p.stats[((size_t)g * p.Cout + cb + tid) * 2 + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&p.stats[((size_t)g * p.Cout + cb + tid) * 2 + 1], s_red[tid * 2 + 1]);
+                }
+            } else {
+                const int cch = cb + tid;
+                const int dj = cch >= p.c_split ? 1 : 0;
+                const rd_dst_t dd = select_dst(p, dj);
+                if (dd.kind != RD_DST_NONE && dd.bstats) {
+                    const int cdd = cch - (dj ? p.c_split : 0);
+                    const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
+                    atomicAdd(&dd.bstats[((size_t)gd * dd.Cd + cdd) * 2 + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&dd.bstats[((size_t)gd * dd.Cd + cdd) * 2 + 1], s_red[tid * 2 + 1]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int TAPS, int NB>
+int launch_conv(const rd_conv_t& p, hipStream_t st) {
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    size_t lds = (size_t)(PH * PW * 4 + TAPS * NB * 32 * 4) * sizeof(uint4);
+    const size_t lds_epi = (size_t)(TH * TW * 32 + 64) * sizeof(float);
+    if (lds < lds_epi) lds = lds_epi;
+    dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), p.CoutPad / (NB * 32), p.N);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, TAPS, NB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_kernel<T, TAPS, NB>), grid, dim3(256), lds, st, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int dispatch_conv(const rd_conv_t& p, hipStream_t st) {
+    const bool nb2 = (p.CoutPad % 64) == 0;
+    if (p.taps == 9) return nb2 ? launch_conv<T, 9, 2>(p, st) : launch_conv<T, 9, 1>(p, st);
+    return nb2 ? launch_conv<T, 1, 2>(p, st) : launch_conv<T, 1, 1>(p, st);
+}
+
+// ------------------------------------------------------------------------------------ wgrad kernel
+// dW[tap][n][c] = sum over pixels of dz[p][n] * a[p + tap][c];  M = n (Cout), N = c (Cin), K = pixels.
+// A workgroup owns a (MB*32) x (NB*32) x TAPS block of dW and walks pixel tiles with stride gridDim.x;
+// its 4 waves are MB*NB output blocks x KS = 4/(MB*NB) pixel-row splits.  Each wave stores its partial
+// block; a second kernel reduces the splits in a fixed order (deterministic, no atomics).
+template <typename T, int TAPS, int MB, int NB>
+__global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+    constexpr int S = Slot<T>::N;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int CA = NB * 32, CZ = MB * 32;
+    constexpr int KS = 4 / (MB * NB);
+    constexpr int ROWS = TH / KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* s_a = reinterpret_cast<T*>(smem);                   // [PH*PW][CA]
+    T* s_z = s_a + PH * PW * CA;                           // [TH*TW][CZ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int kq = wave / (MB * NB), blk = wave % (MB * NB);
+    const int mb = blk / NB, nb = blk % NB;
+    const int nbase = blockIdx.y * CZ, cbase = blockIdx.z * CA;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int H = p.H, W = p.W;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int n = tile / (tiles_x * tiles_y);
+        const int trem = tile - n * tiles_x * tiles_y;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        const int g = group_of(gm, n);
+        __syncthreads();
+        for (int idx = tid; idx < PH * PW * (CA / S); idx += 256) {
+            const int pix = idx / (CA / S), s = idx % (CA / S);
+            const int py = pix / PW, px = pix - py * PW;
+            const uint4 u = gather_slot<T>(p.a, p.na, p.Cin, g, n, y0 - HALO + py, x0 - HALO + px, H, W, cbase + s * S);
+            *reinterpret_cast<uint4*>(s_a + pix * CA + s * S) = u;
+        }
+        for (int idx = tid; idx < TH * TW * (CZ / S); idx += 256) {
+            const int pix = idx / (CZ / S), s = idx % (CZ / S);
+            const int py = pix / TW, px = pix - py * TW;
+            const uint4 u = gather_slot<T>(&p.dz, 1, p.Cout, g, n, y0 + py, x0 + px, H, W, nbase + s * S);
+            *reinterpret_cast<uint4*>(s_z + pix * CZ + s * S) = u;
+        }
+        __syncthreads();
+        if constexpr (sizeof(T) == 2) {
+            const unsigned short* za = reinterpret_cast<const unsigned short*>(s_z) + mb * 32 + li;
+            const unsigned short* aa = reinterpret_cast<const unsigned short*>(s_a) + nb * 32 + li;
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int row = kq + rr * KS;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int px0 = ks * 16 + 8 * h;                 // this lane-half's 8 pixels (k = 8h+e)
+                    unsigned zp[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned lo = za[(row * TW + px0 + 2 * e) * CZ];
+                        const unsigned hi = za[(row * TW + px0 + 2 * e + 1) * CZ];
+                        zp[e] = lo | (hi << 16);
+                    }
+                    const bf16x8 afrag = __builtin_bit_cast(bf16x8, make_uint4(zp[0], zp[1], zp[2], zp[3]));
+#pragma unroll
+                    for (int kh = 0; kh < (TAPS == 9 ? 3 : 1); ++kh) {
+                        const int base = (row + kh) * PW + px0;     // halo coords: input pixel = output pixel + tap
+                        if constexpr (TAPS == 9) {
+                            unsigned v[10];
+#pragma unroll
+                            for (int e = 0; e < 10; ++e) v[e] = aa[(base + e) * CA];
+                            unsigned P[5], Q[4];
+#pragma unroll
+                            for (int e = 0; e < 5; ++e) P[e] = v[2 * e] | (v[2 * e + 1] << 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) Q[e] = v[2 * e + 1] | (v[2 * e + 2] << 16);
+                            acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                afrag, __builtin_bit_cast(bf16x8, make_uint4(P[0], P[1], P[2], P[3])), acc[kh * 3 + 0], 0, 0, 0);
+                            acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                afrag, __builtin_bit_cast(bf16x8, make_uint4(Q[0], Q[1], Q[2], Q[3])), acc[kh * 3 + 1], 0, 0, 0);
+                            acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                afrag, __builtin_bit_cast(bf16x8, make_uint4(P[1], P[2], P[3], P[4])), acc[kh * 3 + 2], 0, 0, 0);
+                        } else {
+                            unsigned P[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                P[e] = (unsigned)aa[(base + 2 * e) * CA] | ((unsigned)aa[(base + 2 * e + 1) * CA] << 16);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                afrag, __builtin_bit_cast(bf16x8, make_uint4(P[0], P[1], P[2], P[3])), acc[0], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+            const float* za = reinterpret_cast<const float*>(s_z) + mb * 32 + li;
+            const float* aa = reinterpret_cast<const float*>(s_a) + nb * 32 + li;
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int row = kq + rr * KS;
+#pragma unroll 4
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    const int px = 2 * s2 + h;                       // k = h
+                    const float av = za[(row * TW + px) * CZ];
+#pragma unroll
+                    for (int tap = 0; tap < TAPS; ++tap) {
+                        const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+                        const float bv = aa[((row + kh) * PW + px + kw) * CA];
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // partial[split][tap][n][c]
+    const int split = blockIdx.x * KS + kq;
+    float* out = p.partial + (size_t)split * TAPS * CoutPadW * CinPadW;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ccol = cbase + nb * 32 + li;
+            out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
+        }
+}
+
+__global__ void wgrad_reduce_kernel(const float* partial, float* dW, int nsplit, int taps, int Cout, int Cin, int CoutPadW,
+                                    int CinPadW, float beta) {
+    const int total = taps * Cout * Cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i % Cin, n = (i / Cin) % Cout, tap = i / (Cin * Cout);
+        const size_t stride = (size_t)taps * CoutPadW * CinPadW;
+        const float* src = partial + ((size_t)tap * CoutPadW + n) * CinPadW + c;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += src[k * stride];
+        float* d = dW + ((size_t)n * Cin + c) * taps + tap;
+        *d = (beta != 0.f ? beta * *d : 0.f) + s;
+    }
+}
+
+struct WgradGeom {
+    int MB, NB, KS, CoutPadW, CinPadW, gx, total_tiles, nsplit;
+};
+
+template <typename T>
+WgradGeom wgrad_geom(const rd_wgrad_t& p) {
+    WgradGeom g;
+    const int cout32 = (p.Cout + 31) / 32, cin32 = (p.Cin + 31) / 32;
+    // fp32 keeps 32x32 blocks (LDS budget); bf16 uses 64-wide tiles where the layer has them
+    g.MB = (sizeof(T) == 2 && cout32 % 2 == 0) ? 2 : 1;
+    g.NB = (sizeof(T) == 2 && cin32 % 2 == 0) ? 2 : 1;
+    g.KS = 4 / (g.MB * g.NB);
+    g.CoutPadW = cout32 * 32;
+    g.CinPadW = cin32 * 32;
+    g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    const int pairs = (g.CoutPadW / (g.MB * 32)) * (g.CinPadW / (g.NB * 32));
+    int gx = (768 + pairs - 1) / pairs;                     // ~3 workgroups per CU in flight
+    if (gx > g.total_tiles) gx = g.total_tiles;
+    if (gx < 1) gx = 1;
+    g.gx = gx;
+    g.nsplit = gx * g.KS;
+    return g;
+}
+
+template <typename T, int TAPS, int MB, int NB>
+int launch_wgrad(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    const size_t lds = (size_t)(PH * PW * NB * 32 + TH * TW * MB * 32) * sizeof(T);
+    dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, MB, NB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<T, TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int dispatch_wgrad(const rd_wgrad_t& p, hipStream_t st) {
+    const WgradGeom g = wgrad_geom<T>(p);
+    int e;
+#define RD_WG(TAPS_)                                                                 \
+    if (g.MB == 2 && g.NB == 2) e = launch_wgrad<T, TAPS_, 2, 2>(p, g, st);          \
+    else if (g.MB == 2) e = launch_wgrad<T, TAPS_, 2, 1>(p, g, st);                  \
+    else if (g.NB == 2) e = launch_wgrad<T, TAPS_, 1, 2>(p, g, st);                  \
+    else e = launch_wgrad<T, TAPS_, 1, 1>(p, g, st);
+    if (p.taps == 9) { RD_WG(9) } else { RD_WG(1) }
+#undef RD_WG
+    if (e) return e;
+    const int total = p.taps * p.Cout * p.Cin;
+    int blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
+                       g.CoutPadW, g.CinPadW, p.beta);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ void pack_weights_kernel(const float* w, T* out, int Cout, int Cin, int taps, int transpose, int RowPad, int ColPad) {
+    // forward:   out[tap][n<RowPad(Cout)][c<ColPad(Cin)]   = w[n][c][tap]
+    // transpose: out[tap'][c<RowPad(Cin)][n<ColPad(Cout)]  = w[n][c][taps-1-tap']
+    const int total = taps * RowPad * ColPad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int col = i % ColPad, row = (i / ColPad) % RowPad, tap = i / (ColPad * RowPad);
+        float v = 0.f;
+        if (!transpose) {
+            if (row < Cout && col < Cin) v = w[((size_t)row * Cin + col) * taps + tap];
+        } else {
+            if (row < Cin && col < Cout) v = w[((size_t)col * Cin + row) * taps + (taps - 1 - tap)];
+        }
+        out[i] = from_f<T>(v);
+    }
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t rd_packed_elems(int Cout, int Cin, int taps, int transpose, int dtype) {
+    const int ck = dtype == RD_BF16 ? 32 : 16;
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    return (int64_t)taps * round_up(rows, 32) * round_up(cols, ck);
+}
+
+int rd_pack_weights(const float* w_oihw, void* packed, int Cout, int Cin, int taps, int transpose, int dtype, void* stream) {
+    const int ck = dtype == RD_BF16 ? 32 : 16;
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    const int RowPad = round_up(rows, 32), ColPad = round_up(cols, ck);
+    const int total = taps * RowPad * ColPad;
+    int blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, w_oihw, (bf16_t*)packed, Cout, Cin, taps,
+                           transpose, RowPad, ColPad);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w_oihw, (float*)packed, Cout, Cin, taps,
+                           transpose, RowPad, ColPad);
+    return (int)hipGetLastError();
+}
+
+int rd_conv(const rd_conv_t* p, int dtype, void* stream) {
+    if (!p || (p->taps != 9 && p->taps != 1) || p->G < 1 || p->G > RD_MAX_GROUPS || p->nsrc < 1 || p->nsrc > 2) return -1;
+    const int ck = dtype == RD_BF16 ? 32 : 16;
+    if (p->CinPad % ck || p->CoutPad % 32 || p->CinPad < p->Cin || p->CoutPad < p->Cout) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == RD_BF16 ? dispatch_conv<bf16_t>(*p, st) : dispatch_conv<float>(*p, st);
+}
+
+int64_t rd_wgrad_workspace(const rd_wgrad_t* p, int dtype) {
+    const WgradGeom g = dtype == RD_BF16 ? wgrad_geom<bf16_t>(*p) : wgrad_geom<float>(*p);
+    return (int64_t)g.nsplit * p->taps * g.CoutPadW * g.CinPadW * (int64_t)sizeof(float);
+}
+
+int rd_wgrad(const rd_wgrad_t* p, int dtype, void* stream) {
+    if (!p || (p->taps != 9 && p->taps != 1) || p->G < 1 || p->G > RD_MAX_GROUPS || p->na < 1 || p->na > 2) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == RD_BF16 ? dispatch_wgrad<bf16_t>(*p, st) : dispatch_wgrad<float>(*p, st);
+}
+
+}  // extern "C"

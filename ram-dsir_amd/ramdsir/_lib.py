@@ -1,0 +1,125 @@
+"""ctypes binding of libramdsir_hip.so (include/ramdsir.h).  No fallback: if the HIP library is
+missing or a call fails, this raises -- the product path never routes around the kernels."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libramdsir_hip.so')
+
+RD_F32, RD_BF16 = 0, 1
+MAXG = 8
+SRC_RAW, SRC_AFF, SRC_AFFACT, SRC_POOL, SRC_UP, SRC_BNBWD = range(6)
+DST_PLAIN, DST_POOL, DST_UPY, DST_NONE = range(4)
+
+vp, fp, i32, i64, f32 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class RdSrc(C.Structure):
+    _fields_ = [('ptr', vp), ('ptr2', vp), ('scale', fp), ('shift', fp), ('q', fp), ('mode', i32), ('C', i32),
+                ('slope', f32), ('n_off', i32), ('g_fixed', i32), ('pad_', i32)]
+
+
+class RdDst(C.Structure):
+    _fields_ = [('g', vp), ('z', vp), ('scale', fp), ('shift', fp), ('bstats', fp), ('kind', i32), ('act', i32),
+                ('accumulate', i32), ('Cd', i32), ('slope', f32), ('n_off', i32), ('g_fixed', i32), ('pad_', i32)]
+
+
+class RdConv(C.Structure):
+    _fields_ = [('src', RdSrc * 2), ('nsrc', i32), ('taps', i32), ('w', vp), ('bias', fp), ('CinPad', i32),
+                ('CoutPad', i32), ('N', i32), ('H', i32), ('W', i32), ('Cin', i32), ('Cout', i32), ('G', i32),
+                ('gstart', i32 * (MAXG + 1)), ('emode', i32), ('out', vp), ('stats', fp), ('dst', RdDst * 2),
+                ('c_split', i32), ('pad_', i32)]
+
+
+class RdWgrad(C.Structure):
+    _fields_ = [('a', RdSrc * 2), ('na', i32), ('taps', i32), ('dz', RdSrc), ('N', i32), ('H', i32), ('W', i32),
+                ('Cin', i32), ('Cout', i32), ('G', i32), ('gstart', i32 * (MAXG + 1)), ('partial', fp), ('dW', fp),
+                ('beta', f32), ('pad_', i32)]
+
+
+class RdBnFwd(C.Structure):
+    _fields_ = [('stats', fp), ('scale', fp), ('shift', fp), ('mean', fp), ('invstd', fp), ('gamma', fp * MAXG),
+                ('beta', fp * MAXG), ('running_mean', fp * MAXG), ('running_var', fp * MAXG),
+                ('num_batches_tracked', vp * MAXG), ('count', f32 * MAXG), ('C', i32), ('G', i32), ('eps', f32),
+                ('momentum', f32), ('training', i32), ('pad_', i32)]
+
+
+class RdBnBwd(C.Structure):
+    _fields_ = [('bstats', fp), ('mean', fp), ('invstd', fp), ('gamma', fp * MAXG), ('dgamma', fp * MAXG),
+                ('dbeta', fp * MAXG), ('P', fp), ('Q', fp), ('R', fp), ('count', f32 * MAXG), ('C', i32), ('G', i32)]
+
+
+class RdSegLoss(C.Structure):
+    _fields_ = [('logits', vp), ('target', vp), ('dlogits', vp), ('partial', fp), ('losses_out', fp), ('B', i32),
+                ('H', i32), ('W', i32), ('K', i32), ('kind', i32), ('consistency', i32), ('cons_weight', f32),
+                ('pad_', i32)]
+
+
+class RdAdam(C.Structure):
+    _fields_ = [('param', fp), ('grad', fp), ('exp_avg', fp), ('exp_avg_sq', fp), ('n', i64), ('n_half_lr', i64),
+                ('iter', vp), ('hyper_out', fp), ('base_lr', f32), ('total_iters', i32), ('beta1', f32),
+                ('beta2', f32), ('eps', f32), ('pad_', i32)]
+
+
+_SIGS = {
+    'rd_conv': (C.c_int, [C.POINTER(RdConv), C.c_int, vp]),
+    'rd_wgrad_workspace': (i64, [C.POINTER(RdWgrad), C.c_int]),
+    'rd_wgrad': (C.c_int, [C.POINTER(RdWgrad), C.c_int, vp]),
+    'rd_pack_weights': (C.c_int, [fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rd_packed_elems': (i64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'rd_bn_finalize_fwd': (C.c_int, [C.POINTER(RdBnFwd), vp]),
+    'rd_bn_finalize_bwd': (C.c_int, [C.POINTER(RdBnBwd), vp]),
+    'rd_up_stats': (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
+    'rd_up_bwd': (C.c_int, [vp, vp, vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32),
+                            C.c_int, vp]),
+    'rd_nchw_to_nhwc': (C.c_int, [fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rd_nhwc_to_nchw': (C.c_int, [vp, fp, fp, fp, C.c_int, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(i32), C.c_int, vp]),
+    'rd_grad_in': (C.c_int, [fp, vp, vp, fp, fp, fp, C.c_int, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_int, C.POINTER(i32), C.c_int, vp]),
+    'rd_colsum': (C.c_int, [vp, fp, fp, i64, C.c_int, f32, C.c_int, vp]),
+    'rd_seg_loss_workspace': (i64, [C.POINTER(RdSegLoss)]),
+    'rd_seg_loss': (C.c_int, [C.POINTER(RdSegLoss), C.c_int, vp]),
+    'rd_rec_loss': (C.c_int, [vp, vp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), f32,
+                              C.c_int, vp]),
+    'rd_rec_loss_workspace': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'rd_adam_step': (C.c_int, [C.POINTER(RdAdam), vp]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """The loaded library (cached).  Raises if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libramdsir_hip.so is not built: run `make -C ram-dsir_amd/csrc` '
+                               '(or __graft_entry__.build()); there is no CPU fallback')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(err, what=''):
+    if err != 0:
+        raise RuntimeError('ramdsir HIP call failed (%s): error %d' % (what, err))
+
+
+def gstart_array(gs):
+    a = (i32 * (MAXG + 1))()
+    for i, v in enumerate(gs):
+        a[i] = int(v)
+    return a
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,500 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against a plain torch fp32 restatement of the
+same op on the same seeded inputs (fp32: 2e-5 x RMS; bf16: inputs pre-rounded to bf16, 2.5e-2 x RMS =
+a few bf16 ulps of the accumulated value -- the tolerance is the one written in gpu_util.RTOL)."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from ramdsir import _lib as L          # noqa: E402
+import gpu_util as U                   # noqa: E402
+
+DTYPES = ['f32', 'bf16']
+
+
+def _params(G, Cc, gen):
+    return 1.0 + 0.3 * torch.randn(G, Cc, generator=gen), 0.2 * torch.randn(G, Cc, generator=gen)
+
+
+def _conv_desc(keep, srcs, w, bias, N, H, W, gstart, dtype, taps, transpose=False):
+    p = L.RdConv()
+    for i, s in enumerate(srcs):
+        p.src[i] = s
+    p.nsrc, p.taps = len(srcs), taps
+    wp = keep(U.pack_weights(w, dtype, transpose))
+    p.w = wp.data_ptr()
+    Cout, Cin = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    p.bias = keep(U.fdev(bias)).data_ptr() if bias is not None else None
+    p.CinPad, p.CoutPad = U.pads(Cout, Cin, dtype)
+    p.N, p.H, p.W, p.Cin, p.Cout = N, H, W, Cin, Cout
+    p.G = len(gstart) - 1
+    p.gstart = L.gstart_array(gstart)
+    return p
+
+
+# ------------------------------------------------------------------------------------ conv forward
+FWD_CASES = [
+    # name, taps, [(mode, C)], Cout, N, H, W, gstart, slope
+    ('img3_16', 9, [(L.SRC_RAW, 3)], 16, 2, 20, 36, [0, 2], 0.0),
+    ('aff16_16', 9, [(L.SRC_AFF, 16)], 16, 3, 16, 32, [0, 1, 3], 0.0),
+    ('affact32_64', 9, [(L.SRC_AFFACT, 32)], 64, 2, 25, 25, [0, 1, 2], 0.0),
+    ('leaky64_32', 9, [(L.SRC_AFFACT, 64)], 32, 2, 9, 40, [0, 2], 0.01),
+    ('pool16_32', 9, [(L.SRC_POOL, 16)], 32, 2, 12, 20, [0, 1, 2], 0.0),
+    ('up32_32', 9, [(L.SRC_UP, 32)], 32, 2, 16, 24, [0, 2], 0.0),
+    ('cat16_up16_32', 9, [(L.SRC_AFFACT, 16), (L.SRC_UP, 16)], 32, 2, 16, 40, [0, 1, 2], 0.0),
+    ('cat64_up64_128', 9, [(L.SRC_AFFACT, 64), (L.SRC_UP, 64)], 128, 2, 10, 12, [0, 1, 2], 0.0),
+    ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, [0, 1, 2], 0.0),
+    ('out16_3', 9, [(L.SRC_AFFACT, 16)], 3, 3, 8, 32, [0, 1, 2, 3], 0.0),
+    ('c256_256', 9, [(L.SRC_AFFACT, 256)], 256, 2, 6, 7, [0, 1, 2], 0.0),
+    ('k1_128_64', 1, [(L.SRC_AFFACT, 128)], 64, 2, 10, 34, [0, 1, 2], 0.0),
+    ('k1_16_16', 1, [(L.SRC_AFFACT, 16)], 16, 2, 20, 20, [0, 2], 0.0),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', FWD_CASES, ids=[c[0] for c in FWD_CASES])
+def test_conv_forward(case, dtype):
+    name, taps, src_spec, Cout, N, H, W, gstart, slope = case
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    keep = U.Keep()
+    G = len(gstart) - 1
+    srcs, virt = [], []
+    for mode, Cc in src_spec:
+        hs, ws = (2 * H, 2 * W) if mode == L.SRC_POOL else ((H // 2, W // 2) if mode == L.SRC_UP else (H, W))
+        x = U.rnd(torch.randn(N, Cc, hs, ws, generator=gen), dtype)
+        sc, sh = _params(G, Cc, gen)
+        srcs.append(U.make_src(keep, x, mode, dtype, sc, sh, slope))
+        virt.append(U.virtual_input(x, mode, sc, sh, slope, gstart))
+    a = torch.cat(virt, 1)
+    Cin = a.shape[1]
+    k = 3 if taps == 9 else 1
+    w = U.rnd(torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * taps), dtype)
+    bias = 0.1 * torch.randn(Cout, generator=gen)
+    ref = F.conv2d(a, w, bias, padding=k // 2)
+    p = _conv_desc(keep, srcs, w, bias, N, H, W, gstart, dtype, taps)
+    out = torch.full((N, H, W, Cout), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
+    stats = torch.zeros(G, Cout, 2, device=U.dev())
+    p.emode, p.out, p.stats = 0, out.data_ptr(), stats.data_ptr()
+    L.check(L.lib().rd_conv(C.byref(p), U.DT[dtype][0], None), name)
+    torch.cuda.synchronize()
+    U.assert_close(U.from_nhwc(out), ref, dtype, name)
+    ref_stats = torch.stack([torch.stack([ref[gstart[g]:gstart[g + 1]].sum((0, 2, 3)),
+                                          ref[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1) for g in range(G)])
+    npx = H * W * max(gstart[g + 1] - gstart[g] for g in range(G))
+    # sums of npx values: compare relative to sqrt(npx)*rms (stats are taken from the fp32 accumulators)
+    assert float((stats.cpu() - ref_stats).abs().max()) <= (1e-3 if dtype == 'bf16' else 1e-4) * npx * float(ref.abs().max() + 1) ** 2
+
+
+# ------------------------------------------------------------------------------------ conv gradient (dgrad + epilogues)
+GRAD_CASES = [
+    # name, taps, [(kind, Cd, act)], Cout_fwd, N, H, W, gstart, slope, accumulate
+    ('plain32', 9, [(L.DST_PLAIN, 32, 1)], 32, 2, 12, 36, [0, 1, 2], 0.0, 0),
+    ('plain16_noact_acc', 9, [(L.DST_PLAIN, 16, 0)], 16, 3, 9, 20, [0, 1, 3], 0.0, 1),
+    ('pool16_acc', 9, [(L.DST_POOL, 16, 1)], 32, 2, 8, 20, [0, 1, 2], 0.0, 1),
+    ('pool64_leaky', 9, [(L.DST_POOL, 64, 1)], 64, 2, 5, 6, [0, 2], 0.01, 0),
+    ('upy32', 9, [(L.DST_UPY, 32, 1)], 32, 2, 12, 16, [0, 1, 2], 0.0, 0),
+    ('cat16_upy16', 9, [(L.DST_PLAIN, 16, 1), (L.DST_UPY, 16, 1)], 32, 2, 16, 40, [0, 1, 2], 0.0, 0),
+    ('cat64_upy64', 9, [(L.DST_PLAIN, 64, 1), (L.DST_UPY, 64, 1)], 128, 2, 10, 12, [0, 1, 2], 0.0, 0),
+    ('k1_plain128', 1, [(L.DST_PLAIN, 128, 1)], 64, 2, 10, 34, [0, 1, 2], 0.0, 0),
+    ('from_out2', 9, [(L.DST_PLAIN, 32, 1)], 2, 2, 16, 33, [0, 1, 2], 0.0, 0),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', GRAD_CASES, ids=[c[0] for c in GRAD_CASES])
+def test_conv_gradient_epilogues(case, dtype):
+    name, taps, dst_spec, Cout, N, H, W, gstart, slope, accumulate = case
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000 + 1)
+    keep = U.Keep()
+    G = len(gstart) - 1
+    k = 3 if taps == 9 else 1
+    ys, virt, prod = [], [], []
+    for kind, Cd, act in dst_spec:
+        hs, ws = (2 * H, 2 * W) if kind == L.DST_POOL else ((H // 2, W // 2) if kind == L.DST_UPY else (H, W))
+        z = U.rnd(torch.randn(N, Cd, hs, ws, generator=gen), dtype)
+        sc, sh = _params(G, Cd, gen)
+        scn, shn = U.group_rows(sc, gstart, N), U.group_rows(sh, gstart, N)
+        zz = F.interpolate(z, scale_factor=2, mode='bilinear', align_corners=False) if kind == L.DST_UPY else z
+        y = (zz * scn + shn).requires_grad_(True)
+        a = U.act(y, slope) if act else y
+        if kind == L.DST_POOL:
+            a = F.max_pool2d(a, 2)
+        ys.append(y)
+        virt.append(a)
+        prod.append((z, zz, sc, sh))
+    a = torch.cat(virt, 1)
+    Cin = a.shape[1]
+    w = U.rnd(torch.randn(Cout, Cin, k, k, generator=gen) / np.sqrt(Cin * taps), dtype)
+    dz = U.rnd(torch.randn(N, Cout, H, W, generator=gen), dtype)
+    (F.conv2d(a, w, None, padding=k // 2) * dz).sum().backward()
+    src = U.make_src(keep, dz, L.SRC_RAW, dtype)
+    p = _conv_desc(keep, [src], w, None, N, H, W, gstart, dtype, taps, transpose=True)
+    p.emode = 1
+    p.c_split = dst_spec[0][1] if len(dst_spec) == 2 else Cin
+    outs = []
+    for i, (kind, Cd, act) in enumerate(dst_spec):
+        z, zz, sc, sh = prod[i]
+        d = L.RdDst()
+        old = U.rnd(torch.randn(ys[i].shape, generator=gen), dtype) if accumulate else torch.zeros(ys[i].shape)
+        gbuf = keep(U.nhwc(old if accumulate else torch.full(ys[i].shape, float('nan')), dtype))
+        bst = keep(torch.zeros(G, Cd, 2, device=U.dev()))
+        d.g, d.z = gbuf.data_ptr(), keep(U.nhwc(z, dtype)).data_ptr()
+        d.scale, d.shift = keep(U.fdev(sc)).data_ptr(), keep(U.fdev(sh)).data_ptr()
+        d.bstats, d.kind, d.act, d.accumulate, d.Cd, d.slope, d.n_off, d.g_fixed = bst.data_ptr(), kind, act, accumulate, Cd, slope, 0, -1
+        p.dst[i] = d
+        outs.append((gbuf, bst, old))
+    if len(dst_spec) == 1:
+        p.dst[1].kind = L.DST_NONE
+    L.check(L.lib().rd_conv(C.byref(p), U.DT[dtype][0], None), name)
+    torch.cuda.synchronize()
+    for i, (kind, Cd, act) in enumerate(dst_spec):
+        gbuf, bst, old = outs[i]
+        gref = ys[i].grad
+        U.assert_close(U.from_nhwc(gbuf), gref + old, dtype, '%s.dst%d' % (name, i), scale=2.0)
+        zz = prod[i][1]
+        rs = torch.stack([torch.stack([gref[gstart[g]:gstart[g + 1]].sum((0, 2, 3)),
+                                       (gref * zz)[gstart[g]:gstart[g + 1]].sum((0, 2, 3))], -1) for g in range(G)])
+        tol = (3e-2 if dtype == 'bf16' else 2e-4) * float(rs.abs().max() + gref.abs().sum() / Cd / G * 0.05 + 1e-3)
+        assert float((bst.cpu() - rs).abs().max()) <= tol, '%s bstats' % name
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_bnbwd_loader_and_image_offsets(dtype):
+    """dz = P*g + Q*z + R folded into the read; n_off / g_fixed as the rec decoder uses them on x5."""
+    gen = torch.Generator().manual_seed(11)
+    keep = U.Keep()
+    N, H, W, Cz, Ca = 2, 9, 20, 32, 64
+    gstart = [0, 1, 2]
+    g = U.rnd(torch.randn(N, Cz, H, W, generator=gen), dtype)
+    z = U.rnd(torch.randn(N, Cz, H, W, generator=gen), dtype)
+    P, R = _params(2, Cz, gen)
+    Q = 0.1 * torch.randn(2, Cz, generator=gen)
+    dz = g * U.group_rows(P, gstart, N) + z * U.group_rows(Q, gstart, N) + U.group_rows(R, gstart, N)
+    w = U.rnd(torch.randn(Cz, Ca, 3, 3, generator=gen) / 24, dtype)
+    # destination: a 4-image producer tensor; this launch covers its images 2..3 which live in producer group 1
+    zprod = U.rnd(torch.randn(4, Ca, H, W, generator=gen), dtype)
+    sc, sh = _params(2, Ca, gen)
+    y = (zprod[2:4] * sc[1][None, :, None, None] + sh[1][None, :, None, None]).requires_grad_(True)
+    (F.conv2d(F.relu(y), w, None, padding=1) * dz).sum().backward()
+    src = U.make_src(keep, g, L.SRC_BNBWD, dtype, scale=P, shift=R, ptr2=z, q=Q)
+    p = _conv_desc(keep, [src], w, None, N, H, W, gstart, dtype, 9, transpose=True)
+    p.emode, p.c_split = 1, Ca
+    old = U.rnd(torch.randn(4, Ca, H, W, generator=gen), dtype)
+    gbuf = U.nhwc(old, dtype)
+    bst = torch.zeros(2, Ca, 2, device=U.dev())
+    d = L.RdDst()
+    d.g, d.z = gbuf.data_ptr(), keep(U.nhwc(zprod, dtype)).data_ptr()
+    d.scale, d.shift = keep(U.fdev(sc)).data_ptr(), keep(U.fdev(sh)).data_ptr()
+    d.bstats, d.kind, d.act, d.accumulate, d.Cd, d.slope, d.n_off, d.g_fixed = bst.data_ptr(), L.DST_PLAIN, 1, 1, Ca, 0.0, 2, 1
+    p.dst[0] = d
+    p.dst[1].kind = L.DST_NONE
+    L.check(L.lib().rd_conv(C.byref(p), U.DT[dtype][0], None), 'bnbwd')
+    torch.cuda.synchronize()
+    ref = old.clone()
+    ref[2:4] += y.grad
+    U.assert_close(U.from_nhwc(gbuf), ref, dtype, 'bnbwd', scale=3.0)
+    assert float(bst[0].abs().max()) == 0.0                 # only producer group 1 was touched
+    np.testing.assert_allclose(bst[1, :, 0].cpu(), y.grad.sum((0, 2, 3)), rtol=0, atol=(0.5 if dtype == 'bf16' else 5e-3))
+
+
+# ------------------------------------------------------------------------------------ wgrad
+WG_CASES = [
+    ('img3_16', 9, [(L.SRC_RAW, 3)], 16, 2, 20, 36, 0),
+    ('affact32_64', 9, [(L.SRC_AFFACT, 32)], 64, 3, 25, 25, 1),
+    ('pool16_32', 9, [(L.SRC_POOL, 16)], 32, 2, 12, 20, 1),
+    ('cat16_up16_32', 9, [(L.SRC_AFFACT, 16), (L.SRC_UP, 16)], 32, 2, 16, 40, 1),
+    ('c128_128', 9, [(L.SRC_AFFACT, 128)], 128, 2, 10, 12, 1),
+    ('c256_128', 9, [(L.SRC_AFFACT, 256)], 128, 2, 6, 7, 1),
+    ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, 0),
+    ('k1_128_64', 1, [(L.SRC_AFFACT, 128)], 64, 2, 10, 34, 0),
+    ('k1_16_16', 1, [(L.SRC_AFFACT, 16)], 16, 2, 20, 20, 0),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_wgrad(case, dtype):
+    name, taps, src_spec, Cout, N, H, W, bnbwd = case
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000 + 2)
+    keep = U.Keep()
+    gstart = [0, 1, N]
+    G = 2
+    k = 3 if taps == 9 else 1
+    p = L.RdWgrad()
+    virt = []
+    for i, (mode, Cc) in enumerate(src_spec):
+        hs, ws = (2 * H, 2 * W) if mode == L.SRC_POOL else ((H // 2, W // 2) if mode == L.SRC_UP else (H, W))
+        x = U.rnd(torch.randn(N, Cc, hs, ws, generator=gen), dtype)
+        sc, sh = _params(G, Cc, gen)
+        p.a[i] = U.make_src(keep, x, mode, dtype, sc, sh, 0.0)
+        virt.append(U.virtual_input(x, mode, sc, sh, 0.0, gstart))
+    a = torch.cat(virt, 1)
+    Cin = a.shape[1]
+    gz = U.rnd(torch.randn(N, Cout, H, W, generator=gen), dtype)
+    if bnbwd:
+        z = U.rnd(torch.randn(N, Cout, H, W, generator=gen), dtype)
+        P, R = _params(G, Cout, gen)
+        Q = 0.1 * torch.randn(G, Cout, generator=gen)
+        dz = gz * U.group_rows(P, gstart, N) + z * U.group_rows(Q, gstart, N) + U.group_rows(R, gstart, N)
+        p.dz = U.make_src(keep, gz, L.SRC_BNBWD, dtype, scale=P, shift=R, ptr2=z, q=Q)
+    else:
+        dz = gz
+        p.dz = U.make_src(keep, gz, L.SRC_RAW, dtype)
+    w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    (F.conv2d(a, w, None, padding=k // 2) * dz).sum().backward()
+    p.na, p.taps, p.N, p.H, p.W, p.Cin, p.Cout, p.G = len(src_spec), taps, N, H, W, Cin, Cout, G
+    p.gstart = L.gstart_array(gstart)
+    ws_bytes = L.lib().rd_wgrad_workspace(C.byref(p), U.DT[dtype][0])
+    part = torch.empty(ws_bytes // 4, device=U.dev())
+    old = torch.randn(Cout, Cin, k, k, generator=gen)
+    dW = old.clone().to(U.dev())
+    p.partial, p.dW, p.beta = part.data_ptr(), dW.data_ptr(), 1.0
+    L.check(L.lib().rd_wgrad(C.byref(p), U.DT[dtype][0], None), name)
+    torch.cuda.synchronize()
+    U.assert_close(dW.cpu() - old, w.grad, dtype, name)
+
+
+# ------------------------------------------------------------------------------------ BN finalize
+def test_bn_finalize_forward_and_backward():
+    gen = torch.Generator().manual_seed(3)
+    Cc, gstart = 24, [0, 2, 5]
+    G, N, H, W = 2, 5, 6, 7
+    x = torch.randn(N, Cc, H, W, generator=gen) * 2 + 0.5
+    gam, bet = _params(1, Cc, gen)
+    stats = torch.stack([torch.stack([x[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), x[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
+                         for g in range(G)]).to(U.dev())
+    bufs = {k: torch.zeros(G, Cc, device=U.dev()) for k in ('scale', 'shift', 'mean', 'invstd')}
+    gd, bd = gam[0].to(U.dev()), bet[0].to(U.dev())
+    rm, rv = torch.zeros(Cc, device=U.dev()), torch.ones(Cc, device=U.dev())
+    nbt = torch.zeros((), dtype=torch.long, device=U.dev())
+    p = L.RdBnFwd()
+    p.stats = stats.data_ptr()
+    for k, t in bufs.items():
+        setattr(p, k, t.data_ptr())
+    for g in range(G):                                     # both groups share one BN, like the two encoder passes
+        p.gamma[g], p.beta[g], p.running_mean[g], p.running_var[g] = gd.data_ptr(), bd.data_ptr(), rm.data_ptr(), rv.data_ptr()
+        p.num_batches_tracked[g] = nbt.data_ptr()
+        p.count[g] = (gstart[g + 1] - gstart[g]) * H * W
+    p.C, p.G, p.eps, p.momentum, p.training = Cc, G, 1e-5, 0.1, 1
+    L.check(L.lib().rd_bn_finalize_fwd(C.byref(p), None), 'bnf')
+    torch.cuda.synchronize()
+    bn = torch.nn.BatchNorm2d(Cc)
+    bn.weight.data, bn.bias.data = gam[0].clone(), bet[0].clone()
+    bn.train()
+    for g in range(G):
+        xs = x[gstart[g]:gstart[g + 1]]
+        ref = bn(xs)
+        got = xs * bufs['scale'][g].cpu()[None, :, None, None] + bufs['shift'][g].cpu()[None, :, None, None]
+        np.testing.assert_allclose(got.detach(), ref.detach(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rm.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    assert int(nbt) == 2
+    # eval mode: running statistics
+    p.training = 0
+    L.check(L.lib().rd_bn_finalize_fwd(C.byref(p), None), 'bnf-eval')
+    torch.cuda.synchronize()
+    bn.eval()
+    got = x * bufs['scale'][0].cpu()[None, :, None, None] + bufs['shift'][0].cpu()[None, :, None, None]
+    np.testing.assert_allclose(got, bn(x).detach(), rtol=1e-4, atol=1e-5)
+    assert int(nbt) == 2
+    # backward coefficients: dz = P*g + Q*z + R against autograd through F.batch_norm, group by group
+    p.training = 1
+    rm.zero_(); rv.fill_(1)
+    L.check(L.lib().rd_bn_finalize_fwd(C.byref(p), None), 'bnf2')
+    gy = torch.randn(N, Cc, H, W, generator=gen)
+    bst = torch.stack([torch.stack([gy[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), (gy * x)[gstart[g]:gstart[g + 1]].sum((0, 2, 3))], -1)
+                       for g in range(G)]).to(U.dev())
+    q = L.RdBnBwd()
+    dgam, dbet = torch.zeros(Cc, device=U.dev()), torch.zeros(Cc, device=U.dev())
+    PQR = [torch.zeros(G, Cc, device=U.dev()) for _ in range(3)]
+    q.bstats, q.mean, q.invstd = bst.data_ptr(), bufs['mean'].data_ptr(), bufs['invstd'].data_ptr()
+    q.P, q.Q, q.R = (t.data_ptr() for t in PQR)
+    for g in range(G):
+        q.gamma[g], q.dgamma[g], q.dbeta[g] = gd.data_ptr(), dgam.data_ptr(), dbet.data_ptr()
+        q.count[g] = (gstart[g + 1] - gstart[g]) * H * W
+    q.C, q.G = Cc, G
+    L.check(L.lib().rd_bn_finalize_bwd(C.byref(q), None), 'bnb')
+    torch.cuda.synchronize()
+    gw = gam[0].clone().requires_grad_(True)
+    gb = bet[0].clone().requires_grad_(True)
+    for g in range(G):
+        xs = x[gstart[g]:gstart[g + 1]].clone().requires_grad_(True)
+        (F.batch_norm(xs, None, None, gw, gb, True) * gy[gstart[g]:gstart[g + 1]]).sum().backward()
+        P, Q, R = (t[g].cpu()[None, :, None, None] for t in PQR)
+        got = P * gy[gstart[g]:gstart[g + 1]] + Q * xs.detach() + R
+        np.testing.assert_allclose(got, xs.grad, rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(dgam.cpu(), gw.grad, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(dbet.cpu(), gb.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_upsample_stats_and_backward(dtype):
+    gen = torch.Generator().manual_seed(5)
+    N, Cc, h, w = 3, 32, 7, 9
+    gstart = [0, 1, 3]
+    t = U.rnd(torch.randn(N, Cc, h, w, generator=gen), dtype).requires_grad_(True)
+    y = F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False)
+    td = U.nhwc(t.detach(), dtype)
+    stats = torch.zeros(2, Cc, 2, device=U.dev())
+    gs = L.gstart_array(gstart)
+    L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats), N, h, w, Cc, 2, gs, U.DT[dtype][0], None), 'upstats')
+    torch.cuda.synchronize()
+    ref = torch.stack([torch.stack([y[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), y[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
+                       for g in range(2)]).detach()
+    np.testing.assert_allclose(stats.cpu(), ref, rtol=1e-3, atol=1e-2)
+    P, R = _params(2, Cc, gen)
+    Q = 0.1 * torch.randn(2, Cc, generator=gen)
+    g2 = U.rnd(torch.randn(N, Cc, 2 * h, 2 * w, generator=gen), dtype)
+    dzh = g2 * U.group_rows(P, gstart, N) + y.detach() * U.group_rows(Q, gstart, N) + U.group_rows(R, gstart, N)
+    (y * dzh).sum().backward()
+    dt = torch.full((N, h, w, Cc), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
+    g2d = U.nhwc(g2, dtype)
+    Pd, Qd, Rd = U.fdev(P), U.fdev(Q), U.fdev(R)
+    L.check(L.lib().rd_up_bwd(L.ptr(g2d), L.ptr(td), L.ptr(dt), L.ptr(Pd), L.ptr(Qd), L.ptr(Rd), N, h, w, Cc, 2, gs,
+                              U.DT[dtype][0], None), 'upbwd')
+    torch.cuda.synchronize()
+    U.assert_close(U.from_nhwc(dt), t.grad, dtype, 'up_bwd')
+
+
+# ------------------------------------------------------------------------------------ losses / Adam / layout
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cons', [0, 1, 2])
+def test_seg_loss_fundus(dtype, cons):
+    from oracle import losses as OL
+    gen = torch.Generator().manual_seed(21 + cons)
+    B, K, H, W = 3, 2, 12, 20
+    lg = U.rnd(2 * torch.randn(2 * B, K, H, W, generator=gen), dtype).requires_grad_(True)
+    mask = (torch.rand(B, K, H, W, generator=gen) > 0.6).float()
+    p1, p2 = torch.sigmoid(lg[:B]), torch.sigmoid(lg[B:])
+    comps = [OL.bce(p1, mask), OL.dice_loss(p1, mask), OL.bce(p2, mask), OL.dice_loss(p2, mask)]
+    c = OL.kd(p2, p1) if cons == 1 else (F.mse_loss(p2, p1) if cons == 2 else torch.zeros(()))
+    total = sum(comps) + 0.5 * c
+    total.backward()
+    _run_seg(lg, mask.to(U.dev()), B, K, H, W, 0, cons, dtype, comps + [c, total])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cons', [1, 2])
+def test_seg_loss_prostate(dtype, cons):
+    from oracle import losses as OL
+    gen = torch.Generator().manual_seed(31 + cons)
+    B, K, H, W = 2, 2, 10, 18
+    lg = U.rnd(2 * torch.randn(2 * B, K, H, W, generator=gen), dtype).requires_grad_(True)
+    tgt = (torch.rand(B, H, W, generator=gen) > 0.7).long()
+    p1, p2 = torch.softmax(lg[:B], 1), torch.softmax(lg[B:], 1)
+    comps = [F.cross_entropy(lg[:B], tgt), OL.dice_loss_multi(p1, tgt, K, 0), F.cross_entropy(lg[B:], tgt), OL.dice_loss_multi(p2, tgt, K, 0)]
+    c = OL.kd(p2, p1) if cons == 1 else F.mse_loss(p2, p1)
+    total = sum(comps) + 0.5 * c
+    total.backward()
+    _run_seg(lg, tgt.to(U.dev()), B, K, H, W, 1, cons, dtype, comps + [c, total])
+
+
+def _run_seg(lg, target_dev, B, K, H, W, kind, cons, dtype, ref_losses):
+    lgd = U.nhwc(lg.detach(), dtype)
+    dl = torch.full((2 * B, H, W, K), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
+    losses = torch.zeros(8, device=U.dev())
+    p = L.RdSegLoss()
+    p.logits, p.target, p.dlogits, p.losses_out = lgd.data_ptr(), target_dev.data_ptr(), dl.data_ptr(), losses.data_ptr()
+    p.B, p.H, p.W, p.K, p.kind, p.consistency, p.cons_weight = B, H, W, K, kind, cons, 0.5
+    ws = torch.empty(L.lib().rd_seg_loss_workspace(C.byref(p)) // 4, device=U.dev())
+    p.partial = ws.data_ptr()
+    L.check(L.lib().rd_seg_loss(C.byref(p), U.DT[dtype][0], None), 'segloss')
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses[:6].cpu(), [float(v) for v in ref_losses], rtol=2e-5, atol=1e-7)
+    U.assert_close(U.from_nhwc(dl), lg.grad, dtype, 'dlogits', scale=0.5 if dtype == 'bf16' else 5.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_rec_loss(dtype):
+    gen = torch.Generator().manual_seed(41)
+    B, Cc, H, W = 5, 3, 8, 12
+    gstart = [0, 2, 3, 5]
+    lg = U.rnd(torch.randn(B, Cc, H, W, generator=gen), dtype).requires_grad_(True)
+    tgt = U.rnd(torch.rand(B, Cc, H, W, generator=gen) * 2 - 1, dtype)
+    mses = [F.mse_loss(torch.tanh(lg[gstart[g]:gstart[g + 1]]), tgt[gstart[g]:gstart[g + 1]]) for g in range(3)]
+    (0.1 * sum(mses)).backward()
+    lgd, td = U.nhwc(lg.detach(), dtype), U.nhwc(tgt, dtype)
+    dl = torch.empty_like(lgd)
+    out = torch.zeros(3, device=U.dev())
+    ws = torch.empty(L.lib().rd_rec_loss_workspace(B, H, W, Cc) // 4, device=U.dev())
+    L.check(L.lib().rd_rec_loss(L.ptr(lgd), L.ptr(td), L.ptr(dl), L.ptr(out), L.ptr(ws), B, H, W, Cc, 3, L.gstart_array(gstart), 0.1,
+                                U.DT[dtype][0], None), 'recloss')
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu(), [float(m) for m in mses], rtol=2e-5)
+    U.assert_close(U.from_nhwc(dl), lg.grad, dtype, 'rec dlogits', scale=0.5 if dtype == 'bf16' else 5.0)
+
+
+def test_adam_matches_torch_optim_with_poly_lr():
+    gen = torch.Generator().manual_seed(51)
+    n, n_enc, base_lr, total = 1000, 300, 2e-3, 40
+    p0 = torch.randn(n, generator=gen)
+    pe = torch.nn.Parameter(p0[:n_enc].clone())
+    po = torch.nn.Parameter(p0[n_enc:].clone())
+    opt = torch.optim.Adam([{'params': [pe], 'lr': base_lr / 2}, {'params': [po], 'lr': base_lr}], lr=base_lr, betas=(0.9, 0.999))
+    pd, m, v = p0.clone().to(U.dev()), torch.zeros(n, device=U.dev()), torch.zeros(n, device=U.dev())
+    it = torch.zeros((), dtype=torch.int32, device=U.dev())
+    hyper = torch.zeros(4, device=U.dev())
+    a = L.RdAdam()
+    a.param, a.exp_avg, a.exp_avg_sq, a.n, a.n_half_lr = pd.data_ptr(), m.data_ptr(), v.data_ptr(), n, n_enc
+    a.iter, a.hyper_out, a.base_lr, a.total_iters, a.beta1, a.beta2, a.eps = it.data_ptr(), hyper.data_ptr(), base_lr, total, 0.9, 0.999, 1e-8
+    for step in range(5):
+        g = torch.randn(n, generator=gen)
+        pe.grad, po.grad = g[:n_enc].clone(), g[n_enc:].clone()
+        opt.step()
+        lr = base_lr * (1 - step / total) ** 0.9           # train.py:289-293, written after the step
+        opt.param_groups[0]['lr'], opt.param_groups[1]['lr'] = lr / 2, lr
+        gd = g.to(U.dev())
+        a.grad = gd.data_ptr()
+        L.check(L.lib().rd_adam_step(C.byref(a), None), 'adam')
+        torch.cuda.synchronize()
+        ref = torch.cat([pe.data, po.data])
+        np.testing.assert_allclose(pd.cpu(), ref, rtol=1e-5, atol=2e-7)
+    assert int(it) == 5
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_layout_boundary_kernels(dtype):
+    gen = torch.Generator().manual_seed(61)
+    N, Cc, H, W = 3, 16, 9, 11
+    gstart = [0, 1, 3]
+    x = U.rnd(torch.randn(N, Cc, H, W, generator=gen), dtype)
+    xd = x.to(U.dev())
+    y = torch.empty(N, H, W, Cc, dtype=U.DT[dtype][1], device=U.dev())
+    L.check(L.lib().rd_nchw_to_nhwc(L.ptr(xd), L.ptr(y), N, Cc, H, W, U.DT[dtype][0], None), 'to_nhwc')
+    torch.cuda.synchronize()
+    assert torch.equal(U.from_nhwc(y), x)
+    sc, sh = _params(2, Cc, gen)
+    scd, shd = U.fdev(sc), U.fdev(sh)
+    back = torch.empty(N, Cc, H, W, device=U.dev())
+    gs = L.gstart_array(gstart)
+    L.check(L.lib().rd_nhwc_to_nchw(L.ptr(y), L.ptr(back), L.ptr(scd), L.ptr(shd), 1, 0.0, N, Cc, H, W, 2, gs, U.DT[dtype][0], None), 'to_nchw')
+    torch.cuda.synchronize()
+    ref = F.relu(x * U.group_rows(sc, gstart, N) + U.group_rows(sh, gstart, N))
+    np.testing.assert_allclose(back.cpu(), ref, rtol=1e-6, atol=1e-6)
+    # gradient entering from torch: mask + BN-backward sums
+    dy = torch.randn(N, Cc, H, W, generator=gen)
+    old = U.rnd(torch.randn(N, Cc, H, W, generator=gen), dtype)
+    gbuf = U.nhwc(old, dtype)
+    bst = torch.zeros(2, Cc, 2, device=U.dev())
+    dyd = dy.to(U.dev())
+    L.check(L.lib().rd_grad_in(L.ptr(dyd), L.ptr(y), L.ptr(gbuf), L.ptr(scd), L.ptr(shd), L.ptr(bst), 1, 0.0, 1, N, Cc, H, W, 2, gs,
+                               U.DT[dtype][0], None), 'grad_in')
+    torch.cuda.synchronize()
+    gnew = dy * (ref > 0).float()
+    U.assert_close(U.from_nhwc(gbuf), old + gnew, dtype, 'grad_in')
+    rs = torch.stack([torch.stack([gnew[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), (gnew * x)[gstart[g]:gstart[g + 1]].sum((0, 2, 3))], -1)
+                      for g in range(2)])
+    np.testing.assert_allclose(bst.cpu(), rs, rtol=1e-3, atol=1e-3)
+    # column sums (bias gradient of out1)
+    t3 = U.rnd(torch.randn(2, 3, 20, 30, generator=gen), dtype)
+    t3d = U.nhwc(t3, dtype)
+    outc = torch.ones(3, device=U.dev())
+    wsb = torch.empty(8192, device=U.dev())
+    L.check(L.lib().rd_colsum(L.ptr(t3d), L.ptr(outc), L.ptr(wsb), 2 * 20 * 30, 3, 1.0, U.DT[dtype][0], None), 'colsum')
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(outc.cpu(), 1 + t3.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
