@@ -126,6 +126,17 @@ int rd_pack_weights(const float* w_oihw, void* packed, int Cout, int Cin, int ta
                     int dtype, void* stream);
 int64_t rd_packed_elems(int Cout, int Cin, int taps, int transpose, int dtype);
 
+/* every conv of the network in ONE launch (run after each optimizer step): entry e reads the OIHW
+ * weight at params+src_off and owns packed elements [start, next start) at packed+dst_off. */
+typedef struct {
+    int64_t src_off;     /* floats into the parameter arena */
+    int64_t dst_off;     /* elements into the packed arena (== start) */
+    int64_t start;
+    int32_t Cout, Cin, taps, transpose, RowPad, ColPad;
+} rd_pack_entry_t;
+int rd_pack_weights_batched(const float* params, void* packed, const rd_pack_entry_t* table_dev, int n_entries,
+                            int64_t total, int dtype, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d (train: batch statistics; eval: running statistics) split into "finalize" launches

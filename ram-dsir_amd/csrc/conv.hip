@@ -707,6 +707,30 @@ __global__ void pack_weights_kernel(const float* w, T* out, int Cout, int Cin, i
     }
 }
 
+// all convs of the network in one launch: entry e owns packed elements [start_e, start_{e+1})
+template <typename T>
+__global__ void pack_weights_batched_kernel(const float* params, T* packed, const rd_pack_entry_t* tab, int n_entries,
+                                            int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_entries - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid].start <= i) lo = mid; else hi = mid - 1;
+        }
+        const rd_pack_entry_t e = tab[lo];
+        const int j = (int)(i - e.start);
+        const int col = j % e.ColPad, row = (j / e.ColPad) % e.RowPad, tap = j / (e.ColPad * e.RowPad);
+        const float* w = params + e.src_off;
+        float v = 0.f;
+        if (!e.transpose) {
+            if (row < e.Cout && col < e.Cin) v = w[((size_t)row * e.Cin + col) * e.taps + tap];
+        } else {
+            if (row < e.Cin && col < e.Cout) v = w[((size_t)col * e.Cin + row) * e.taps + (e.taps - 1 - tap)];
+        }
+        packed[e.dst_off + j] = from_f<T>(v);
+    }
+}
+
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 }  // namespace
@@ -733,6 +757,21 @@ int rd_pack_weights(const float* w_oihw, void* packed, int Cout, int Cin, int ta
     else
         hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w_oihw, (float*)packed, Cout, Cin, taps,
                            transpose, RowPad, ColPad);
+    return (int)hipGetLastError();
+}
+
+int rd_pack_weights_batched(const float* params, void* packed, const rd_pack_entry_t* table_dev, int n_entries, int64_t total,
+                            int dtype, void* stream) {
+    if (n_entries < 1 || total < 1) return -1;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, st, params, (bf16_t*)packed, table_dev,
+                           n_entries, total);
+    else
+        hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3((int)blocks), dim3(256), 0, st, params, (float*)packed, table_dev,
+                           n_entries, total);
     return (int)hipGetLastError();
 }
 

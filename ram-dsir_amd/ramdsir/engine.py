@@ -1,0 +1,534 @@
+"""Host-side execution engine: turns the RAM-DSIR network (code/networks/unet.py) into a static list of
+HIP launches over preallocated HBM buffers.
+
+Design (MI355X-first):
+  * activations / gradients are NHWC in `dtype` (bf16 or fp32); every conv output is stored RAW
+    (pre-BatchNorm); the BN affine + activation + max-pool / bilinear x2 / concat of the reference graph
+    live in the tile loaders of the consuming conv ("normalise on read") -- no intermediate tensor of
+    the reference between two convs is ever materialised;
+  * images that share BatchNorm statistics form a *group*; the two encoder/seg-decoder passes of a
+    training step run as ONE batch of 2B images with 2 groups, the per-domain restoration-decoder calls
+    as ONE batch with one group per domain (DomainSpecificBatchNorm2d);
+  * the 1x1 conv of ConvU / ConvU_Rec is evaluated below the upsample (it commutes with bilinear
+    interpolation); BN2 statistics are still those of the upsampled tensor (rd_up_stats);
+  * backward: dgrad epilogues write the gradient w.r.t. the producer's BN output (activation mask,
+    max-pool scatter, skip accumulation) and the two BN-backward sums; BN backward itself is the
+    per-channel P*g+Q*z+R folded into the reads of the next dgrad / wgrad.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+EPS = 1e-5
+MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------------ specs
+def _conv_spec(out, name, cin, cout, k):
+    out.append((name + '.weight', (cout, cin, k, k), 'param', torch.float32))
+    out.append((name + '.bias', (cout,), 'param', torch.float32))
+
+
+def _bn_spec(out, name, c):
+    out.append((name + '.weight', (c,), 'param', torch.float32))
+    out.append((name + '.bias', (c,), 'param', torch.float32))
+    out.append((name + '.running_mean', (c,), 'buffer', torch.float32))
+    out.append((name + '.running_var', (c,), 'buffer', torch.float32))
+    out.append((name + '.num_batches_tracked', (), 'buffer', torch.int64))
+
+
+def _norm_spec(out, name, c, num_domains):
+    if num_domains is None:
+        _bn_spec(out, name, c)
+    else:
+        for d in range(num_domains):
+            _bn_spec(out, '%s.bns.%d' % (name, d), c)
+
+
+def encoder_specs(c=3, n=16):
+    """state_dict layout of networks.unet.Encoder (unet.py:248-255): 105 entries at n=16."""
+    out = []
+    ch = [c, n, 2 * n, 4 * n, 8 * n, 16 * n]
+    for l in range(1, 6):
+        for j, ci in ((1, ch[l - 1]), (2, ch[l]), (3, ch[l])):
+            _conv_spec(out, 'convd%d.conv%d' % (l, j), ci, ch[l], 3)
+            _bn_spec(out, 'convd%d.bn%d' % (l, j), ch[l])
+    return out
+
+
+def decoder_specs(n=16, num_classes=2):
+    """networks.unet.Decoder (unet.py:273-281)."""
+    out = []
+    for l, planes, first in ((4, 16 * n, True), (3, 8 * n, False), (2, 4 * n, False), (1, 2 * n, False)):
+        p = 'convu%d' % l
+        if not first:
+            _conv_spec(out, p + '.conv1', 2 * planes, planes, 3)
+            _bn_spec(out, p + '.bn1', planes)
+        _conv_spec(out, p + '.conv2', planes, planes // 2, 1)
+        _bn_spec(out, p + '.bn2', planes // 2)
+        _conv_spec(out, p + '.conv3', planes, planes, 3)
+        _bn_spec(out, p + '.bn3', planes)
+    _conv_spec(out, 'out1', 2 * n, num_classes, 3)
+    return out
+
+
+def rec_decoder_specs(n=16, num_classes=3, num_domains=None):
+    """networks.unet.Rec_Decoder (unet.py:299-307); norm='dsbn' when num_domains is given."""
+    out = []
+    for l, planes in ((4, 16 * n), (3, 8 * n), (2, 4 * n), (1, 2 * n)):
+        p, h = 'convu%d' % l, planes // 2
+        _conv_spec(out, p + '.conv1', planes, h, 3)
+        _norm_spec(out, p + '.bn1', h, num_domains)
+        _conv_spec(out, p + '.conv2', h, h, 1)
+        _norm_spec(out, p + '.bn2', h, num_domains)
+        _conv_spec(out, p + '.conv3', h, h, 3)
+        _norm_spec(out, p + '.bn3', h, num_domains)
+    _conv_spec(out, 'out1', n, num_classes, 3)
+    return out
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+class ParamBank:
+    """Flat fp32 arenas (parameters, gradients, Adam moments) for a list of modules, in the reference's
+    ``parameters()`` order, plus the BN buffers; tensors handed out are views, so an optimizer step
+    on the arena is an optimizer step on every nn.Parameter."""
+
+    def __init__(self, modules, device):
+        # modules: list of (module_name, specs)
+        self.device = device
+        self.index = {}             # (module, key) -> (offset, shape)
+        self.module_range = {}
+        off = 0
+        for mname, specs in modules:
+            start = off
+            for key, shape, kind, _ in specs:
+                if kind == 'param':
+                    self.index[(mname, key)] = (off, shape)
+                    off += _numel(shape)
+            self.module_range[mname] = (start, off)
+        self.n = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.buffers = {}
+        for mname, specs in modules:
+            for key, shape, kind, dt in specs:
+                if kind == 'buffer':
+                    if key.endswith('running_var'):
+                        t = torch.ones(shape, dtype=dt, device=device)
+                    else:
+                        t = torch.zeros(shape, dtype=dt, device=device)
+                    self.buffers[(mname, key)] = t
+
+    def view(self, arena, mname, key):
+        off, shape = self.index[(mname, key)]
+        return arena[off:off + _numel(shape)].view(shape)
+
+    def p(self, mname, key):
+        return self.view(self.params, mname, key)
+
+    def g(self, mname, key):
+        return self.view(self.grads, mname, key)
+
+    def b(self, mname, key):
+        return self.buffers[(mname, key)]
+
+    def ensure_adam(self):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.params)
+            self.exp_avg_sq = torch.zeros_like(self.params)
+
+
+# ------------------------------------------------------------------------------------------------ graph
+class Norm:
+    """One normalisation site: per-group parameter views (DSBN: one BN per group; shared BN: the same
+    views in every group)."""
+
+    def __init__(self, bank, mname, name, groups_to_domain=None):
+        self.bank, self.mname, self.name = bank, mname, name
+        self.groups_to_domain = groups_to_domain      # None: plain BN shared by all groups
+
+    def key(self, g, leaf):
+        if self.groups_to_domain is None:
+            return '%s.%s' % (self.name, leaf)
+        return '%s.bns.%d.%s' % (self.name, self.groups_to_domain[g], leaf)
+
+    def param(self, g, leaf):
+        return self.bank.p(self.mname, self.key(g, leaf))
+
+    def grad(self, g, leaf):
+        return self.bank.g(self.mname, self.key(g, leaf))
+
+    def buf(self, g, leaf):
+        return self.bank.b(self.mname, self.key(g, leaf))
+
+
+class Act:
+    """A stored raw tensor plus the pending (virtual) BatchNorm + activation applied by its readers."""
+
+    def __init__(self, plan, N, H, W, Cc, norm=None, act=False, up=False, name=''):
+        self.plan, self.N, self.H, self.W, self.C = plan, N, H, W, Cc
+        self.norm, self.act, self.up, self.name = norm, act, up, name
+        self.buf = plan.alloc_act((N, H, W, Cc))
+        self.g = None                 # gradient w.r.t. the BN output (hi-res when up)
+        self.g_written = False
+        G = plan.G
+        if norm is not None:
+            self.stats = plan.alloc_stat(G * Cc * 2)
+            self.bstats = plan.alloc_stat(G * Cc * 2)
+            self.scale, self.shift = plan.alloc_f32(G * Cc), plan.alloc_f32(G * Cc)
+            self.mean, self.invstd = plan.alloc_f32(G * Cc), plan.alloc_f32(G * Cc)
+            self.P, self.Q, self.R = plan.alloc_f32(G * Cc), plan.alloc_f32(G * Cc), plan.alloc_f32(G * Cc)
+        else:
+            self.stats = self.bstats = self.scale = self.shift = None
+
+    def grad_buf(self):
+        if self.g is None:
+            Hh, Ww = (2 * self.H, 2 * self.W) if self.up else (self.H, self.W)
+            self.g = self.plan.alloc_act((self.N, Hh, Ww, self.C))
+        return self.g
+
+
+class ConvNode:
+    def __init__(self, mname, name, inputs, out, taps, Cin, Cout, has_bias_grad):
+        self.mname, self.name, self.inputs, self.out = mname, name, inputs, out
+        self.taps, self.Cin, self.Cout = taps, Cin, Cout
+        self.has_bias_grad = has_bias_grad          # out1 convs: live bias (no BN behind it)
+
+
+class Plan:
+    """Buffers + launch lists for one batch geometry (N images in G groups at H x W)."""
+
+    def __init__(self, bank, dtype, N, gstart, slope=0.0, training=True):
+        self.bank, self.dtype = bank, dtype
+        self.dt = L.RD_BF16 if dtype == torch.bfloat16 else L.RD_F32
+        self.device = bank.device
+        self.N, self.gstart, self.G = N, list(gstart), len(gstart) - 1
+        self.slope, self.training = slope, training
+        self.nodes = []
+        self.keep = []
+        self._stat_chunks = []
+        self.fwd, self.bwd = [], []
+        self.ws_bytes = 0
+        self.gs_arr = L.gstart_array(self.gstart)
+
+    # ---- allocation
+    def alloc_act(self, shape):
+        t = torch.zeros(shape, dtype=self.dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def alloc_f32(self, n):
+        t = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def alloc_stat(self, n):
+        self._stat_chunks.append(n)
+        return ('stat', len(self._stat_chunks) - 1)
+
+    def finalize_stats(self):
+        total = sum(self._stat_chunks)
+        self.stat_arena = torch.zeros(max(total, 1), dtype=torch.float32, device=self.device)
+        offs, o = [], 0
+        for n in self._stat_chunks:
+            offs.append(o)
+            o += n
+        self._stat_off = offs
+
+    def stat_ptr(self, handle):
+        return self.stat_arena.data_ptr() + 4 * self._stat_off[handle[1]]
+
+    def stat_view(self, handle, G, Cc):
+        o = self._stat_off[handle[1]]
+        return self.stat_arena[o:o + G * Cc * 2].view(G, Cc, 2)
+
+    # ---- graph construction
+    def conv(self, mname, name, inputs, Cout, taps, norm=None, act=False, up_out=False, H=None, W=None, N=None):
+        """inputs: list of (Act, mode, n_off, g_fixed).  Output dims: H x W of the conv itself."""
+        Cin = sum(a.C for a, _, _, _ in inputs)
+        out = Act(self, N if N is not None else self.N, H, W, Cout, norm=norm, act=act, up=up_out, name='%s.%s' % (mname, name))
+        node = ConvNode(mname, name, inputs, out, taps, Cin, Cout, norm is None)
+        self.nodes.append(node)
+        return out
+
+    # ---- descriptor helpers
+    def _src(self, a, mode, n_off, g_fixed):
+        s = L.RdSrc()
+        s.ptr = a.buf.data_ptr()
+        if mode != L.SRC_RAW:
+            s.scale, s.shift = a.scale.data_ptr(), a.shift.data_ptr()
+        s.mode, s.C, s.slope, s.n_off, s.g_fixed = mode, a.C, self.slope, n_off, g_fixed
+        return s
+
+    def _dz_src(self, node):
+        """Source descriptor of the gradient w.r.t. this conv's output."""
+        o = node.out
+        s = L.RdSrc()
+        s.C, s.slope, s.n_off, s.g_fixed = o.C, 0.0, 0, -1
+        if o.norm is None or o.up:
+            s.ptr, s.mode = (o.dt_buf if o.up else o.grad_buf()).data_ptr(), L.SRC_RAW
+        else:
+            s.ptr, s.ptr2, s.mode = o.grad_buf().data_ptr(), o.buf.data_ptr(), L.SRC_BNBWD
+            s.scale, s.shift, s.q = o.P.data_ptr(), o.R.data_ptr(), o.Q.data_ptr()
+        return s
+
+    def build(self, wpack):
+        """wpack: WeightPack giving packed-weight pointers per (module, conv name)."""
+        lib = L.lib()
+        self.finalize_stats()
+        dt = self.dt
+        ws_need = 0
+        for node in self.nodes:
+            o = node.out
+            H, W, N = o.H, o.W, o.N
+            # ---------------- forward conv
+            p = L.RdConv()
+            for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
+                p.src[i] = self._src(a, mode, n_off, g_fixed)
+            p.nsrc, p.taps = len(node.inputs), node.taps
+            p.w = wpack.ptr(node.mname, node.name, False)
+            p.bias = self.bank.p(node.mname, node.name + '.bias').data_ptr()
+            p.CinPad, p.CoutPad = wpack.pads(node.Cout, node.Cin)
+            p.N, p.H, p.W, p.Cin, p.Cout = N, H, W, node.Cin, node.Cout
+            p.G, p.gstart = self.G, self.gs_arr
+            p.emode, p.out = 0, o.buf.data_ptr()
+            p.stats = o.plan.stat_ptr(o.stats) if (o.norm is not None and not o.up) else None
+            self.keep.append(p)
+            self.fwd.append((lib.rd_conv, (C.byref(p), dt)))
+            if o.norm is not None:
+                if o.up:
+                    self.fwd.append((lib.rd_up_stats, (o.buf.data_ptr(), o.plan.stat_ptr(o.stats), N, H, W, o.C, self.G, self.gs_arr, dt)))
+                b = L.RdBnFwd()
+                b.stats = o.plan.stat_ptr(o.stats)
+                b.scale, b.shift, b.mean, b.invstd = o.scale.data_ptr(), o.shift.data_ptr(), o.mean.data_ptr(), o.invstd.data_ptr()
+                hw = (4 if o.up else 1) * H * W
+                for g in range(self.G):
+                    b.gamma[g] = o.norm.param(g, 'weight').data_ptr()
+                    b.beta[g] = o.norm.param(g, 'bias').data_ptr()
+                    b.running_mean[g] = o.norm.buf(g, 'running_mean').data_ptr()
+                    b.running_var[g] = o.norm.buf(g, 'running_var').data_ptr()
+                    b.num_batches_tracked[g] = o.norm.buf(g, 'num_batches_tracked').data_ptr()
+                    b.count[g] = float((self.gstart[g + 1] - self.gstart[g]) * hw)
+                b.C, b.G, b.eps, b.momentum, b.training = o.C, self.G, EPS, MOMENTUM, 1 if self.training else 0
+                self.keep.append(b)
+                o.bn_desc = b
+                self.fwd.append((lib.rd_bn_finalize_fwd, (C.byref(b),)))
+        if not self.training:
+            return
+        # ---------------- backward, reverse order; bwd_split[m] = index where module m's backward starts
+        self.bwd_split = {}
+        for node in reversed(self.nodes):
+            if node.mname not in self.bwd_split:
+                self.bwd_split[node.mname] = len(self.bwd)
+            o = node.out
+            H, W, N = o.H, o.W, o.N
+            if o.norm is not None:
+                q = L.RdBnBwd()
+                q.bstats = o.plan.stat_ptr(o.bstats)
+                q.mean, q.invstd = o.mean.data_ptr(), o.invstd.data_ptr()
+                q.P, q.Q, q.R = o.P.data_ptr(), o.Q.data_ptr(), o.R.data_ptr()
+                hw = (4 if o.up else 1) * H * W
+                for g in range(self.G):
+                    q.gamma[g] = o.norm.param(g, 'weight').data_ptr()
+                    q.dgamma[g] = o.norm.grad(g, 'weight').data_ptr()
+                    q.dbeta[g] = o.norm.grad(g, 'bias').data_ptr()
+                    q.count[g] = float((self.gstart[g + 1] - self.gstart[g]) * hw)
+                q.C, q.G = o.C, self.G
+                self.keep.append(q)
+                self.bwd.append((lib.rd_bn_finalize_bwd, (C.byref(q),)))
+                if o.up:
+                    o.dt_buf = self.alloc_act((N, H, W, o.C))
+                    self.bwd.append((lib.rd_up_bwd, (o.grad_buf().data_ptr(), o.buf.data_ptr(), o.dt_buf.data_ptr(), o.P.data_ptr(),
+                                                     o.Q.data_ptr(), o.R.data_ptr(), N, H, W, o.C, self.G, self.gs_arr, dt)))
+            # wgrad
+            wg = L.RdWgrad()
+            for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
+                wg.a[i] = self._src(a, mode, n_off, g_fixed)
+            wg.na, wg.taps = len(node.inputs), node.taps
+            wg.dz = self._dz_src(node)
+            wg.N, wg.H, wg.W, wg.Cin, wg.Cout = N, H, W, node.Cin, node.Cout
+            wg.G, wg.gstart = self.G, self.gs_arr
+            wg.dW = self.bank.g(node.mname, node.name + '.weight').data_ptr()
+            wg.beta = 0.0
+            ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
+            self.keep.append(wg)
+            node.wg = wg
+            self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt)))
+            if node.has_bias_grad:
+                node.bias_ws = self.alloc_f32(8192)
+                self.bwd.append((lib.rd_colsum, (o.grad_buf().data_ptr(), self.bank.g(node.mname, node.name + '.bias').data_ptr(),
+                                                 node.bias_ws.data_ptr(), N * H * W, o.C, 0.0, dt)))
+            # dgrad (skipped when no input needs a gradient, i.e. the first conv on the image)
+            dsts = []
+            for (a, mode, n_off, g_fixed) in node.inputs:
+                d = L.RdDst()
+                if mode == L.SRC_RAW and a.norm is None and not getattr(a, 'needs_grad', False):
+                    d.kind = L.DST_NONE
+                else:
+                    d.kind = {L.SRC_RAW: L.DST_PLAIN, L.SRC_AFF: L.DST_PLAIN, L.SRC_AFFACT: L.DST_PLAIN,
+                              L.SRC_POOL: L.DST_POOL, L.SRC_UP: L.DST_UPY}[mode]
+                    d.g = a.grad_buf().data_ptr()
+                    if a.norm is not None:
+                        d.z = a.buf.data_ptr()
+                        d.scale, d.shift = a.scale.data_ptr(), a.shift.data_ptr()
+                        d.bstats = a.plan.stat_ptr(a.bstats)
+                    d.act = 1 if (a.act and a.norm is not None) else 0
+                    d.accumulate = 1 if a.g_written else 0
+                    a.g_written = True
+                    d.Cd, d.slope, d.n_off, d.g_fixed = a.C, self.slope, n_off, g_fixed
+                dsts.append(d)
+            if all(d.kind == L.DST_NONE for d in dsts):
+                continue
+            p = L.RdConv()
+            p.src[0] = self._dz_src(node)
+            p.nsrc, p.taps = 1, node.taps
+            p.w = wpack.ptr(node.mname, node.name, True)
+            p.bias = None
+            p.CinPad, p.CoutPad = wpack.pads(node.Cin, node.Cout)       # roles swapped: K = Cout, N = Cin
+            p.N, p.H, p.W, p.Cin, p.Cout = N, H, W, node.Cout, node.Cin
+            p.G, p.gstart = self.G, self.gs_arr
+            p.emode = 1
+            p.dst[0] = dsts[0]
+            if len(dsts) == 2:
+                p.dst[1] = dsts[1]
+                p.c_split = node.inputs[0][0].C
+            else:
+                p.dst[1].kind = L.DST_NONE
+                p.c_split = node.Cin
+            self.keep.append(p)
+            self.bwd.append((lib.rd_conv, (C.byref(p), dt)))
+        self.ws_bytes = ws_need
+
+    def bind_workspace(self, ws):
+        """ws: float32 tensor of at least ws_bytes/4 elements, shared by all plans of a step."""
+        for node in self.nodes:
+            if hasattr(node, 'wg'):
+                node.wg.partial = ws.data_ptr()
+
+    @staticmethod
+    def run(ops, stream):
+        for fn, args in ops:
+            err = fn(*args, stream)
+            if err:
+                raise RuntimeError('ramdsir HIP launch failed: %s -> %d' % (fn.__name__, err))
+
+
+class WeightPack:
+    """Packed (forward and dgrad) copies of every conv weight in `dtype`, refreshed by one launch."""
+
+    def __init__(self, bank, modules, dtype):
+        self.bank, self.dtype = bank, dtype
+        self.dt = L.RD_BF16 if dtype == torch.bfloat16 else L.RD_F32
+        self.ck = 32 if dtype == torch.bfloat16 else 16
+        lib = L.lib()
+        entries, self.off = [], {}
+        total = 0
+        for mname, specs in modules:
+            for key, shape, kind, _ in specs:
+                if kind == 'param' and len(shape) == 4:
+                    cout, cin, k, _ = shape
+                    taps = k * k
+                    for tr in (0, 1):
+                        n = lib.rd_packed_elems(cout, cin, taps, tr, self.dt)
+                        e = L.RdPackEntry()
+                        e.src_off = bank.index[(mname, key)][0]
+                        e.dst_off = e.start = total
+                        rows, cols = (cin, cout) if tr else (cout, cin)
+                        e.Cout, e.Cin, e.taps, e.transpose = cout, cin, taps, tr
+                        e.RowPad, e.ColPad = (rows + 31) // 32 * 32, (cols + self.ck - 1) // self.ck * self.ck
+                        assert e.RowPad * e.ColPad * taps == n
+                        entries.append(e)
+                        self.off[(mname, key[:-len('.weight')], bool(tr))] = total
+                        total += n
+        self.total = total
+        self.packed = torch.zeros(total, dtype=dtype, device=bank.device)
+        arr = (L.RdPackEntry * len(entries))(*entries)
+        raw = bytes(memoryview(arr))
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(bank.device)
+        self.n_entries = len(entries)
+        self.esize = self.packed.element_size()
+
+    def ptr(self, mname, conv, transpose):
+        return self.packed.data_ptr() + self.off[(mname, conv, transpose)] * self.esize
+
+    def pads(self, Cout, Cin):
+        return (Cin + self.ck - 1) // self.ck * self.ck, (Cout + 31) // 32 * 32
+
+    def refresh_op(self):
+        return (L.lib().rd_pack_weights_batched, (self.bank.params.data_ptr(), self.packed.data_ptr(), self.table.data_ptr(),
+                                                  self.n_entries, self.total, self.dt))
+
+    def refresh(self, stream=None):
+        fn, args = self.refresh_op()
+        L.check(fn(*args, stream), 'pack_weights_batched')
+
+
+# ------------------------------------------------------------------------------------------------ network builders
+def build_encoder(plan, x_act, n=16, mname='enc'):
+    """Encoder.forward (unet.py:264-271).  x_act: Act of the image batch (no norm).  Returns [z3_1..z3_5]."""
+    bank = plan.bank
+    feats = []
+    H, W = x_act.H, x_act.W
+    prev, prev_mode = x_act, L.SRC_RAW
+    for l in range(1, 6):
+        if l > 1:
+            H, W = H // 2, W // 2
+        p = 'convd%d' % l
+        co = n * (1 << (l - 1))
+        z1 = plan.conv(mname, p + '.conv1', [(prev, prev_mode, 0, -1)], co, 9, Norm(bank, mname, p + '.bn1'), act=False, H=H, W=W)
+        z2 = plan.conv(mname, p + '.conv2', [(z1, L.SRC_AFF, 0, -1)], co, 9, Norm(bank, mname, p + '.bn2'), act=True, H=H, W=W)
+        z3 = plan.conv(mname, p + '.conv3', [(z2, L.SRC_AFFACT, 0, -1)], co, 9, Norm(bank, mname, p + '.bn3'), act=True, H=H, W=W)
+        feats.append(z3)
+        prev, prev_mode = z3, L.SRC_POOL
+    return feats
+
+
+def _feat_mode(a):
+    return L.SRC_AFFACT if a.norm is not None else L.SRC_RAW
+
+
+def build_decoder(plan, feats, n=16, num_classes=2, mname='dec'):
+    """Decoder.forward (unet.py:290-296).  feats: 5 Acts (raw+pending BN, or materialised RAW inputs)."""
+    bank = plan.bank
+    x = feats[4]
+    for l, planes, first, skip in ((4, 16 * n, True, feats[3]), (3, 8 * n, False, feats[2]), (2, 4 * n, False, feats[1]),
+                                   (1, 2 * n, False, feats[0])):
+        p = 'convu%d' % l
+        if not first:
+            x = plan.conv(mname, p + '.conv1', [(x, _feat_mode(x), 0, -1)], planes, 9, Norm(bank, mname, p + '.bn1'), act=True,
+                          H=x.H, W=x.W)
+        # 1x1 conv below the upsample (commutes with bilinear interpolation); BN2 statistics on up(t)
+        t = plan.conv(mname, p + '.conv2', [(x, _feat_mode(x), 0, -1)], planes // 2, 1, Norm(bank, mname, p + '.bn2'), act=True,
+                      up_out=True, H=x.H, W=x.W)
+        x = plan.conv(mname, p + '.conv3', [(skip, _feat_mode(skip), 0, -1), (t, L.SRC_UP, 0, -1)], planes, 9,
+                      Norm(bank, mname, p + '.bn3'), act=True, H=skip.H, W=skip.W)
+    return plan.conv(mname, 'out1', [(x, L.SRC_AFFACT, 0, -1)], num_classes, 9, None, H=x.H, W=x.W)
+
+
+def build_rec_decoder(plan, x5, n_off, g_fixed, domains, n=16, num_classes=3, mname='rec'):
+    """Rec_Decoder.forward (unet.py:316-322) for all domain slices at once; plan.G groups, group g uses
+    DomainSpecificBatchNorm2d.bns[domains[g]] (dsbn.py:26).  x5: bottleneck Act (of another plan when
+    n_off/g_fixed address a slice of the encoder batch)."""
+    bank = plan.bank
+    x, mode = x5, _feat_mode(x5)
+    H, W = x5.H, x5.W
+    for l, planes in ((4, 16 * n), (3, 8 * n), (2, 4 * n), (1, 2 * n)):
+        p, h = 'convu%d' % l, planes // 2
+        nrm = (lambda nm: Norm(bank, mname, nm, domains)) if domains is not None else (lambda nm: Norm(bank, mname, nm))
+        z1 = plan.conv(mname, p + '.conv1', [(x, mode, n_off if x is x5 else 0, g_fixed if x is x5 else -1)], h, 9, nrm(p + '.bn1'),
+                       act=True, H=H, W=W)
+        t = plan.conv(mname, p + '.conv2', [(z1, L.SRC_AFFACT, 0, -1)], h, 1, nrm(p + '.bn2'), act=True, up_out=True, H=H, W=W)
+        H, W = 2 * H, 2 * W
+        x = plan.conv(mname, p + '.conv3', [(t, L.SRC_UP, 0, -1)], h, 9, nrm(p + '.bn3'), act=True, H=H, W=W)
+        mode = L.SRC_AFFACT
+    return plan.conv(mname, 'out1', [(x, L.SRC_AFFACT, 0, -1)], num_classes, 9, None, H=H, W=W)

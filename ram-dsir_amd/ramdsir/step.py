@@ -1,0 +1,195 @@
+"""The fused RAM-DSIR training step (code/train.py:225-296 fundus, :393-465 prostate) as one static
+launch list on one HIP stream, optionally captured into a hipGraph:
+
+    [RAM mix] -> encoder+seg-decoder on [img ; img_freq] (2B images, 2 BN groups)
+              -> restoration decoder on the img_freq bottleneck (B images, one DSBN group per domain)
+              -> fused seg/consistency loss + rec loss (dlogits)
+              -> seg-decoder backward -> rec-decoder backward -> encoder backward
+              -> Adam (3 param groups, poly LR) -> repack conv weights
+
+Only the flag combination that runs in the reference (--ram --rec [--consistency]) exists here.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import engine as E
+
+
+class TrainStep:
+    def __init__(self, bank, mods, dtype, batch_sizes, H, W, dataset='fundus', consistency='kd', lambda_rec=0.1, lr=2e-3,
+                 total_iters=21200, in_channels=3, n=16, num_classes=2, slope=0.0, wpack=None):
+        self.bank, self.dtype = bank, dtype
+        self.dt = L.RD_BF16 if dtype == torch.bfloat16 else L.RD_F32
+        self.batch_sizes = list(batch_sizes)
+        self.B = B = sum(batch_sizes)
+        self.H, self.W, self.K, self.c = H, W, num_classes, in_channels
+        self.dataset = dataset
+        dev = bank.device
+        lib = L.lib()
+        self.wpack = wpack if wpack is not None else E.WeightPack(bank, mods, dtype)
+        # ---- graphs
+        self.seg = E.Plan(bank, dtype, 2 * B, [0, B, 2 * B], slope=slope)
+        self.x = E.Act(self.seg, 2 * B, H, W, in_channels, name='input')
+        self.feats = E.build_encoder(self.seg, self.x, n=n)
+        self.logits = E.build_decoder(self.seg, self.feats, n=n, num_classes=num_classes)
+        gs = [0]
+        for b in batch_sizes:
+            gs.append(gs[-1] + b)
+        self.rec = E.Plan(bank, dtype, B, gs, slope=slope)
+        self.rec_logits = E.build_rec_decoder(self.rec, self.feats[4], n_off=B, g_fixed=1, domains=list(range(len(batch_sizes))),
+                                              n=n, num_classes=in_channels)
+        self.seg.build(self.wpack)
+        self.rec.build(self.wpack)
+        ws_bytes = max(self.seg.ws_bytes, self.rec.ws_bytes, 4)
+        self.ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device=dev)
+        self.seg.bind_workspace(self.ws)
+        self.rec.bind_workspace(self.ws)
+        # ---- losses
+        if dataset == 'fundus':
+            self.target = torch.zeros(B, num_classes, H, W, dtype=torch.float32, device=dev)
+        else:
+            self.target = torch.zeros(B, H, W, dtype=torch.int64, device=dev)
+        self.losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.rec_mse = torch.zeros(len(batch_sizes), dtype=torch.float32, device=dev)
+        sl = L.RdSegLoss()
+        sl.logits, sl.target = self.logits.buf.data_ptr(), self.target.data_ptr()
+        sl.dlogits, sl.losses_out = self.logits.grad_buf().data_ptr(), self.losses.data_ptr()
+        sl.B, sl.H, sl.W, sl.K = B, H, W, num_classes
+        sl.kind = 0 if dataset == 'fundus' else 1
+        sl.consistency = {None: 0, 'kd': 1, 'mse': 2}[consistency]
+        sl.cons_weight = 0.5
+        self.seg_ws = torch.empty(lib.rd_seg_loss_workspace(C.byref(sl)) // 4, dtype=torch.float32, device=dev)
+        sl.partial = self.seg_ws.data_ptr()
+        self.sl = sl
+        self.rec_ws = torch.empty(max(lib.rd_rec_loss_workspace(B, H, W, in_channels) // 4, 1), dtype=torch.float32, device=dev)
+        self.lambda_rec = lambda_rec
+        # ---- optimizer
+        bank.ensure_adam()
+        self.iter = torch.zeros((), dtype=torch.int32, device=dev)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        ad = L.RdAdam()
+        ad.param, ad.grad = bank.params.data_ptr(), bank.grads.data_ptr()
+        ad.exp_avg, ad.exp_avg_sq = bank.exp_avg.data_ptr(), bank.exp_avg_sq.data_ptr()
+        ad.n, ad.n_half_lr = bank.n, bank.module_range['enc'][1]
+        ad.iter, ad.hyper_out = self.iter.data_ptr(), self.hyper.data_ptr()
+        ad.base_lr, ad.total_iters, ad.beta1, ad.beta2, ad.eps = lr, total_iters, 0.9, 0.999, 1e-8
+        self.ad = ad
+        self.graph = None
+        self._ops = self._build_ops()
+
+    def _build_ops(self):
+        lib = L.lib()
+        B, H, W = self.B, self.H, self.W
+        split = self.seg.bwd_split['enc']
+        ops = []
+        ops += self.seg.fwd
+        ops += self.rec.fwd
+        ops.append((lib.rd_seg_loss, (C.byref(self.sl), self.dt)))
+        ops.append((lib.rd_rec_loss, (self.rec_logits.buf.data_ptr(), self.x.buf.data_ptr(), self.rec_logits.grad_buf().data_ptr(),
+                                      self.rec_mse.data_ptr(), self.rec_ws.data_ptr(), B, H, W, self.c, self.rec.G, self.rec.gs_arr,
+                                      self.lambda_rec, self.dt)))
+        ops += self.seg.bwd[:split]
+        ops += self.rec.bwd
+        ops += self.seg.bwd[split:]
+        ops.append((lib.rd_adam_step, (C.byref(self.ad),)))
+        ops.append(self.wpack.refresh_op())
+        return ops
+
+    # ---- inputs
+    def load_images(self, img_nchw, img_freq_nchw, stream=None):
+        """fp32 NCHW device tensors in [-1,1] (what the reference's DataLoader yields, train.py:244)."""
+        lib, B = L.lib(), self.B
+        s = self._stream() if stream is None else stream
+        half = self.x.buf[B:]
+        L.check(lib.rd_nchw_to_nhwc(img_nchw.data_ptr(), self.x.buf.data_ptr(), B, self.c, self.H, self.W, self.dt, s), 'load img')
+        L.check(lib.rd_nchw_to_nhwc(img_freq_nchw.data_ptr(), half.data_ptr(), B, self.c, self.H, self.W, self.dt, s), 'load img_freq')
+
+    def load_target(self, mask):
+        self.target.copy_(mask)
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- execution
+    def zero(self):
+        self.seg.stat_arena.zero_()
+        self.rec.stat_arena.zero_()
+        self.bank.grads.zero_()
+
+    def run_eager(self):
+        self.zero()
+        E.Plan.run(self._ops, self._stream())
+
+    def capture(self):
+        """Capture one step (zeroing + every launch) into a hipGraph on a side stream."""
+        self.wpack.refresh(self._stream())
+        torch.cuda.synchronize()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            # warm-up outside capture so that lazy module loading / attribute setting is done
+            saved = self._snapshot()
+            self.run_eager()
+            st.synchronize()
+            self._restore(saved)
+            with torch.cuda.graph(g, stream=st):
+                self.run_eager()
+        torch.cuda.current_stream().wait_stream(st)
+        self.graph = g
+        return g
+
+    def _snapshot(self):
+        b = self.bank
+        return (b.params.clone(), b.exp_avg.clone(), b.exp_avg_sq.clone(), {k: v.clone() for k, v in b.buffers.items()},
+                self.iter.clone())
+
+    def _restore(self, saved):
+        b = self.bank
+        b.params.copy_(saved[0]); b.exp_avg.copy_(saved[1]); b.exp_avg_sq.copy_(saved[2])
+        for k, v in saved[3].items():
+            b.buffers[k].copy_(v)
+        self.iter.copy_(saved[4])
+        self.wpack.refresh(self._stream())
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.run_eager()
+
+    def loss_dict(self):
+        """Synchronises.  Names follow the tensorboard scalars of train.py:298-304."""
+        l = self.losses.cpu().tolist()
+        r = self.rec_mse.cpu().tolist()
+        seg = 'bce' if self.dataset == 'fundus' else 'ce'
+        return {'loss_%s_1' % seg: l[0], 'loss_dice_1': l[1], 'loss_%s_2' % seg: l[2], 'loss_dice_2': l[3],
+                'loss_consistency': l[4], 'rec': r, 'loss': l[5] + self.lambda_rec * sum(r)}
+
+
+def make_bank(device, in_channels=3, n=16, num_classes=2, num_domains=3):
+    mods = [('enc', E.encoder_specs(in_channels, n)), ('dec', E.decoder_specs(n, num_classes)),
+            ('rec', E.rec_decoder_specs(n, in_channels, num_domains))]
+    return E.ParamBank(mods, device), mods
+
+
+def load_state(bank, mname, sd):
+    """Copy a reference-layout state_dict (any device) into the bank's arenas / buffers."""
+    for k, v in sd.items():
+        if (mname, k) in bank.index:
+            bank.p(mname, k).copy_(v.to(bank.device))
+        elif (mname, k) in bank.buffers:
+            bank.buffers[(mname, k)].copy_(v.to(bank.device))
+        else:
+            raise KeyError('unexpected key %s.%s' % (mname, k))
+
+
+def state_dict_of(bank, mname, specs):
+    from collections import OrderedDict
+    out = OrderedDict()
+    for key, shape, kind, _ in specs:
+        out[key] = (bank.p(mname, key) if kind == 'param' else bank.b(mname, key)).detach().clone()
+    return out

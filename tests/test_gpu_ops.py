@@ -213,17 +213,21 @@ WG_CASES = [
     ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, 0),
     ('k1_128_64', 1, [(L.SRC_AFFACT, 128)], 64, 2, 10, 34, 0),
     ('k1_16_16', 1, [(L.SRC_AFFACT, 16)], 16, 2, 20, 20, 0),
+    # exact geometries of the fused step at 32x32 (3 DSBN groups of 2/3/3 images; 2 groups of 8)
+    ('rec_u1c3', 9, [(L.SRC_UP, 16)], 16, 8, 32, 32, 1, [0, 2, 5, 8]),
+    ('dec_u1c2', 1, [(L.SRC_AFFACT, 32)], 16, 16, 16, 16, 0, [0, 8, 16]),
+    ('dec_u1c1', 9, [(L.SRC_AFFACT, 64)], 32, 16, 16, 16, 1, [0, 8, 16]),
 ]
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
 def test_wgrad(case, dtype):
-    name, taps, src_spec, Cout, N, H, W, bnbwd = case
+    name, taps, src_spec, Cout, N, H, W, bnbwd = case[:8]
     gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000 + 2)
     keep = U.Keep()
-    gstart = [0, 1, N]
-    G = 2
+    gstart = case[8] if len(case) > 8 else [0, 1, N]
+    G = len(gstart) - 1
     k = 3 if taps == 9 else 1
     p = L.RdWgrad()
     virt = []

@@ -1,0 +1,195 @@
+"""-m gpu: the fused training step (all HIP, through the C ABI) against (a) the committed fixtures of the
+reference's own step and (b) the oracle run live on the same inputs.  fp32 tolerances: losses 1e-4 rel,
+gradients 2e-3 of each tensor's RMS (fp32 reassociation through ~40 layers), bf16: loss band only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ramdsir import step as S, engine as E, _lib as L      # noqa: E402
+from oracle import step as OS, unet as OU                   # noqa: E402
+from golden_util import (assert_sig_close, load_step, step_states, bn_shadowed_bias, sig)   # noqa: E402
+
+T = torch.from_numpy
+DEV = 'cuda:0'
+
+# Element-wise gradient parity of a FULL step is limited by the problem, not the kernels: ReLU masks and
+# 2x2-pixel BatchNorm batches make the fp32 reference itself differ from an fp64 run of the same code by
+# up to 1.8e-1 max/RMS and 1.1e-2 relative L2 on these fixtures (measured with the oracle, fp32 vs fp64).
+# Full-step checks therefore use relative L2 <= 4e-2; the smooth-activation test below (slope=1, no ReLU
+# kinks) holds the same composition to 2e-3, and tests/test_gpu_ops.py holds every kernel to 2e-5.
+REL_L2_STEP = 4e-2
+
+
+def rel_l2(got, ref):
+    return float((got.double() - ref.double()).norm() / (ref.double().norm() + 1e-30))
+
+
+def _setup(golden_dir, name, dtype):
+    G, meta = load_step(golden_dir, name)
+    enc, dec, rec = step_states(meta)
+    nd = len(meta['batch_sizes'])
+    bank, mods = S.make_bank(DEV, 3, 16, meta['num_classes'], nd)
+    for m, sd in (('enc', enc), ('dec', dec), ('rec', rec)):
+        S.load_state(bank, m, sd)
+    ts = S.TrainStep(bank, mods, dtype, meta['batch_sizes'], meta['S'], meta['S'],
+                     dataset='fundus' if name.startswith('fundus') else 'prostate', consistency=meta['consistency'],
+                     lambda_rec=meta['lambda_rec'], lr=meta['base_lr'], total_iters=meta['total_iters'],
+                     num_classes=meta['num_classes'])
+    ts.wpack.refresh()
+    return G, meta, (enc, dec, rec), bank, mods, ts
+
+
+def _feed(ts, G, it):
+    ts.load_images(T(G['s%d.img' % it]).to(DEV), T(G['s%d.img_freq' % it]).to(DEV))
+    ts.load_target(T(G['s%d.mask' % it]).to(DEV))
+
+
+@pytest.mark.parametrize('name', ['fundus', 'fundus_mse', 'prostate'])
+def test_step_fp32_matches_reference_fixture(golden_dir, name):
+    G, meta, states, bank, mods, ts = _setup(golden_dir, name, torch.float32)
+    _feed(ts, G, 0)
+    ts.step()
+    torch.cuda.synchronize()
+    ld = ts.loss_dict()
+    ref = G['s0.losses']
+    got = [ts.losses[i].item() for i in range(5)] + [ld['loss']]
+    np.testing.assert_allclose(got, ref, rtol=1e-4)
+    np.testing.assert_allclose(ld['rec'], G['s0.rec_losses'], rtol=1e-4)
+    # gradients of every parameter vs the reference's (signatures: L2, L1, first 8 elements)
+    for m in ('enc', 'dec', 'rec'):
+        for key, shape, kind, _ in dict(mods)[m]:
+            if kind != 'param':
+                continue
+            g = bank.g(m, key).cpu()
+            if bn_shadowed_bias(key):
+                assert float(g.abs().max()) == 0.0          # exact zero here, fp32 noise in the reference
+                continue
+            ref = G['s0.g%s.sig.%s' % (m, key)]
+            np.testing.assert_allclose(float(g.double().norm()), np.sqrt(ref[2]), rtol=REL_L2_STEP, err_msg=key)
+            np.testing.assert_allclose(float(g.double().abs().sum()), ref[1], rtol=REL_L2_STEP, err_msg=key)
+            fk = 's0.g%s.full.%s' % (m, key)
+            if fk in G.files:
+                assert rel_l2(g, T(G[fk])) <= REL_L2_STEP, key
+    # post-step state.  Adam's first update is ~lr*sign(g): elements whose gradient is below fp32 noise take
+    # a platform-dependent sign, so parameters are held to |diff| <= 2*lr per element and 1e-2 on the norm;
+    # running statistics / num_batches_tracked are plain fp32 averages and held to 1e-3.
+    lr = meta['base_lr']
+    for m in ('enc', 'dec', 'rec'):
+        for key, shape, kind, _ in dict(mods)[m]:
+            if bn_shadowed_bias(key):
+                continue
+            v = (bank.p(m, key) if kind == 'param' else bank.b(m, key)).cpu().double().reshape(-1)
+            ref = G['s0.post.%s.sig.%s' % (m, key)]
+            n8 = int(min(8, ref[3]))
+            if kind == 'param':
+                assert np.abs(v[:n8].numpy() - ref[4:4 + n8]).max() <= 2.1 * lr, key
+                np.testing.assert_allclose(float(v.norm()), np.sqrt(ref[2]), rtol=1e-2, err_msg=key)
+            else:
+                np.testing.assert_allclose(v[:n8].numpy(), ref[4:4 + n8], rtol=1e-3, atol=1e-6, err_msg=key)
+    assert int(ts.iter) == 1
+
+
+def test_step_fp32_three_steps_track_reference(golden_dir):
+    G, meta, states, bank, mods, ts = _setup(golden_dir, 'fundus', torch.float32)
+    for it in range(meta['nsteps']):
+        _feed(ts, G, it)
+        ts.step()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(ts.hyper[0].item(), G['s%d.lr_used' % it][1], rtol=1e-6)
+        got = [ts.losses[i].item() for i in range(5)]
+        # steps >= 1: Adam's sign-like first update amplifies fp32 noise (see tests/test_oracle_step.py)
+        np.testing.assert_allclose(got, G['s%d.losses' % it][:5], rtol=1e-4 if it == 0 else 5e-2)
+
+
+@pytest.mark.parametrize('name', ['fundus', 'prostate'])
+def test_step_fp32_full_tensors_vs_oracle(golden_dir, name):
+    """Everything the step produces, element-wise, against the oracle run here on the same inputs."""
+    G, meta, (enc, dec, rec), bank, mods, ts = _setup(golden_dir, name, torch.float32)
+    _feed(ts, G, 0)
+    ts.step()
+    torch.cuda.synchronize()
+    cfg = OS.StepConfig(dataset='fundus' if name.startswith('fundus') else 'prostate', batch_sizes=meta['batch_sizes'],
+                        lambda_rec=meta['lambda_rec'], consistency=meta['consistency'], lr=meta['base_lr'],
+                        total_iters=meta['total_iters'], num_classes=meta['num_classes'])
+    e2, d2, r2 = (OU.clone_state(s, requires_grad=True) for s in (enc, dec, rec))
+    loss, comps, inter = OS.forward_losses(e2, d2, r2, T(G['s0.img']), T(G['s0.img_freq']), T(G['s0.mask']), cfg)
+    loss.backward()
+    B = sum(meta['batch_sizes'])
+    lg = ts.logits.buf.float().cpu().permute(0, 3, 1, 2)
+    for got, ref in ((lg[:B], inter['logit1']), (lg[B:], inter['logit2'])):
+        rms = ref.detach().pow(2).mean().sqrt()
+        assert float((got - ref.detach()).abs().max()) < 1e-4 * rms * 10
+    rl = ts.rec_logits.buf.float().cpu().permute(0, 3, 1, 2)
+    ref = torch.atanh(inter['rec_soft'].detach().clamp(-0.999999, 0.999999))
+    assert float((torch.tanh(rl) - inter["rec_soft"].detach()).abs().max()) < 2e-3   # tiny DSBN slices (2-3 images at 2x2) amplify fp32 noise
+    for m, sd in (('enc', e2), ('dec', d2), ('rec', r2)):
+        for k in OU.param_keys(sd):
+            g = bank.g(m, k).cpu()
+            r = sd[k].grad
+            if bn_shadowed_bias(k):
+                continue
+            assert rel_l2(g, r) <= REL_L2_STEP, (m, k, rel_l2(g, r))
+
+
+def test_step_fp32_smooth_activation_tight(golden_dir):
+    """Same composition with activation slope 1 (LeakyReLU(1.0) == identity): no ReLU kinks, so the whole
+    fused step -- every loader mode, epilogue, BN backward, up/pool paths, losses -- must agree with the
+    oracle to fp32 accuracy."""
+    G, meta = load_step(golden_dir, 'fundus')
+    enc, dec, rec = step_states(meta)
+    bank, mods = S.make_bank(DEV, 3, 16, 2, 3)
+    for m, sd in (('enc', enc), ('dec', dec), ('rec', rec)):
+        S.load_state(bank, m, sd)
+    ts = S.TrainStep(bank, mods, torch.float32, meta['batch_sizes'], 32, 32, dataset='fundus', consistency='kd',
+                     lr=meta['base_lr'], total_iters=meta['total_iters'], slope=1.0)
+    ts.wpack.refresh()
+    _feed(ts, G, 0)
+    ts.step()
+    torch.cuda.synchronize()
+    cfg = OS.StepConfig(dataset='fundus', batch_sizes=meta['batch_sizes'], consistency='kd', lr=meta['base_lr'],
+                        total_iters=meta['total_iters'], slope=1.0)
+    e2, d2, r2 = (OU.clone_state(s, requires_grad=True) for s in (enc, dec, rec))
+    # fp32 oracle (BCE's log clamp / sigmoid saturation are defined in fp32; linear activations give large logits)
+    loss, comps, inter = OS.forward_losses(e2, d2, r2, T(G['s0.img']), T(G['s0.img_freq']), T(G['s0.mask']), cfg)
+    loss.backward()
+    got = [ts.losses[i].item() for i in range(5)]
+    np.testing.assert_allclose(got, [comps[k].item() for k in ('seg1', 'dice1', 'seg2', 'dice2', 'cons')], rtol=1e-4)
+    rows = []
+    for m, sd in (('enc', e2), ('dec', d2), ('rec', r2)):
+        for k in OU.param_keys(sd):
+            if bn_shadowed_bias(k):
+                continue
+            r = sd[k].grad
+            rows.append((rel_l2(bank.g(m, k).cpu(), r), float(r.double().pow(2).mean().sqrt()), m, k))
+    med = float(np.median([r[1] for r in rows]))
+    # with linear activations a BN bias in front of a 1x1 conv + BN has an analytically zero gradient: such
+    # noise-level tensors (RMS < 1e-3 of the median) are excluded from the relative check
+    live = [r for r in rows if r[1] > 1e-3 * med]
+    assert len(live) > 0.8 * len(rows)
+    bad = [r for r in live if r[0] > 2e-3]
+    assert not bad, sorted(bad, reverse=True)[:10]
+
+
+def test_step_bf16_loss_band_and_graph_replay(golden_dir):
+    """bf16 storage: element-wise parity with the fp32 oracle is not defined beyond single ops (SURVEY.md
+    section 7); the step is held to a loss band and to bit-identical behaviour eager vs hipGraph replay
+    (modulo atomics order)."""
+    G, meta, states, bank, mods, ts = _setup(golden_dir, 'fundus', torch.bfloat16)
+    _feed(ts, G, 0)
+    ts.step()
+    torch.cuda.synchronize()
+    got = np.array([ts.losses[i].item() for i in range(5)])
+    np.testing.assert_allclose(got, G['s0.losses'][:5], rtol=5e-2)
+    # graph path
+    G2, meta2, _, bank2, mods2, ts2 = _setup(golden_dir, 'fundus', torch.bfloat16)
+    _feed(ts2, G2, 0)
+    ts2.capture()
+    ts2.step()
+    torch.cuda.synchronize()
+    got2 = np.array([ts2.losses[i].item() for i in range(5)])
+    np.testing.assert_allclose(got2, got, rtol=1e-2)
+    assert int(ts2.iter) == 1
+    rel = float((bank2.params - bank.params).abs().max())
+    assert rel < 5e-3            # Adam moves every weight by ~lr; eager and replay agree up to atomics order
