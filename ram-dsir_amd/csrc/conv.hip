@@ -32,27 +32,53 @@ __device__ __forceinline__ void load_vec(const T* p, int cvalid, bool vec_ok, fl
     }
 }
 
-// One 16-byte slot (channels c .. c+S-1 of source s) of conv-input pixel (n, y, x), transformed.
-// (y, x) are in the conv's H x W frame and already known to be inside the image.
+// Per-thread, per-chunk constants of the tile loader: which source the thread's channel slot belongs to
+// and that slot's BN coefficients (each thread keeps ONE slot index for a whole chunk, so these are loaded
+// once per chunk instead of once per pixel).
 template <typename T>
-__device__ __forceinline__ void load_slot(const rd_src_t& s, int g_img, int n, int y, int x, int H, int W, int c,
-                                          float* v) {
+struct SlotCtx {
+    static constexpr int S = Slot<T>::N;
+    int si;        // source index, -1: channel slot beyond Cin (zeros)
+    int c;         // channel within the source
+    float sc[S], sh[S], q[S];
+};
+
+template <typename T>
+__device__ __forceinline__ void slot_ctx(SlotCtx<T>& k, const rd_src_t* src, int nsrc, int Cin, int g_img, int c) {
     constexpr int S = Slot<T>::N;
-    const int C = s.C;
-    const int cvalid = C - c;                     // > 0 guaranteed by caller
+    k.si = -1;
+    k.c = 0;
+    if (c >= Cin) return;
+    k.si = (nsrc == 1 || c < src[0].C) ? 0 : 1;
+    k.c = c - (k.si ? src[0].C : 0);
+    // field-by-field select keeps the kernarg struct out of scratch
+    const int C = k.si ? src[1].C : src[0].C;
+    const int mode = k.si ? src[1].mode : src[0].mode;
+    const int gf = k.si ? src[1].g_fixed : src[0].g_fixed;
+    const float* scp = k.si ? src[1].scale : src[0].scale;
+    const float* shp = k.si ? src[1].shift : src[0].shift;
+    const float* qp = k.si ? src[1].q : src[0].q;
+    const int cvalid = C - k.c;
+    const int g = gf >= 0 ? gf : g_img;
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        const bool ok = (e < cvalid) && mode != RD_SRC_RAW;
+        k.sc[e] = ok ? scp[g * C + k.c + e] : 0.f;
+        k.sh[e] = ok ? shp[g * C + k.c + e] : 0.f;
+        k.q[e] = (ok && mode == RD_SRC_BNBWD) ? qp[g * C + k.c + e] : 0.f;
+    }
+}
+
+// One 16-byte slot of conv-input pixel (n, y, x) of source s, transformed.  (y, x) are in the conv's
+// H x W frame and inside the image.
+template <typename T>
+__device__ __forceinline__ void load_slot(const rd_src_t& s, const SlotCtx<T>& k, int n, int y, int x, int H, int W, float* v) {
+    constexpr int S = Slot<T>::N;
+    const int C = s.C, c = k.c;
+    const int cvalid = C - c;
     const bool vec_ok = (C % S) == 0;
-    const int g = s.g_fixed >= 0 ? s.g_fixed : g_img;
     const T* base = reinterpret_cast<const T*>(s.ptr);
     n += s.n_off;
-    float sc[S], sh[S];
-    if (s.mode != RD_SRC_RAW) {
-#pragma unroll
-        for (int e = 0; e < S; ++e) {
-            bool ok = e < cvalid;
-            sc[e] = ok ? s.scale[g * C + c + e] : 0.f;
-            sh[e] = ok ? s.shift[g * C + c + e] : 0.f;
-        }
-    }
     switch (s.mode) {
     case RD_SRC_RAW: {
         load_vec<T>(base + ((size_t)(n * H + y) * W + x) * C + c, cvalid, vec_ok, v);
@@ -60,25 +86,25 @@ __device__ __forceinline__ void load_slot(const rd_src_t& s, int g_img, int n, i
     case RD_SRC_AFF: {
         load_vec<T>(base + ((size_t)(n * H + y) * W + x) * C + c, cvalid, vec_ok, v);
 #pragma unroll
-        for (int e = 0; e < S; ++e) v[e] = v[e] * sc[e] + sh[e];
+        for (int e = 0; e < S; ++e) v[e] = v[e] * k.sc[e] + k.sh[e];
     } break;
     case RD_SRC_AFFACT: {
         load_vec<T>(base + ((size_t)(n * H + y) * W + x) * C + c, cvalid, vec_ok, v);
 #pragma unroll
-        for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * sc[e] + sh[e], s.slope);
+        for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * k.sc[e] + k.sh[e], s.slope);
     } break;
     case RD_SRC_POOL: {
         const int Hs = 2 * H, Ws = 2 * W;
-        float t[S];
+        float t[4][S];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int yy = 2 * y + (k >> 1), xx = 2 * x + (k & 1);
-            load_vec<T>(base + ((size_t)(n * Hs + yy) * Ws + xx) * C + c, cvalid, vec_ok, t);
+        for (int j = 0; j < 4; ++j)
+            load_vec<T>(base + ((size_t)(n * Hs + 2 * y + (j >> 1)) * Ws + 2 * x + (j & 1)) * C + c, cvalid, vec_ok, t[j]);
 #pragma unroll
-            for (int e = 0; e < S; ++e) {
-                float a = act_fn(t[e] * sc[e] + sh[e], s.slope);
-                v[e] = (k == 0) ? a : fmaxf(v[e], a);
-            }
+        for (int e = 0; e < S; ++e) {
+            float m = act_fn(t[0][e] * k.sc[e] + k.sh[e], s.slope);
+#pragma unroll
+            for (int j = 1; j < 4; ++j) m = fmaxf(m, act_fn(t[j][e] * k.sc[e] + k.sh[e], s.slope));
+            v[e] = m;
         }
     } break;
     case RD_SRC_UP: {
@@ -97,7 +123,7 @@ __device__ __forceinline__ void load_slot(const rd_src_t& s, int g_img, int n, i
             float top = t00[e] + lx * (t01[e] - t00[e]);
             float bot = t10[e] + lx * (t11[e] - t10[e]);
             float u = top + ly * (bot - top);
-            v[e] = act_fn(u * sc[e] + sh[e], s.slope);
+            v[e] = act_fn(u * k.sc[e] + k.sh[e], s.slope);
         }
     } break;
     case RD_SRC_BNBWD: {
@@ -107,10 +133,7 @@ __device__ __forceinline__ void load_slot(const rd_src_t& s, int g_img, int n, i
         load_vec<T>(base + off, cvalid, vec_ok, gz);
         load_vec<T>(zb + off, cvalid, vec_ok, zz);
 #pragma unroll
-        for (int e = 0; e < S; ++e) {
-            float q = (e < cvalid) ? s.q[g * C + c + e] : 0.f;
-            v[e] = sc[e] * gz[e] + q * zz[e] + sh[e];
-        }
+        for (int e = 0; e < S; ++e) v[e] = k.sc[e] * gz[e] + k.q[e] * zz[e] + k.sh[e];
     } break;
     default:
 #pragma unroll
@@ -121,19 +144,18 @@ __device__ __forceinline__ void load_slot(const rd_src_t& s, int g_img, int n, i
         if (e >= cvalid) v[e] = 0.f;
 }
 
-// slot of concatenated-channel index c of conv-input pixel (n,y,x); zero outside the image / channels
+// slot of conv-input pixel (n,y,x) for the thread's channel slot; zero outside the image / channels
 template <typename T>
-__device__ __forceinline__ uint4 gather_slot(const rd_src_t* src, int nsrc, int Cin, int g, int n, int y, int x, int H,
-                                             int W, int c) {
+__device__ __forceinline__ uint4 gather_slot(const rd_src_t* src, const SlotCtx<T>& k, int n, int y, int x, int H, int W) {
     constexpr int S = Slot<T>::N;
     float v[S];
 #pragma unroll
     for (int e = 0; e < S; ++e) v[e] = 0.f;
-    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && c < Cin) {
-        if (nsrc == 1 || c < src[0].C)
-            load_slot<T>(src[0], g, n, y, x, H, W, c, v);
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && k.si >= 0) {
+        if (k.si == 0)
+            load_slot<T>(src[0], k, n, y, x, H, W, v);
         else
-            load_slot<T>(src[1], g, n, y, x, H, W, c - src[0].C, v);
+            load_slot<T>(src[1], k, n, y, x, H, W, v);
     }
     return Slot<T>::pack(v);
 }
@@ -197,22 +219,14 @@ __device__ __forceinline__ void store_vec(T* p, const float* v, int cvalid, bool
 // output: activation mask, max-pool scatter or upsample-side mask; b1 += g, b2 += g*z per channel.
 template <typename T>
 __device__ __forceinline__ void grad_item(const rd_dst_t& d, int g_img, int n, int y, int x, int H, int W, int cd,
-                                          const float* da, float* b1, float* b2) {
+                                          const float* da, const float* sc, const float* sh, float* b1, float* b2) {
     constexpr int S = Slot<T>::N;
     T* gp = reinterpret_cast<T*>(d.g);
     const T* zp = reinterpret_cast<const T*>(d.z);
     const int Cd = d.Cd;
     const int cvalid = Cd - cd;
     const bool vec_ok = (Cd % S) == 0;
-    const int gd = d.g_fixed >= 0 ? d.g_fixed : g_img;
     n += d.n_off;
-    float sc[S], sh[S];
-#pragma unroll
-    for (int e = 0; e < S; ++e) {
-        const bool ok = (e < cvalid) && d.scale;
-        sc[e] = ok ? d.scale[gd * Cd + cd + e] : 1.f;
-        sh[e] = ok ? d.shift[gd * Cd + cd + e] : 0.f;
-    }
     if (d.kind == RD_DST_PLAIN) {
         const size_t idx = ((size_t)(n * H + y) * W + x) * Cd + cd;
         float z[S], gw[S];
@@ -339,11 +353,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
     const T* wbase = reinterpret_cast<const T*>(p.w);
     for (int c0 = 0; c0 < p.CinPad; c0 += CK) {
         __syncthreads();
-        for (int idx = tid; idx < PH * PW * 4; idx += 256) {
-            const int pix = idx >> 2, s = idx & 3;
-            const int py = pix / PW, px = pix - py * PW;
-            const uint4 u = gather_slot<T>(p.src, p.nsrc, p.Cin, g, n, y0 - HALO + py, x0 - HALO + px, H, W, c0 + s * S);
-            s_in[pix * 4 + (s ^ ((pix >> 2) & 3))] = u;
+        {
+            const int s = tid & 3;                         // idx & 3 is constant per thread (stride 256)
+            SlotCtx<T> ctx;
+            slot_ctx<T>(ctx, p.src, p.nsrc, p.Cin, g, c0 + s * S);
+            for (int idx = tid; idx < PH * PW * 4; idx += 256) {
+                const int pix = idx >> 2;
+                const int py = pix / PW, px = pix - py * PW;
+                const uint4 u = gather_slot<T>(p.src, ctx, n, y0 - HALO + py, x0 - HALO + px, H, W);
+                s_in[pix * 4 + (s ^ ((pix >> 2) & 3))] = u;
+            }
         }
         for (int idx = tid; idx < TAPS * NT * 4; idx += 256) {
             const int s = idx & 3, rec = idx >> 2;
@@ -416,6 +435,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
         const int di = (p.emode == 1 && c >= p.c_split) ? 1 : 0;
         const rd_dst_t d = select_dst(p, di);
         const int cd = c - (di ? p.c_split : 0);
+        float dsc[S], dsh[S];
+        {
+            const int gd = d.g_fixed >= 0 ? d.g_fixed : g;
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                const bool ok = p.emode == 1 && c < p.Cout && d.kind != RD_DST_NONE && d.scale && (cd + e < d.Cd);
+                dsc[e] = ok ? d.scale[gd * d.Cd + cd + e] : 1.f;
+                dsh[e] = ok ? d.shift[gd * d.Cd + cd + e] : 0.f;
+            }
+        }
         if (c < p.Cout) {
             for (int idx = tid; idx < TH * TW * SL; idx += 256) {
                 const int pix = idx / SL;
@@ -430,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
                 if (p.emode == 0)
                     store_vec<T>(out + ((size_t)(n * H + y) * W + x) * p.Cout + c, v, p.Cout - c, (p.Cout % S) == 0);
                 else if (d.kind != RD_DST_NONE)
-                    grad_item<T>(d, g, n, y, x, H, W, cd, v, b1, b2);
+                    grad_item<T>(d, g, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
             }
             if (p.emode == 1 && d.kind != RD_DST_NONE && d.bstats) {
 #pragma unroll
@@ -525,17 +554,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int Cout
         const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
         const int g = group_of(gm, n);
         __syncthreads();
-        for (int idx = tid; idx < PH * PW * (CA / S); idx += 256) {
-            const int pix = idx / (CA / S), s = idx % (CA / S);
-            const int py = pix / PW, px = pix - py * PW;
-            const uint4 u = gather_slot<T>(p.a, p.na, p.Cin, g, n, y0 - HALO + py, x0 - HALO + px, H, W, cbase + s * S);
-            *reinterpret_cast<uint4*>(s_a + pix * CA + s * S) = u;
+        {
+            const int s = tid % (CA / S);                  // constant per thread: 256 % (CA/S) == 0
+            SlotCtx<T> ctx;
+            slot_ctx<T>(ctx, p.a, p.na, p.Cin, g, cbase + s * S);
+            for (int idx = tid; idx < PH * PW * (CA / S); idx += 256) {
+                const int pix = idx / (CA / S);
+                const int py = pix / PW, px = pix - py * PW;
+                const uint4 u = gather_slot<T>(p.a, ctx, n, y0 - HALO + py, x0 - HALO + px, H, W);
+                *reinterpret_cast<uint4*>(s_a + pix * CA + s * S) = u;
+            }
         }
-        for (int idx = tid; idx < TH * TW * (CZ / S); idx += 256) {
-            const int pix = idx / (CZ / S), s = idx % (CZ / S);
-            const int py = pix / TW, px = pix - py * TW;
-            const uint4 u = gather_slot<T>(&p.dz, 1, p.Cout, g, n, y0 + py, x0 + px, H, W, nbase + s * S);
-            *reinterpret_cast<uint4*>(s_z + pix * CZ + s * S) = u;
+        {
+            const int s = tid % (CZ / S);
+            SlotCtx<T> ctx;
+            slot_ctx<T>(ctx, &p.dz, 1, p.Cout, g, nbase + s * S);
+            for (int idx = tid; idx < TH * TW * (CZ / S); idx += 256) {
+                const int pix = idx / (CZ / S);
+                const int py = pix / TW, px = pix - py * TW;
+                const uint4 u = gather_slot<T>(&p.dz, ctx, n, y0 + py, x0 + px, H, W);
+                *reinterpret_cast<uint4*>(s_z + pix * CZ + s * S) = u;
+            }
         }
         __syncthreads();
         if constexpr (sizeof(T) == 2) {
@@ -602,30 +641,63 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int Cout
             }
         }
     }
-    // partial[split][tap][n][c]
-    const int split = blockIdx.x * KS + kq;
-    float* out = p.partial + (size_t)split * TAPS * CoutPadW * CinPadW;
+    // waves that split the pixel rows of the tiles (kq > 0) fold their accumulators into wave kq == 0
+    // through LDS, one tap per round; then one partial block per workgroup: partial[split][tap][n][c]
+    if constexpr (KS > 1) {
+        float* s_acc = reinterpret_cast<float*>(smem);     // [(KS-1)][MB*NB][16][64]
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap)
+        for (int tap = 0; tap < TAPS; ++tap) {
+            __syncthreads();
+            if (kq > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int ccol = cbase + nb * 32 + li;
-            out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
+                for (int r = 0; r < 16; ++r) s_acc[(((kq - 1) * (MB * NB) + blk) * 16 + r) * 64 + lane] = acc[tap][r];
+            }
+            __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int k2 = 0; k2 < KS - 1; ++k2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tap][r] += s_acc[((k2 * (MB * NB) + blk) * 16 + r) * 64 + lane];
+            }
         }
+    }
+    if (kq == 0) {
+        float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int ccol = cbase + nb * 32 + li;
+                out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
+            }
+    }
 }
 
-__global__ void wgrad_reduce_kernel(const float* partial, float* dW, int nsplit, int taps, int Cout, int Cin, int CoutPadW,
-                                    int CinPadW, float beta) {
+// block = 64 outputs x 4 split lanes: each thread sums every 4th split, LDS folds the 4 lanes (fixed order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dW, int nsplit, int taps, int Cout,
+                                                           int Cin, int CoutPadW, int CinPadW, float beta) {
+    __shared__ float s[4][64];
     const int total = taps * Cout * Cin;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int c = i % Cin, n = (i / Cin) % Cout, tap = i / (Cin * Cout);
-        const size_t stride = (size_t)taps * CoutPadW * CinPadW;
-        const float* src = partial + ((size_t)tap * CoutPadW + n) * CinPadW + c;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += src[k * stride];
-        float* d = dW + ((size_t)n * Cin + c) * taps + tap;
-        *d = (beta != 0.f ? beta * *d : 0.f) + s;
+    const int o = threadIdx.x & 63, ql = threadIdx.x >> 6;
+    const size_t stride = (size_t)taps * CoutPadW * CinPadW;
+    for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+        const int i = base + o;
+        float acc = 0.f;
+        int c = 0, n = 0, tap = 0;
+        if (i < total) {
+            c = i % Cin; n = (i / Cin) % Cout; tap = i / (Cin * Cout);
+            const float* src = partial + ((size_t)tap * CoutPadW + n) * CinPadW + c;
+            for (int k = ql; k < nsplit; k += 4) acc += src[k * stride];
+        }
+        s[ql][o] = acc;
+        __syncthreads();
+        if (ql == 0 && i < total) {
+            const float v = (s[0][o] + s[1][o]) + (s[2][o] + s[3][o]);
+            float* d = dW + ((size_t)n * Cin + c) * taps + tap;
+            *d = (beta != 0.f ? beta * *d : 0.f) + v;
+        }
+        __syncthreads();
     }
 }
 
@@ -645,11 +717,11 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     g.CinPadW = cin32 * 32;
     g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const int pairs = (g.CoutPadW / (g.MB * 32)) * (g.CinPadW / (g.NB * 32));
-    int gx = (768 + pairs - 1) / pairs;                     // ~3 workgroups per CU in flight
+    int gx = (512 + pairs - 1) / pairs;                     // ~2 workgroups per CU in flight
     if (gx > g.total_tiles) gx = g.total_tiles;
     if (gx < 1) gx = 1;
     g.gx = gx;
-    g.nsplit = gx * g.KS;
+    g.nsplit = gx;
     return g;
 }
 
@@ -657,7 +729,9 @@ template <typename T, int TAPS, int MB, int NB>
 int launch_wgrad(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
-    const size_t lds = (size_t)(PH * PW * NB * 32 + TH * TW * MB * 32) * sizeof(T);
+    size_t lds = (size_t)(PH * PW * NB * 32 + TH * TW * MB * 32) * sizeof(T);
+    const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * 16 * 64 * sizeof(float);
+    if (lds < lds_red) lds = lds_red;
     dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
     static bool attr_set = false;
     if (!attr_set) {
@@ -682,8 +756,8 @@ int dispatch_wgrad(const rd_wgrad_t& p, hipStream_t st) {
 #undef RD_WG
     if (e) return e;
     const int total = p.taps * p.Cout * p.Cin;
-    int blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (total + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
                        g.CoutPadW, g.CinPadW, p.beta);
     return (int)hipGetLastError();
