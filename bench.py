@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the full RAM-DSIR training step (RAM FFT + seg on img and img_freq +
+consistency + per-domain rec + backward + Adam) on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Fundus target 0 --ram --rec --consistency kd, bf16 storage / fp32
+accumulate, batch 8 = [2,3,3] per GPU at 400x400x3, synthetic images (no dataset is available offline),
+random-init weights.  Weak scaling: every rank runs its own batch of 8; gradients are averaged with RCCL.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'ram-dsir_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+DOMINANT = 'conv_kernel<bf16,9,1>'       # largest share of step time in profiles/ (the 16/32-channel 3x3 layers)
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def synth_inputs(B, S, rank, device):
+    """U[0,255] uint8-valued source and partner images, lambda from random.Random(1337),
+    masks = two concentric random discs (cup inside disc)."""
+    rng = np.random.RandomState(1337 + rank)
+    src = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.float32)
+    trg = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.float32)
+    pr = random.Random(1337 + rank)
+    lam = np.array([pr.randint(1, 10) / 10 for _ in range(B)], np.float32)
+    yy, xx = np.mgrid[0:S, 0:S]
+    mask = np.zeros((B, 2, S, S), np.float32)
+    for i in range(B):
+        cy, cx = rng.uniform(0.35 * S, 0.65 * S, 2)
+        r_disc = rng.uniform(0.15 * S, 0.3 * S)
+        r_cup = r_disc * rng.uniform(0.3, 0.7)
+        d2 = (yy - cy) ** 2 + (xx - cx) ** 2
+        mask[i, 1] = d2 <= r_disc ** 2
+        mask[i, 0] = d2 <= r_cup ** 2
+    t = lambda a: torch.from_numpy(a).to(device)
+    return t(src), t(trg), t(lam), t(mask), (src, trg, lam, mask)
+
+
+def init_weights(bank):
+    """Reference init (unet.py:257-262): kaiming_normal(fan_out) conv weights, default conv bias, BN w=1 b=0."""
+    g = torch.Generator(device='cpu').manual_seed(1337)
+    for (m, k), (off, shape) in bank.index.items():
+        v = bank.p(m, k)
+        if len(shape) == 4:
+            v.copy_((torch.randn(shape, generator=g) * (2.0 / (shape[0] * shape[2] * shape[3])) ** 0.5).to(v.device))
+        elif '.bn' in k and k.endswith('weight'):
+            v.fill_(1.0)
+        elif '.bn' in k:
+            v.zero_()
+        else:
+            wshape = bank.index[(m, k[:-len('bias')] + 'weight')][1]
+            bound = 1.0 / (wshape[1] * wshape[2] * wshape[3]) ** 0.5
+            v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * bound).to(v.device))
+
+
+def dominant_kernel_roofline(ts):
+    """One eager step with HIP events (recorded on the launch stream) around every launch of the dominant
+    kernel template; algorithmic bytes of each launch come from its descriptor (engine.Plan._conv_meta)."""
+    from ramdsir import engine as E
+    stream = torch.cuda.current_stream()
+    ts.zero()
+    evs, nbytes, flops = [], 0, 0
+    for op in ts._ops:
+        meta = op[2] if len(op) > 2 else None
+        hit = meta is not None and meta.get('kernel') == DOMINANT
+        if hit:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        err = op[0](*op[1], stream.cuda_stream)
+        assert err == 0
+        if hit:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(stream)
+            evs.append((e0, e1))
+            nbytes += meta['bytes']
+            flops += meta['flops']
+    torch.cuda.synchronize()
+    total_ms = sum(a.elapsed_time(b) for a, b in evs)
+    n = len(evs)
+    achieved = nbytes / (total_ms * 1e-3) / 1e9
+    return dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=None, kernel=DOMINANT, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
+                avg_algorithmic_bytes=int(nbytes / n), achieved_tflops=round(flops / (total_ms * 1e-3) / 1e12, 1))
+
+
+def cpu_baseline(host_inputs, bs):
+    """The oracle (torch CPU restatement of train.py:225-296 + numpy RAM of fundus.py:13-61) timed on this
+    box's host cores on ONE step of the same workload (8 images at 400x400)."""
+    from oracle import ram as OR, step as OS, unet as OU
+    src, trg, lam, mask = host_inputs
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = src.shape[0]
+    t0 = time.time()
+    pairs = [OR.ram_fundus(src[i], trg[i], float(lam[i]), dtype=np.float32) for i in range(B)]
+    t_ram = time.time() - t0
+    img = torch.from_numpy(np.stack([p[0] for p in pairs]))
+    frq = torch.from_numpy(np.stack([p[1] for p in pairs]))
+    enc, dec, rec = OU.encoder_state(seed=1), OU.decoder_state(seed=2), OU.rec_decoder_state(num_classes=3, num_domains=len(bs), seed=3)
+    opt = dict(enc=OS.adam_state({k: enc[k] for k in OU.param_keys(enc)}), dec=OS.adam_state({k: dec[k] for k in OU.param_keys(dec)}),
+               rec=OS.adam_state({k: rec[k] for k in OU.param_keys(rec)}))
+    cfg = OS.StepConfig(dataset='fundus', batch_sizes=bs, consistency='kd')
+    t0 = time.time()
+    OS.train_step(enc, dec, rec, opt, img, frq, torch.from_numpy(mask), cfg, 0)
+    t_step = time.time() - t0
+    return dict(value=round(B / (t_step + t_ram), 3), unit='images/s', cores=cores, kind='port',
+                sample='1 step of the same workload (8 images 400x400: numpy RAM %.2f s on 1 core + torch-CPU step %.2f s on %d threads)'
+                       % (t_ram, t_step, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--size', type=int, default=400)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    from ramdsir import step as S, ddp as D
+
+    bs, Sz = [2, 3, 3], args.size
+    B = sum(bs)
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    bank, mods = S.make_bank(dev, 3, 16, 2, len(bs))
+    init_weights(bank)
+    ts = S.TrainStep(bank, mods, dtype, bs, Sz, Sz, dataset='fundus', consistency='kd', lambda_rec=0.1, lr=2e-3,
+                     total_iters=21200, ram=True)
+    ts.wpack.refresh()
+    src, trg, lam, mask, host_inputs = synth_inputs(B, Sz, rank, dev)
+    ts.load_raw(src, trg, lam)
+    ts.load_target(mask)
+    torch.cuda.synchronize()
+    if world > 1:
+        runner = D.DataParallelStep(ts)
+        if not args.no_graph:
+            runner.capture()
+        step = runner.step
+    else:
+        if not args.no_graph:
+            ts.capture()
+        step = ts.step
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    losses = ts.loss_dict()
+    assert np.isfinite(losses['loss']), losses
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec (seg+rec+RAM step)', 'value': round(world * B * args.steps / elapsed, 2), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'Fundus target0 --ram --rec --consistency kd, batch 8=[2,3,3] per GPU, %dx%dx3' % (Sz, Sz),
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph,
+                       'final_loss': round(losses['loss'], 4)},
+        }
+        if args.dtype == 'bf16':
+            out['roofline'] = dominant_kernel_roofline(ts)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(host_inputs, bs)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -251,6 +251,29 @@ typedef struct {
 } rd_adam_t;
 int rd_adam_step(const rd_adam_t* p, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Random Amplitude Mixup for a whole batch on the GPU.  Replaces extract_amp_spectrum /
+ * low_freq_mutate_np / source_to_target_freq (code/dataset/fundus.py:13-61 == prostate.py:10-62) and
+ * the call sites fundus.py:211-225 (clip [0,255], /127.5-1) and prostate.py:186-188 (clip [-1,1]).
+ * src/trg: NHWC fp32 [B][H][W][3] (HWC like the PIL / .npy arrays the reference feeds the trio);
+ * lam[B]: the per-sample ratio the reference draws with random.randint(1,10)/10 (fundus.py:35);
+ * b = floor(0.1*min(H,W)) (fundus.py:26).  out_img = src*scale+offset, out_freq =
+ * clip(RAM(src,trg,lam), clip_lo, clip_hi)*scale+offset, both NHWC `dtype` [B][H][W][3] -- normally the two
+ * halves of the network input batch.  tw_w / tw_h: (cos, -sin)(2*pi*k/N) tables of W / H entries.
+ * H and W must factor into 2, 3 and 5 (256, 384, 400, 512 do). */
+typedef struct {
+    const float* src; const float* trg; const float* lam;
+    void* out_img; void* out_freq;
+    void* workspace;            /* rd_ram_workspace() bytes */
+    const float* tw_w; const float* tw_h;
+    int32_t B, H, W, C, b;
+    float clip_lo, clip_hi, scale, offset;
+    int32_t pad_;
+} rd_ram_t;
+int64_t rd_ram_workspace(int B, int H, int W, int b);
+int rd_ram_mix(const rd_ram_t* p, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

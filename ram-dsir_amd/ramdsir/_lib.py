@@ -61,12 +61,20 @@ class RdAdam(C.Structure):
                 ('beta2', f32), ('eps', f32), ('pad_', i32)]
 
 
+class RdRam(C.Structure):
+    _fields_ = [('src', fp), ('trg', fp), ('lam', fp), ('out_img', vp), ('out_freq', vp), ('workspace', vp),
+                ('tw_w', fp), ('tw_h', fp), ('B', i32), ('H', i32), ('W', i32), ('C', i32), ('b', i32),
+                ('clip_lo', f32), ('clip_hi', f32), ('scale', f32), ('offset', f32), ('pad_', i32)]
+
+
 class RdPackEntry(C.Structure):
     _fields_ = [('src_off', i64), ('dst_off', i64), ('start', i64), ('Cout', i32), ('Cin', i32), ('taps', i32),
                 ('transpose', i32), ('RowPad', i32), ('ColPad', i32)]
 
 
 _SIGS = {
+    'rd_ram_workspace': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'rd_ram_mix': (C.c_int, [C.POINTER(RdRam), C.c_int, vp]),
     'rd_pack_weights_batched': (C.c_int, [fp, vp, vp, C.c_int, i64, C.c_int, vp]),
     'rd_conv': (C.c_int, [C.POINTER(RdConv), C.c_int, vp]),
     'rd_wgrad_workspace': (i64, [C.POINTER(RdWgrad), C.c_int]),

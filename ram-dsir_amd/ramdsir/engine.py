@@ -304,7 +304,7 @@ class Plan:
             p.emode, p.out = 0, o.buf.data_ptr()
             p.stats = o.plan.stat_ptr(o.stats) if (o.norm is not None and not o.up) else None
             self.keep.append(p)
-            self.fwd.append((lib.rd_conv, (C.byref(p), dt)))
+            self.fwd.append((lib.rd_conv, (C.byref(p), dt), self._conv_meta(node, N, H, W, node.Cin, node.Cout, 'fwd')))
             if o.norm is not None:
                 if o.up:
                     self.fwd.append((lib.rd_up_stats, (o.buf.data_ptr(), o.plan.stat_ptr(o.stats), N, H, W, o.C, self.G, self.gs_arr, dt)))
@@ -363,7 +363,7 @@ class Plan:
             ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
             self.keep.append(wg)
             node.wg = wg
-            self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt)))
+            self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt), dict(kernel='wgrad', layer='%s.%s' % (node.mname, node.name))))
             if node.has_bias_grad:
                 node.bias_ws = self.alloc_f32(8192)
                 self.bwd.append((lib.rd_colsum, (o.grad_buf().data_ptr(), self.bank.g(node.mname, node.name + '.bias').data_ptr(),
@@ -406,8 +406,17 @@ class Plan:
                 p.dst[1].kind = L.DST_NONE
                 p.c_split = node.Cin
             self.keep.append(p)
-            self.bwd.append((lib.rd_conv, (C.byref(p), dt)))
+            self.bwd.append((lib.rd_conv, (C.byref(p), dt), self._conv_meta(node, N, H, W, node.Cout, node.Cin, 'dgrad')))
         self.ws_bytes = ws_need
+
+    def _conv_meta(self, node, N, H, W, Cin, Cout, what):
+        """Which conv_kernel instantiation a launch uses and its ALGORITHMIC bytes: the logical input read
+        once + the output written once, in the storage dtype."""
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        nb = 2 if ((Cout + 31) // 32 * 32) % 64 == 0 else 1
+        tname = 'bf16' if self.dtype == torch.bfloat16 else 'f32'
+        return dict(kernel='conv_kernel<%s,%d,%d>' % (tname, node.taps, nb), what=what, layer='%s.%s' % (node.mname, node.name),
+                    bytes=N * H * W * (Cin + Cout) * esz, flops=2 * N * H * W * Cin * Cout * node.taps)
 
     def bind_workspace(self, ws):
         """ws: float32 tensor of at least ws_bytes/4 elements, shared by all plans of a step."""
@@ -417,7 +426,8 @@ class Plan:
 
     @staticmethod
     def run(ops, stream):
-        for fn, args in ops:
+        for op in ops:
+            fn, args = op[0], op[1]
             err = fn(*args, stream)
             if err:
                 raise RuntimeError('ramdsir HIP launch failed: %s -> %d' % (fn.__name__, err))

@@ -15,11 +15,12 @@ import torch
 
 from . import _lib as L
 from . import engine as E
+from . import ram as R
 
 
 class TrainStep:
     def __init__(self, bank, mods, dtype, batch_sizes, H, W, dataset='fundus', consistency='kd', lambda_rec=0.1, lr=2e-3,
-                 total_iters=21200, in_channels=3, n=16, num_classes=2, slope=0.0, wpack=None):
+                 total_iters=21200, in_channels=3, n=16, num_classes=2, slope=0.0, wpack=None, ram=False):
         self.bank, self.dtype = bank, dtype
         self.dt = L.RD_BF16 if dtype == torch.bfloat16 else L.RD_F32
         self.batch_sizes = list(batch_sizes)
@@ -76,26 +77,39 @@ class TrainStep:
         ad.iter, ad.hyper_out = self.iter.data_ptr(), self.hyper.data_ptr()
         ad.base_lr, ad.total_iters, ad.beta1, ad.beta2, ad.eps = lr, total_iters, 0.9, 0.999, 1e-8
         self.ad = ad
+        # ---- RAM (optional: raw images + partner images + lambda in, both network inputs out)
+        self.ram = None
+        if ram:
+            self.src = torch.zeros(B, H, W, in_channels, dtype=torch.float32, device=dev)
+            self.trg = torch.zeros(B, H, W, in_channels, dtype=torch.float32, device=dev)
+            self.lam = torch.ones(B, dtype=torch.float32, device=dev)
+            self.ram = R.RamMixer(B, H, W, dtype, dev, dataset)
+            self.ram.bind(self.src, self.trg, self.lam, self.x.buf[:B], self.x.buf[B:])
         self.graph = None
         self._ops = self._build_ops()
 
     def _build_ops(self):
+        """Three segments: A = [RAM] forward, losses, seg-decoder + rec-decoder backward; B = encoder backward;
+        C = Adam + weight repack.  Single GPU runs A+B+C back to back; data parallel all-reduces the
+        decoder-side gradients while B runs and the encoder gradients before C (ddp.py)."""
         lib = L.lib()
         B, H, W = self.B, self.H, self.W
         split = self.seg.bwd_split['enc']
-        ops = []
-        ops += self.seg.fwd
-        ops += self.rec.fwd
-        ops.append((lib.rd_seg_loss, (C.byref(self.sl), self.dt)))
-        ops.append((lib.rd_rec_loss, (self.rec_logits.buf.data_ptr(), self.x.buf.data_ptr(), self.rec_logits.grad_buf().data_ptr(),
-                                      self.rec_mse.data_ptr(), self.rec_ws.data_ptr(), B, H, W, self.c, self.rec.G, self.rec.gs_arr,
-                                      self.lambda_rec, self.dt)))
-        ops += self.seg.bwd[:split]
-        ops += self.rec.bwd
-        ops += self.seg.bwd[split:]
-        ops.append((lib.rd_adam_step, (C.byref(self.ad),)))
-        ops.append(self.wpack.refresh_op())
-        return ops
+        a = []
+        if self.ram is not None:
+            a.append(self.ram.op())
+        a += self.seg.fwd
+        a += self.rec.fwd
+        a.append((lib.rd_seg_loss, (C.byref(self.sl), self.dt)))
+        a.append((lib.rd_rec_loss, (self.rec_logits.buf.data_ptr(), self.x.buf.data_ptr(), self.rec_logits.grad_buf().data_ptr(),
+                                    self.rec_mse.data_ptr(), self.rec_ws.data_ptr(), B, H, W, self.c, self.rec.G, self.rec.gs_arr,
+                                    self.lambda_rec, self.dt)))
+        a += self.seg.bwd[:split]
+        a += self.rec.bwd
+        b = list(self.seg.bwd[split:])
+        c = [(lib.rd_adam_step, (C.byref(self.ad),)), self.wpack.refresh_op()]
+        self.seg_a, self.seg_b, self.seg_c = a, b, c
+        return a + b + c
 
     # ---- inputs
     def load_images(self, img_nchw, img_freq_nchw, stream=None):
@@ -105,6 +119,13 @@ class TrainStep:
         half = self.x.buf[B:]
         L.check(lib.rd_nchw_to_nhwc(img_nchw.data_ptr(), self.x.buf.data_ptr(), B, self.c, self.H, self.W, self.dt, s), 'load img')
         L.check(lib.rd_nchw_to_nhwc(img_freq_nchw.data_ptr(), half.data_ptr(), B, self.c, self.H, self.W, self.dt, s), 'load img_freq')
+
+    def load_raw(self, src_nhwc, trg_nhwc, lam):
+        """RAM inputs: what Fundus_Multi.__getitem__ holds before the FFTs (fundus.py:209-212): the
+        transformed image and the partner image as HWC float32 arrays, and the mix ratio."""
+        self.src.copy_(src_nhwc)
+        self.trg.copy_(trg_nhwc)
+        self.lam.copy_(lam)
 
     def load_target(self, mask):
         self.target.copy_(mask)
