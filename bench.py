@@ -103,7 +103,9 @@ def cpu_baseline(host_inputs, bs):
     box's host cores on ONE step of the same workload (8 images at 400x400)."""
     from oracle import ram as OR, step as OS, unet as OU
     src, trg, lam, mask = host_inputs
-    cores = os.cpu_count() or 1
+    # torch's CPU conv kernels stop scaling (and then regress) well before the 100+ cores of a GPU host:
+    # 16 threads is the fastest setting we measured for this step; `cores` reports the threads actually used
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     B = src.shape[0]
     t0 = time.time()

@@ -1,0 +1,213 @@
+"""nn.Module machinery behind the drop-in ``networks.unet`` classes: parameters are nn.Parameters that alias
+a ParamBank arena, forward/backward of a whole Encoder / Decoder / Rec_Decoder are ONE autograd.Function
+each that runs the HIP launch lists of an engine.Plan (there is no ATen compute and no CPU fallback)."""
+import os
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+
+
+def storage_dtype():
+    """Activation storage type of the module-level path: fp32 (default, parity-grade) or bf16
+    (RAMDSIR_DTYPE=bf16).  The fused trainer chooses its own dtype."""
+    return torch.bfloat16 if os.environ.get('RAMDSIR_DTYPE', 'f32') == 'bf16' else torch.float32
+
+
+class FusedConv2d(nn.Conv2d):
+    """Holds weight/bias exactly like nn.Conv2d (same state_dict keys, isinstance checks and init loops of
+    unet.py:257-262 work); the arithmetic runs inside the owning module's fused launch list."""
+
+    def forward(self, x):
+        raise NotImplementedError('this conv is executed inside the fused HIP graph of its parent module')
+
+
+class FusedBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d as a parameter/buffer holder (``isinstance(m, nn.BatchNorm2d)`` and ``m.train()`` of
+    test_fundus_slice.py:75-83 work); statistics and the affine run inside the fused conv kernels."""
+
+    def forward(self, x):
+        raise NotImplementedError('this BatchNorm is executed inside the fused HIP graph of its parent module')
+
+
+def activation_slope(activation):
+    return 0.0 if activation == 'relu' else 0.01      # unet.py:47-50: anything but 'relu' is LeakyReLU(0.01)
+
+
+class FusedModule(nn.Module):
+    """Common part of Encoder / Decoder / Rec_Decoder."""
+    _mname = 'mod'
+
+    def _finish_init(self, specs, activation):
+        self._specs = specs
+        self._slope = activation_slope(activation)
+        self._plans = {}
+        self._bank = None
+        self._wpack = None
+        self._bound_device = None
+        # reference init (unet.py:257-262 and twins)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu' if activation == 'relu' else 'leaky_relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    # ---- parameter arena binding
+    def _named_tensors(self):
+        d = dict(self.named_parameters())
+        d.update(dict(self.named_buffers()))
+        return d
+
+    def bind(self, bank, mname, wpack=None):
+        """Re-home every parameter / buffer into `bank` (values are kept); used by the fused trainer to put
+        the three modules into one arena."""
+        cur = self._named_tensors()
+        for key, shape, kind, dt in self._specs:
+            dst = bank.p(mname, key) if kind == 'param' else bank.b(mname, key)
+            dst.copy_(cur[key].detach().to(dst.device))
+            cur[key].data = dst
+        self._bank, self._mname, self._wpack = bank, mname, wpack
+        self._bound_device = bank.device
+        self._plans = {}
+
+    def _ensure_bound(self, device):
+        if self._bank is None or self._bound_device != device:
+            bank = E.ParamBank([(self._mname, self._specs)], device)
+            self.bind(bank, self._mname)
+        else:
+            # .to()/.cuda()/load_state_dict keep .data aliasing unless a tensor was replaced: re-alias if needed
+            cur = self._named_tensors()
+            for key, shape, kind, dt in self._specs:
+                dst = self._bank.p(self._mname, key) if kind == 'param' else self._bank.b(self._mname, key)
+                if cur[key].data_ptr() != dst.data_ptr():
+                    dst.copy_(cur[key].detach().to(dst.device))
+                    cur[key].data = dst
+        if self._wpack is None or self._wpack.dtype != storage_dtype():
+            self._wpack = E.WeightPack(self._bank, [(self._mname, self._specs)], storage_dtype())
+            self._plans = {}
+
+    def _bn_training(self):
+        flags = [m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        return any(flags)
+
+    def _acquire_plan(self, key, builder):
+        pool = self._plans.setdefault(key, [])
+        for pl in pool:
+            if not pl.busy:
+                pl.busy = True
+                return pl
+        pl = builder()
+        pl.busy = True
+        pool.append(pl)
+        return pl
+
+    @staticmethod
+    def _release(pl):
+        pl.busy = False
+
+    def _param_list(self):
+        return [p for _, p in self.named_parameters()]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def to_nhwc(x, act_buf, dt):
+    N, Cc, H, W = x.shape
+    x = x.contiguous().float()
+    L.check(L.lib().rd_nchw_to_nhwc(x.data_ptr(), act_buf.data_ptr(), N, Cc, H, W, dt, _stream()), 'nchw_to_nhwc')
+
+
+def materialize(a, plan):
+    """NCHW fp32 tensor of act(BN(z)) for a plan Act (what the reference module returns)."""
+    out = torch.empty(a.N, a.C, a.H, a.W, dtype=torch.float32, device=a.buf.device)
+    sc = a.scale.data_ptr() if a.norm is not None else None
+    sh = a.shift.data_ptr() if a.norm is not None else None
+    L.check(L.lib().rd_nhwc_to_nchw(a.buf.data_ptr(), out.data_ptr(), sc, sh, 1 if a.act else 0, plan.slope, a.N, a.C, a.H, a.W,
+                                    plan.G, plan.gs_arr, plan.dt, _stream()), 'nhwc_to_nchw')
+    return out
+
+
+def grad_in(a, plan, dy):
+    """Gradient arriving from torch for a materialised output: mask by the activation, accumulate BN sums."""
+    dy = dy.contiguous().float()
+    g = a.grad_buf()
+    has_bn = a.norm is not None
+    L.check(L.lib().rd_grad_in(dy.data_ptr(), a.buf.data_ptr() if has_bn else None, g.data_ptr(),
+                               a.scale.data_ptr() if has_bn else None, a.shift.data_ptr() if has_bn else None,
+                               a.plan.stat_ptr(a.bstats) if has_bn else None, 1 if (a.act and has_bn) else 0, plan.slope,
+                               1 if a.g_written_rt else 0, a.N, a.C, a.H, a.W, plan.G, plan.gs_arr, plan.dt, _stream()), 'grad_in')
+    a.g_written_rt = True
+
+
+def grad_out(a, plan):
+    """NCHW fp32 gradient w.r.t. a RAW input Act (a feature tensor handed in by torch)."""
+    out = torch.empty(a.N, a.C, a.H, a.W, dtype=torch.float32, device=a.buf.device)
+    L.check(L.lib().rd_nhwc_to_nchw(a.grad_buf().data_ptr(), out.data_ptr(), None, None, 0, 0.0, a.N, a.C, a.H, a.W, plan.G, plan.gs_arr,
+                                    plan.dt, _stream()), 'grad nhwc_to_nchw')
+    return out
+
+
+class FusedFn(torch.autograd.Function):
+    """forward(module, plan, inputs (Acts to fill), outputs (Acts to materialise), n_in, *tensors)"""
+
+    @staticmethod
+    def forward(ctx, module, plan, in_acts, out_acts, *tensors):
+        n_in = len(in_acts)
+        xs = tensors[:n_in]
+        for a, x in zip(in_acts, xs):
+            to_nhwc(x, a.buf, plan.dt)
+        module._wpack.refresh(_stream())
+        plan.stat_arena.zero_()
+        E.Plan.run(plan.fwd, _stream())
+        outs = tuple(materialize(a, plan) for a in out_acts)
+        ctx.module, ctx.plan, ctx.in_acts, ctx.out_acts = module, plan, in_acts, out_acts
+        ctx.needs_in = [x.requires_grad for x in xs]
+        try:
+            weakref.finalize(ctx, FusedModule._release, plan)      # forward without backward: free the plan with the graph
+        except TypeError:
+            pass
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        module, plan = ctx.module, ctx.plan
+        if not plan.training:
+            raise RuntimeError('backward through BatchNorm in eval mode is not implemented in the HIP path')
+        bank = module._bank
+        lo, hi = bank.module_range[module._mname]
+        bank.grads[lo:hi].zero_()
+        for a in ctx.out_acts:
+            a.g_written_rt = False
+        for a, dy in zip(ctx.out_acts, grads):
+            if dy is not None:
+                grad_in(a, plan, dy)
+        for a in ctx.out_acts:
+            if not a.g_written_rt:                      # output unused downstream: its gradient is zero
+                a.grad_buf().zero_()
+        E.Plan.run(plan.bwd, _stream())
+        gin = [grad_out(a, plan) if need else None for a, need in zip(ctx.in_acts, ctx.needs_in)]
+        gpar = [bank.g(module._mname, key).clone() for key, shape, kind, dt in module._specs if kind == 'param']
+        FusedModule._release(plan)
+        return (None, None, None, None) + tuple(gin) + tuple(gpar)
+
+
+def run_fused(module, plan, in_acts, out_acts, xs):
+    params = module._param_list()
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(x.requires_grad for x in xs)):
+        return FusedFn.apply(module, plan, in_acts, out_acts, *xs, *params)
+    with torch.no_grad():
+        try:
+            for a, x in zip(in_acts, xs):
+                to_nhwc(x, a.buf, plan.dt)
+            module._wpack.refresh(_stream())
+            plan.stat_arena.zero_()
+            E.Plan.run(plan.fwd, _stream())
+            return tuple(materialize(a, plan) for a in out_acts)
+        finally:
+            FusedModule._release(plan)
