@@ -27,6 +27,10 @@ extern "C" {
 #define RD_F32 0
 #define RD_BF16 1
 #define RD_MAX_GROUPS_C 8
+/* BatchNorm sums are accumulated with atomics; to keep thousands of workgroups off the same few addresses
+ * every statistics buffer has RD_STAT_SLOTS copies, [G][RD_STAT_SLOTS][C][2]; a workgroup adds into slot
+ * (its tile index mod RD_STAT_SLOTS) and the finalize kernels sum the slots. */
+#define RD_STAT_SLOTS 64
 
 /* how a conv reads one of its (virtual) input tensors -- the producer's BatchNorm + activation
  * (+ max-pool / bilinear x2) are applied while the tile is staged into LDS ("normalise on read") */
@@ -64,7 +68,7 @@ typedef struct {
     const void* z;       /* producer's raw tensor (PLAIN/POOL: same dims as g; UPY: t_lo, half res) */
     const float* scale;  /* producer BN scale/shift [G][Cd] (mask needs the sign of the BN output)  */
     const float* shift;
-    float* bstats;       /* [G][Cd][2] += (sum g, sum g*z)  or NULL                                 */
+    float* bstats;       /* [G][RD_STAT_SLOTS][Cd][2] += (sum g, sum g*z)  or NULL                  */
     int32_t kind;
     int32_t act;         /* 1: an activation follows the producer BN                                */
     int32_t accumulate;  /* 1: g += (skip connection / second consumer)                             */
@@ -90,7 +94,7 @@ typedef struct {
     int32_t gstart[RD_MAX_GROUPS_C + 1];
     int32_t emode;       /* 0 forward: write out (+stats); 1 gradient: write through dst[] */
     void* out;           /* forward: NHWC [N][H][W][Cout] */
-    float* stats;        /* forward: [G][Cout][2] += (sum, sum of squares) or NULL */
+    float* stats;        /* forward: [G][RD_STAT_SLOTS][Cout][2] += (sum, sum of squares) or NULL */
     rd_dst_t dst[2];     /* gradient: channels [0,c_split) -> dst[0], [c_split,Cout) -> dst[1] */
     int32_t c_split;
     int32_t pad_;
@@ -145,7 +149,7 @@ int rd_pack_weights_batched(const float* params, void* packed, const rd_pack_ent
  * BN (same pointers in both groups -> running stats updated twice, in order); DSBN gives each domain
  * group its own bns[d]. */
 typedef struct {
-    const float* stats;   /* [G][C][2] sum, sum of squares of the conv output */
+    const float* stats;   /* [G][RD_STAT_SLOTS][C][2] sum, sum of squares of the conv output */
     float* scale;         /* [G][C] out: gamma*invstd          */
     float* shift;         /* [G][C] out: beta - mean*scale     */
     float* mean;          /* [G][C] out (saved for backward)   */
@@ -166,7 +170,7 @@ int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream);
 /* BatchNorm backward, second half: from (sum g, sum g*z) produce the per-channel coefficients
  * dz = P*g + Q*z + R that the next dgrad / wgrad fold into their reads, and accumulate dgamma, dbeta. */
 typedef struct {
-    const float* bstats;  /* [G][C][2] */
+    const float* bstats;  /* [G][RD_STAT_SLOTS][C][2] */
     const float* mean;    /* [G][C] */
     const float* invstd;  /* [G][C] */
     const float* gamma[RD_MAX_GROUPS_C];

@@ -8,15 +8,24 @@
 
 namespace {
 
-__global__ void bn_finalize_fwd_kernel(const rd_bn_fwd_t p) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= p.C) return;
+// one wave per channel: lane k sums slot k of the RD_STAT_SLOTS partial sums, lane 0 does the per-channel math
+__global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(const rd_bn_fwd_t p) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     for (int g = 0; g < p.G; ++g) {                       // in order: shared BNs see pass 0 then pass 1
+        float s1 = 0.f, s2 = 0.f;
+        if (p.training) {
+            for (int k = lane; k < RD_STAT_SLOTS; k += 64) {
+                s1 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
+                s2 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
+            }
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+        }
+        if (lane != 0) continue;
         const float gam = p.gamma[g][c], bet = p.beta[g][c];
         float mean, invstd;
         if (p.training) {
             const float cnt = p.count[g];
-            const float s1 = p.stats[(g * p.C + c) * 2 + 0], s2 = p.stats[(g * p.C + c) * 2 + 1];
             mean = s1 / cnt;
             float var = s2 / cnt - mean * mean;
             if (var < 0.f) var = 0.f;
@@ -39,12 +48,18 @@ __global__ void bn_finalize_fwd_kernel(const rd_bn_fwd_t p) {
     }
 }
 
-__global__ void bn_finalize_bwd_kernel(const rd_bn_bwd_t p) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= p.C) return;
+__global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(const rd_bn_bwd_t p) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     for (int g = 0; g < p.G; ++g) {
+        float s1 = 0.f, sgz = 0.f;
+        for (int k = lane; k < RD_STAT_SLOTS; k += 64) {
+            s1 += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
+            sgz += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
+        }
+        s1 = wave_sum(s1);
+        sgz = wave_sum(sgz);
+        if (lane != 0) continue;
         const float cnt = p.count[g];
-        const float s1 = p.bstats[(g * p.C + c) * 2 + 0], sgz = p.bstats[(g * p.C + c) * 2 + 1];
         const float mu = p.mean[g * p.C + c], is = p.invstd[g * p.C + c], gam = p.gamma[g][c];
         const float s2 = is * (sgz - mu * s1);            // sum g * zhat
         const float P = gam * is;
@@ -104,7 +119,8 @@ __global__ __launch_bounds__(256) void up_stats_kernel(const T* t, float* stats,
         atomicAdd(&s_red[(sl * S + e) * 2 + 1], a2[e]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&stats[(size_t)g * C * 2 + i], s_red[i]);
+    const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&stats[((size_t)g * RD_STAT_SLOTS + slot) * C * 2 + i], s_red[i]);
 }
 
 // weights of the (up to 4) hi-res rows 2y-1..2y+2 on lo-res row y, and the 3 coefficients of row y of U^T U
@@ -239,8 +255,10 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float* dy, const T* 
         }
     }
     __syncthreads();
-    if (bstats)
-        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&bstats[(size_t)g * C * 2 + i], s_red[i]);
+    if (bstats) {
+        const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&bstats[((size_t)g * RD_STAT_SLOTS + slot) * C * 2 + i], s_red[i]);
+    }
 }
 
 template <typename T>
@@ -263,12 +281,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial,
     if (threadIdx.x < C) partial[blockIdx.x * 8 + threadIdx.x] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
 }
 
-__global__ void colsum_final_kernel(const float* partial, float* out, int nblocks, int C, float beta) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[b * 8 + c];
-    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
+// one wave per channel; lanes stride over the per-block partials
+__global__ __launch_bounds__(64) void colsum_final_kernel(const float* partial, float* out, int nblocks, int C, float beta) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[b * 8 + c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
 }
 
 GroupMap host_gm(int G, const int32_t* gs) {
@@ -291,13 +310,13 @@ extern "C" {
 
 int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream) {
     if (!p || p->G < 1 || p->G > RD_MAX_GROUPS) return -1;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((p->C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(p->C), dim3(64), 0, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 
 int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
     if (!p || p->G < 1 || p->G > RD_MAX_GROUPS) return -1;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((p->C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(p->C), dim3(64), 0, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 
@@ -376,7 +395,7 @@ int rd_colsum(const void* x, float* out, float* partial_ws, int64_t npix, int C,
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial_ws, npix, C);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, partial_ws, npix, C);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, out, nb, C, beta);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial_ws, out, nb, C, beta);
     return (int)hipGetLastError();
 }
 

@@ -54,13 +54,20 @@ template <> struct Slot<bf16_t> {
         f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
         f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
     }
+    static __device__ __forceinline__ unsigned pk2(float a, float b) {       // one v_cvt_pk_bf16_f32 (RNE)
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+        f2 v = {a, b};
+        b2 r = __builtin_convertvector(v, b2);
+        return __builtin_bit_cast(unsigned, r);
+    }
     static __device__ __forceinline__ uint4 pack(const float* f) {
-        return make_uint4(bf16_bits(f[0]) | (bf16_bits(f[1]) << 16), bf16_bits(f[2]) | (bf16_bits(f[3]) << 16),
-                          bf16_bits(f[4]) | (bf16_bits(f[5]) << 16), bf16_bits(f[6]) | (bf16_bits(f[7]) << 16));
+        return make_uint4(pk2(f[0], f[1]), pk2(f[2], f[3]), pk2(f[4], f[5]), pk2(f[6], f[7]));
     }
 };
 
-__device__ __forceinline__ float act_fn(float v, float slope) { return v > 0.f ? v : v * slope; }
+// ReLU (slope 0) / LeakyReLU (0 < slope < 1) / identity (slope 1): max(v, v*slope), two VALU ops, no select
+__device__ __forceinline__ float act_fn(float v, float slope) { return fmaxf(v, v * slope); }
 __device__ __forceinline__ float act_grad(float v, float slope) { return v > 0.f ? 1.f : slope; }
 
 // group of image n given group start offsets gs[0..G] (gs[G] == N)

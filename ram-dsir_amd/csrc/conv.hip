@@ -14,6 +14,7 @@
 //   MFMA       = v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, bit-exact fmaf chain)
 #include "common.h"
 #include "../../include/ramdsir.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -160,6 +161,170 @@ __device__ __forceinline__ uint4 gather_slot(const rd_src_t* src, const SlotCtx<
     return Slot<T>::pack(v);
 }
 
+// ------------------------------------------------------------------------------------ loads-first tile fill
+// The tile loaders keep many independent 16-byte loads in flight per thread (the layers are HBM-bound):
+// phase A issues the loads of a whole batch of items, phase B transforms and stores them to LDS.  The
+// source mode is resolved OUTSIDE the item loops so that each loop body is straight-line code.
+__device__ __forceinline__ rd_src_t select_src(const rd_src_t* src, int si) {
+    rd_src_t s;
+    s.ptr = si ? src[1].ptr : src[0].ptr;
+    s.ptr2 = si ? src[1].ptr2 : src[0].ptr2;
+    s.scale = si ? src[1].scale : src[0].scale;
+    s.shift = si ? src[1].shift : src[0].shift;
+    s.q = si ? src[1].q : src[0].q;
+    s.mode = si ? src[1].mode : src[0].mode;
+    s.C = si ? src[1].C : src[0].C;
+    s.slope = si ? src[1].slope : src[0].slope;
+    s.n_off = si ? src[1].n_off : src[0].n_off;
+    s.g_fixed = si ? src[1].g_fixed : src[0].g_fixed;
+    s.pad_ = 0;
+    return s;
+}
+
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <typename T, int MODE, int BATCH, typename MapFn, typename StoreFn>
+__device__ __forceinline__ void tile_fill_mode(const rd_src_t& s, const SlotCtx<T>& k, int n, int H, int W, int tid, int total,
+                                               MapFn map, StoreFn store) {
+    constexpr int S = Slot<T>::N;
+    constexpr int NQ = (MODE == RD_SRC_POOL || MODE == RD_SRC_UP) ? 4 : (MODE == RD_SRC_BNBWD ? 2 : 1);
+    const int C = s.C;
+    const T* base = reinterpret_cast<const T*>(s.ptr) + k.c;
+    const T* base2 = reinterpret_cast<const T*>(s.ptr2) + k.c;
+    const int nn = n + s.n_off;
+    for (int idx0 = tid; idx0 < total; idx0 += 256 * BATCH) {
+        uint4 raw[BATCH][NQ];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int idx = idx0 + b * 256;
+            int y = 0, x = 0;
+            const bool in = idx < total && map(idx, y, x);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) raw[b][q] = make_uint4(0, 0, 0, 0);
+            if (in) {
+                if constexpr (MODE == RD_SRC_RAW || MODE == RD_SRC_AFF || MODE == RD_SRC_AFFACT) {
+                    raw[b][0] = ld16(base + ((size_t)(nn * H + y) * W + x) * C);
+                } else if constexpr (MODE == RD_SRC_BNBWD) {
+                    const size_t off = ((size_t)(nn * H + y) * W + x) * C;
+                    raw[b][0] = ld16(base + off);
+                    raw[b][1] = ld16(base2 + off);
+                } else if constexpr (MODE == RD_SRC_POOL) {
+                    const int Ws = 2 * W;
+                    const T* p00 = base + ((size_t)(nn * 2 * H + 2 * y) * Ws + 2 * x) * C;
+                    raw[b][0] = ld16(p00);
+                    raw[b][1] = ld16(p00 + C);
+                    raw[b][2] = ld16(p00 + (size_t)Ws * C);
+                    raw[b][3] = ld16(p00 + (size_t)Ws * C + C);
+                } else {  // UP
+                    const int Hs = H >> 1, Ws = W >> 1;
+                    int y0, y1, x0, x1;
+                    float ly, lx;
+                    up2_coord(y, Hs, y0, y1, ly);
+                    up2_coord(x, Ws, x0, x1, lx);
+                    const T* pn = base + (size_t)nn * Hs * Ws * C;
+                    raw[b][0] = ld16(pn + ((size_t)y0 * Ws + x0) * C);
+                    raw[b][1] = ld16(pn + ((size_t)y0 * Ws + x1) * C);
+                    raw[b][2] = ld16(pn + ((size_t)y1 * Ws + x0) * C);
+                    raw[b][3] = ld16(pn + ((size_t)y1 * Ws + x1) * C);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int idx = idx0 + b * 256;
+            if (idx >= total) continue;
+            int y = 0, x = 0;
+            const bool in = map(idx, y, x);
+            float v[S];
+#pragma unroll
+            for (int e = 0; e < S; ++e) v[e] = 0.f;
+            if (in) {
+                if constexpr (MODE == RD_SRC_RAW) {
+                    store(idx, raw[b][0]);
+                    continue;
+                } else if constexpr (MODE == RD_SRC_AFF) {
+                    Slot<T>::unpack(raw[b][0], v);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) v[e] = v[e] * k.sc[e] + k.sh[e];
+                } else if constexpr (MODE == RD_SRC_AFFACT) {
+                    Slot<T>::unpack(raw[b][0], v);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * k.sc[e] + k.sh[e], s.slope);
+                } else if constexpr (MODE == RD_SRC_BNBWD) {
+                    float zz[S];
+                    Slot<T>::unpack(raw[b][0], v);
+                    Slot<T>::unpack(raw[b][1], zz);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) v[e] = k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e];
+                } else if constexpr (MODE == RD_SRC_POOL) {
+                    float t[S];
+                    Slot<T>::unpack(raw[b][0], v);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * k.sc[e] + k.sh[e], s.slope);
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) {
+                        Slot<T>::unpack(raw[b][j], t);
+#pragma unroll
+                        for (int e = 0; e < S; ++e) v[e] = fmaxf(v[e], act_fn(t[e] * k.sc[e] + k.sh[e], s.slope));
+                    }
+                } else {  // UP
+                    const int Hs = H >> 1, Ws = W >> 1;
+                    int y0, y1, x0, x1;
+                    float ly, lx;
+                    up2_coord(y, Hs, y0, y1, ly);
+                    up2_coord(x, Ws, x0, x1, lx);
+                    float t00[S], t01[S], t10[S], t11[S];
+                    Slot<T>::unpack(raw[b][0], t00);
+                    Slot<T>::unpack(raw[b][1], t01);
+                    Slot<T>::unpack(raw[b][2], t10);
+                    Slot<T>::unpack(raw[b][3], t11);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) {
+                        const float top = t00[e] + lx * (t01[e] - t00[e]);
+                        const float bot = t10[e] + lx * (t11[e] - t10[e]);
+                        const float u = top + ly * (bot - top);
+                        v[e] = act_fn(u * k.sc[e] + k.sh[e], s.slope);
+                    }
+                }
+            }
+            store(idx, Slot<T>::pack(v));
+        }
+    }
+}
+
+// fills `total` items (item idx -> (pixel, this thread's channel slot)); map(idx, y, x) gives the conv-frame
+// pixel and whether it lies inside the image; store(idx, u) writes the 16-byte slot to LDS.
+template <typename T, typename MapFn, typename StoreFn>
+__device__ __forceinline__ void tile_fill(const rd_src_t* src, const SlotCtx<T>& k, int n, int H, int W, int tid, int total,
+                                          MapFn map, StoreFn store) {
+    constexpr int S = Slot<T>::N;
+    if (k.si < 0) {
+        for (int idx = tid; idx < total; idx += 256) store(idx, make_uint4(0, 0, 0, 0));
+        return;
+    }
+    const rd_src_t s = select_src(src, k.si);
+    const bool fast = (s.C % S) == 0 && (s.C - k.c) >= S;
+    if (!fast) {                                           // odd channel counts (3-channel image, 2/3-class dlogits)
+        for (int idx = tid; idx < total; idx += 256) {
+            int y = 0, x = 0;
+            float v[S];
+#pragma unroll
+            for (int e = 0; e < S; ++e) v[e] = 0.f;
+            if (map(idx, y, x)) load_slot<T>(s, k, n, y, x, H, W, v);
+            store(idx, Slot<T>::pack(v));
+        }
+        return;
+    }
+    switch (s.mode) {
+    case RD_SRC_RAW: tile_fill_mode<T, RD_SRC_RAW, 6>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_AFF: tile_fill_mode<T, RD_SRC_AFF, 6>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_AFFACT: tile_fill_mode<T, RD_SRC_AFFACT, 6>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_BNBWD: tile_fill_mode<T, RD_SRC_BNBWD, 3>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_POOL: tile_fill_mode<T, RD_SRC_POOL, 2>(s, k, n, H, W, tid, total, map, store); break;
+    default: tile_fill_mode<T, RD_SRC_UP, 2>(s, k, n, H, W, tid, total, map, store); break;
+    }
+}
+
 __device__ __forceinline__ GroupMap make_gm(const int32_t* gstart, int G) {
     GroupMap gm;
     gm.G = G;
@@ -301,6 +466,31 @@ __device__ __forceinline__ void grad_item(const rd_dst_t& d, int g_img, int n, i
     }
 }
 
+// plain destination, full 16-byte slots: g = da * act'(z*sc+sh) (+ old g); b1 += g, b2 += g*z
+template <typename T>
+__device__ __forceinline__ void grad_plain(const rd_dst_t& d, int n, int y, int x, int H, int W, int cd, const float* da,
+                                           const float* sc, const float* sh, float* b1, float* b2) {
+    constexpr int S = Slot<T>::N;
+    T* gp = reinterpret_cast<T*>(d.g);
+    const T* zp = reinterpret_cast<const T*>(d.z);
+    const size_t idx = ((size_t)((n + d.n_off) * H + y) * W + x) * d.Cd + cd;
+    float z[S], gw[S];
+    uint4 zu = make_uint4(0, 0, 0, 0), gu = make_uint4(0, 0, 0, 0);
+    if (zp) zu = ld16(zp + idx);
+    if (d.accumulate) gu = ld16(gp + idx);
+    Slot<T>::unpack(zu, z);
+    Slot<T>::unpack(gu, gw);
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        const float m = (d.act && zp) ? act_grad(z[e] * sc[e] + sh[e], d.slope) : 1.f;
+        const float gn = da[e] * m;
+        b1[e] += gn;
+        b2[e] += gn * z[e];
+        gw[e] += gn;
+    }
+    *reinterpret_cast<uint4*>(gp + idx) = Slot<T>::pack(gw);
+}
+
 // picks dst[0] or dst[1] field by field (lane-varying di): keeps the kernarg struct out of scratch
 __device__ __forceinline__ rd_dst_t select_dst(const rd_conv_t& p, int di) {
     rd_dst_t d;
@@ -341,6 +531,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
     const GroupMap gm = make_gm(p.gstart, p.G);
     const int g = group_of(gm, n);
     const int H = p.H, W = p.W;
+    const int slot = (blockIdx.x + 7 * blockIdx.z) % RD_STAT_SLOTS;
 
     f32x16 acc[2][NB];
 #pragma unroll
@@ -357,18 +548,37 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
             const int s = tid & 3;                         // idx & 3 is constant per thread (stride 256)
             SlotCtx<T> ctx;
             slot_ctx<T>(ctx, p.src, p.nsrc, p.Cin, g, c0 + s * S);
-            for (int idx = tid; idx < PH * PW * 4; idx += 256) {
+            auto map = [&](int idx, int& y, int& x) -> bool {
                 const int pix = idx >> 2;
                 const int py = pix / PW, px = pix - py * PW;
-                const uint4 u = gather_slot<T>(p.src, ctx, n, y0 - HALO + py, x0 - HALO + px, H, W);
+                y = y0 - HALO + py;
+                x = x0 - HALO + px;
+                return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            };
+            auto store = [&](int idx, const uint4& u) {
+                const int pix = idx >> 2;
                 s_in[pix * 4 + (s ^ ((pix >> 2) & 3))] = u;
-            }
+            };
+            tile_fill<T>(p.src, ctx, n, H, W, tid, PH * PW * 4, map, store);
         }
-        for (int idx = tid; idx < TAPS * NT * 4; idx += 256) {
-            const int s = idx & 3, rec = idx >> 2;
-            const int nn = rec % NT, tap = rec / NT;
-            const uint4 u = *reinterpret_cast<const uint4*>(wbase + ((size_t)(tap * p.CoutPad + n0 + nn) * p.CinPad + c0 + s * S));
-            s_w[rec * 4 + (s ^ ((nn >> 2) & 3))] = u;
+        {
+            constexpr int WTOT = TAPS * NT * 4, WIT = (WTOT + 255) / 256;
+            uint4 wr[WIT];
+#pragma unroll
+            for (int b = 0; b < WIT; ++b) {
+                const int idx = tid + b * 256;
+                const int s = idx & 3, rec = idx >> 2;
+                const int nn = rec % NT, tap = rec / NT;
+                wr[b] = make_uint4(0, 0, 0, 0);
+                if (idx < WTOT) wr[b] = ld16(wbase + ((size_t)(tap * p.CoutPad + n0 + nn) * p.CinPad + c0 + s * S));
+            }
+#pragma unroll
+            for (int b = 0; b < WIT; ++b) {
+                const int idx = tid + b * 256;
+                const int s = idx & 3, rec = idx >> 2;
+                const int nn = rec % NT;
+                if (idx < WTOT) s_w[rec * 4 + (s ^ ((nn >> 2) & 3))] = wr[b];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -473,8 +683,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
         if (tid < 32 && cb + tid < p.Cout) {
             if (p.emode == 0) {
                 if (p.stats) {
-                    atomicAdd(&p.stats[((size_t)g * p.Cout + cb + tid) * 2 + 0], s_red[tid * 2 + 0]);
-                    atomicAdd(&p.stats[((size_t)g * p.Cout + cb + tid) * 2 + 1], s_red[tid * 2 + 1]);
+                    const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + cb + tid) * 2;
+                    atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
                 }
             } else {
                 const int cch = cb + tid;
@@ -483,12 +694,329 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
                 if (dd.kind != RD_DST_NONE && dd.bstats) {
                     const int cdd = cch - (dj ? p.c_split : 0);
                     const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
-                    atomicAdd(&dd.bstats[((size_t)gd * dd.Cd + cdd) * 2 + 0], s_red[tid * 2 + 0]);
-                    atomicAdd(&dd.bstats[((size_t)gd * dd.Cd + cdd) * 2 + 1], s_red[tid * 2 + 1]);
+                    const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
+                    atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
                 }
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------ small-channel persistent kernel
+// Cin <= one 64-byte chunk and Cout <= 32 (every 400x400 / 200x200 layer of the U-Net, forward and dgrad):
+// these layers are HBM-bound, so the kernel is built around keeping loads in flight.  A workgroup walks
+// `tiles_per_wg` consecutive 8x32 tiles of one image; the packed weights stay in LDS for all of them; the
+// raw 16-byte slots of tile t+1 are requested into registers BEFORE the MFMAs and the epilogue of tile t
+// and are transformed / written to LDS afterwards (register double buffering).  BN sums are kept in
+// registers across the tiles and flushed with one set of atomics per workgroup.
+template <typename T, int NIT>
+__device__ __forceinline__ void pf_issue(uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, int n, int H, int W, int tid,
+                                         int total, int yh, int xh, int PW) {
+    const int C = s.C;
+    const T* base = reinterpret_cast<const T*>(s.ptr) + k.c;
+    const T* base2 = reinterpret_cast<const T*>(s.ptr2) + k.c;
+    const int nn = n + s.n_off;
+    const bool two = s.mode == RD_SRC_BNBWD;
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) {
+        const int idx = tid + b * 256;
+        raw[b][0] = make_uint4(0, 0, 0, 0);
+        raw[b][1] = make_uint4(0, 0, 0, 0);
+        if (idx < total) {
+            const int pix = idx >> 2;
+            const int py = pix / PW, px = pix - py * PW;
+            const int y = yh + py, x = xh + px;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                const size_t off = ((size_t)(nn * H + y) * W + x) * C;
+                raw[b][0] = ld16(base + off);
+                if (two) raw[b][1] = ld16(base2 + off);
+            }
+        }
+    }
+}
+
+template <typename T, int NIT>
+__device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, int H, int W, int tid,
+                                           int total, int yh, int xh, int PW, uint4* s_in, int sslot) {
+    constexpr int S = Slot<T>::N;
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) {
+        const int idx = tid + b * 256;
+        if (idx >= total) continue;
+        const int pix = idx >> 2;
+        const int py = pix / PW, px = pix - py * PW;
+        const int y = yh + py, x = xh + px;
+        const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        uint4 u = raw[b][0];
+        if (s.mode != RD_SRC_RAW) {
+            float v[S];
+            Slot<T>::unpack(raw[b][0], v);
+            if (s.mode == RD_SRC_AFF) {
+#pragma unroll
+                for (int e = 0; e < S; ++e) v[e] = v[e] * k.sc[e] + k.sh[e];
+            } else if (s.mode == RD_SRC_AFFACT) {
+#pragma unroll
+                for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * k.sc[e] + k.sh[e], s.slope);
+            } else {
+                float zz[S];
+                Slot<T>::unpack(raw[b][1], zz);
+#pragma unroll
+                for (int e = 0; e < S; ++e) v[e] = k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e];
+            }
+            u = in ? Slot<T>::pack(v) : make_uint4(0, 0, 0, 0);
+        }
+        s_in[pix * 4 + (sslot ^ ((pix >> 2) & 3))] = u;
+    }
+}
+
+// SRCG: sources may need the generic (synchronous) loader: max-pool / upsample / odd channel counts.
+// EPI : 0 forward, 1 gradient with plain destinations only, 2 gradient with pool / upsample destinations.
+template <typename T, int TAPS, bool SRCG, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, int tiles_per_wg) {
+    constexpr int S = Slot<T>::N;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int NT = 32, SL = 32 / S;
+    constexpr int TOTAL = PH * PW * 4, NIT = (TOTAL + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* s_in = reinterpret_cast<uint4*>(smem);          // [PH*PW][4]
+    uint4* s_w = s_in + PH * PW * 4;                       // [TAPS][32][4]
+    float* s_out = reinterpret_cast<float*>(s_w + TAPS * NT * 4);   // [TH*TW][32]
+    float* s_red = s_out + TH * TW * 32;                   // [32][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + TW - 1) / TW, ntiles = tiles_x * ((H + TH - 1) / TH);
+    const int t_begin = blockIdx.x * tiles_per_wg;
+    const int t_end = min(ntiles, t_begin + tiles_per_wg);
+    const int n = blockIdx.z;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+    const int g = group_of(gm, n);
+    const int slot = (blockIdx.x + 7 * blockIdx.z) % RD_STAT_SLOTS;
+
+    // ---- packed weights: once per workgroup
+    {
+        const T* wbase = reinterpret_cast<const T*>(p.w);
+        constexpr int WTOT = TAPS * NT * 4, WIT = (WTOT + 255) / 256;
+        uint4 wr[WIT];
+#pragma unroll
+        for (int b = 0; b < WIT; ++b) {
+            const int idx = tid + b * 256;
+            const int sw = idx & 3, rec = idx >> 2;
+            const int nn = rec % NT, tap = rec / NT;
+            wr[b] = make_uint4(0, 0, 0, 0);
+            if (idx < WTOT) wr[b] = ld16(wbase + ((size_t)(tap * p.CoutPad + nn) * p.CinPad + sw * S));
+        }
+#pragma unroll
+        for (int b = 0; b < WIT; ++b) {
+            const int idx = tid + b * 256;
+            const int sw = idx & 3, rec = idx >> 2;
+            const int nn = rec % NT;
+            if (idx < WTOT) s_w[rec * 4 + (sw ^ ((nn >> 2) & 3))] = wr[b];
+        }
+    }
+    if (tid < 64) s_red[tid] = 0.f;
+
+    // ---- loader constants of this thread (its channel slot never changes)
+    const int sslot = tid & 3;
+    SlotCtx<T> ctx;
+    slot_ctx<T>(ctx, p.src, p.nsrc, p.Cin, g, sslot * S);
+    const rd_src_t ssrc = select_src(p.src, ctx.si > 0 ? 1 : 0);
+    // !SRCG: the host guarantees simple modes and full slots; a slot beyond Cin prefetches zeros (mode RAW)
+    bool pre = true;
+    if constexpr (SRCG)
+        pre = ctx.si >= 0 && (ssrc.C % S) == 0 && (ssrc.C - ctx.c) >= S &&
+              (ssrc.mode == RD_SRC_RAW || ssrc.mode == RD_SRC_AFF || ssrc.mode == RD_SRC_AFFACT || ssrc.mode == RD_SRC_BNBWD);
+    const bool live_slot = ctx.si >= 0;
+
+    // ---- epilogue constants of this thread
+    const int sl = tid % SL;
+    const int c = sl * S;
+    const int di = (p.emode == 1 && c >= p.c_split) ? 1 : 0;
+    const rd_dst_t d = select_dst(p, di);
+    const int cd = c - (di ? p.c_split : 0);
+    float dsc[S], dsh[S], b1[S], b2[S];
+    {
+        const int gd = d.g_fixed >= 0 ? d.g_fixed : g;
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const bool ok = p.emode == 1 && c < p.Cout && d.kind != RD_DST_NONE && d.scale && (cd + e < d.Cd);
+            dsc[e] = ok ? d.scale[gd * d.Cd + cd + e] : 1.f;
+            dsh[e] = ok ? d.shift[gd * d.Cd + cd + e] : 0.f;
+            b1[e] = b2[e] = 0.f;
+        }
+    }
+    const bool cok = li < p.Cout;
+    const float bsv = (p.emode == 0 && cok && p.bias) ? p.bias[li] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    T* out = reinterpret_cast<T*>(p.out);
+
+    uint4 raw[NIT][2];
+    if (pre && t_begin < t_end)
+        pf_issue<T, NIT>(raw, ssrc, ctx, n, live_slot ? H : 0, W, tid, TOTAL, (t_begin / tiles_x) * TH - HALO, (t_begin % tiles_x) * TW - HALO, PW);
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int x0 = (t % tiles_x) * TW, y0 = (t / tiles_x) * TH;
+        if (pre) {
+            pf_consume<T, NIT>(raw, ssrc, ctx, live_slot ? H : 0, W, tid, TOTAL, y0 - HALO, x0 - HALO, PW, s_in, sslot);
+        } else if constexpr (SRCG) {
+            auto map = [&](int idx, int& y, int& x) -> bool {
+                const int pix = idx >> 2;
+                const int py = pix / PW, px = pix - py * PW;
+                y = y0 - HALO + py;
+                x = x0 - HALO + px;
+                return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            };
+            auto store = [&](int idx, const uint4& u) {
+                const int pix = idx >> 2;
+                s_in[pix * 4 + (sslot ^ ((pix >> 2) & 3))] = u;
+            };
+            tile_fill<T>(p.src, ctx, n, H, W, tid, TOTAL, map, store);
+        }
+        __syncthreads();
+        if (pre && t + 1 < t_end)
+            pf_issue<T, NIT>(raw, ssrc, ctx, n, live_slot ? H : 0, W, tid, TOTAL, ((t + 1) / tiles_x) * TH - HALO, ((t + 1) % tiles_x) * TW - HALO, PW);
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int pix = (wave * 2 + mb + kh) * PW + li + kw;
+                Mma<T>::chunk(s_in + pix * 4, (pix >> 2) & 3, s_w + (tap * NT + li) * 4, (li >> 2) & 3, h, acc[mb]);
+            }
+        }
+        // stage the 32-channel block (s_out is a separate LDS region: no barrier needed before writing it)
+        const bool interior = (x0 + TW <= W) && (y0 + TH <= H);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int y = y0 + wave * 2 + mb;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = acc[mb][r] + bsv;
+                s_out[((wave * 2 + mb) * TW + col) * 32 + li] = v;
+                if constexpr (EPI == 0) {
+                    if (interior || (y < H && x0 + col < W)) { s1 += v; s2 += v * v; }
+                }
+            }
+        }
+        __syncthreads();
+        if (c < p.Cout) {
+            for (int idx = tid; idx < TH * TW * SL; idx += 256) {
+                const int pix = idx / SL;
+                const int y = y0 + pix / TW, x = x0 + pix % TW;
+                if (y >= H || x >= W) continue;
+                float v[S];
+#pragma unroll
+                for (int e = 0; e < S; e += 4) {
+                    const float4 f = *reinterpret_cast<const float4*>(s_out + pix * 32 + sl * S + e);
+                    v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
+                }
+                if constexpr (EPI == 0) {
+                    store_vec<T>(out + ((size_t)(n * H + y) * W + x) * p.Cout + c, v, p.Cout - c, (p.Cout % S) == 0);
+                } else if constexpr (EPI == 1) {
+                    if (d.kind != RD_DST_NONE) grad_plain<T>(d, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
+                } else {
+                    if (d.kind != RD_DST_NONE) grad_item<T>(d, g, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
+                }
+            }
+        }
+        __syncthreads();                                   // s_in / s_out are rewritten by the next tile
+    }
+
+    // ---- flush the BN sums of all tiles of this workgroup
+    if constexpr (EPI == 0) {
+        if (p.stats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0 && cok) {
+                atomicAdd(&s_red[li * 2 + 0], s1);
+                atomicAdd(&s_red[li * 2 + 1], s2);
+            }
+        }
+    } else if (c < p.Cout && d.kind != RD_DST_NONE && d.bstats) {
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            atomicAdd(&s_red[(sl * S + e) * 2 + 0], b1[e]);
+            atomicAdd(&s_red[(sl * S + e) * 2 + 1], b2[e]);
+        }
+    }
+    __syncthreads();
+    if (tid < 32 && tid < p.Cout) {
+        if (p.emode == 0) {
+            if (p.stats) {
+                const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + tid) * 2;
+                atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
+            }
+        } else {
+            const int dj = tid >= p.c_split ? 1 : 0;
+            const rd_dst_t dd = select_dst(p, dj);
+            if (dd.kind != RD_DST_NONE && dd.bstats) {
+                const int cdd = tid - (dj ? p.c_split : 0);
+                const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
+                const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
+                atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
+            }
+        }
+    }
+}
+
+template <typename T, int TAPS, bool SRCG, int EPI>
+int launch_conv_small(const rd_conv_t& p, hipStream_t st) {
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    const size_t lds = (size_t)(PH * PW * 4 + TAPS * 32 * 4) * sizeof(uint4) + (size_t)(TH * TW * 32 + 64) * sizeof(float);
+    const int ntiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
+    static int tpw_env = -1;
+    if (tpw_env < 0) { const char* e = getenv("RD_TPW"); tpw_env = e ? atoi(e) : 0; }
+    int tpw = tpw_env > 0 ? tpw_env : 4;
+    while (tpw_env <= 0 && tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * p.N < 1536) tpw >>= 1;     // keep >= ~3 workgroups per CU-slot
+    dim3 grid((ntiles + tpw - 1) / tpw, 1, p.N);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<T, TAPS, SRCG, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_small_kernel<T, TAPS, SRCG, EPI>), grid, dim3(256), lds, st, p, tpw);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int TAPS>
+int dispatch_conv_small(const rd_conv_t& p, hipStream_t st) {
+    constexpr int S = Slot<T>::N;
+    bool srcg = false;
+    for (int i = 0; i < p.nsrc; ++i) {
+        const int m = p.src[i].mode;
+        if (!(m == RD_SRC_RAW || m == RD_SRC_AFF || m == RD_SRC_AFFACT || m == RD_SRC_BNBWD) || (p.src[i].C % S)) srcg = true;
+    }
+    int epi = 0;
+    if (p.emode == 1) {
+        epi = 1;
+        for (int i = 0; i < 2; ++i) {
+            const rd_dst_t& d = p.dst[i];
+            if (d.kind == RD_DST_NONE) continue;
+            if (d.kind != RD_DST_PLAIN || (d.Cd % S)) epi = 2;
+        }
+    } else if (p.Cout % S) {
+        epi = 0;                                           // store_vec handles narrow outputs
+    }
+#define RD_CS(SG, EP) return launch_conv_small<T, TAPS, SG, EP>(p, st)
+    if (!srcg) { if (epi == 0) RD_CS(false, 0); if (epi == 1) RD_CS(false, 1); RD_CS(false, 2); }
+    if (epi == 0) RD_CS(true, 0);
+    if (epi == 1) RD_CS(true, 1);
+    RD_CS(true, 2);
+#undef RD_CS
 }
 
 template <typename T, int TAPS, int NB>
@@ -511,6 +1039,9 @@ int launch_conv(const rd_conv_t& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_conv(const rd_conv_t& p, hipStream_t st) {
+    constexpr int CK = 4 * Slot<T>::N;
+    if (p.CinPad == CK && p.CoutPad == 32)                 // one K chunk, one N block: the HBM-bound layers
+        return p.taps == 9 ? dispatch_conv_small<T, 9>(p, st) : dispatch_conv_small<T, 1>(p, st);
     const bool nb2 = (p.CoutPad % 64) == 0;
     if (p.taps == 9) return nb2 ? launch_conv<T, 9, 2>(p, st) : launch_conv<T, 9, 1>(p, st);
     return nb2 ? launch_conv<T, 1, 2>(p, st) : launch_conv<T, 1, 1>(p, st);
@@ -548,33 +1079,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int Cout
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    SlotCtx<T> ctx_a, ctx_z;
+    int g_ctx = -1;
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         const int n = tile / (tiles_x * tiles_y);
         const int trem = tile - n * tiles_x * tiles_y;
         const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
         const int g = group_of(gm, n);
         __syncthreads();
+        if (g != g_ctx) {                                  // BN coefficients depend on the image's group only
+            slot_ctx<T>(ctx_a, p.a, p.na, p.Cin, g, cbase + (tid % (CA / S)) * S);
+            slot_ctx<T>(ctx_z, &p.dz, 1, p.Cout, g, nbase + (tid % (CZ / S)) * S);
+            g_ctx = g;
+        }
         {
             const int s = tid % (CA / S);                  // constant per thread: 256 % (CA/S) == 0
-            SlotCtx<T> ctx;
-            slot_ctx<T>(ctx, p.a, p.na, p.Cin, g, cbase + s * S);
-            for (int idx = tid; idx < PH * PW * (CA / S); idx += 256) {
+            const SlotCtx<T>& ctx = ctx_a;
+            auto map = [&](int idx, int& y, int& x) -> bool {
                 const int pix = idx / (CA / S);
                 const int py = pix / PW, px = pix - py * PW;
-                const uint4 u = gather_slot<T>(p.a, ctx, n, y0 - HALO + py, x0 - HALO + px, H, W);
+                y = y0 - HALO + py;
+                x = x0 - HALO + px;
+                return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            };
+            auto store = [&](int idx, const uint4& u) {
+                const int pix = idx / (CA / S);
                 *reinterpret_cast<uint4*>(s_a + pix * CA + s * S) = u;
-            }
+            };
+            tile_fill<T>(p.a, ctx, n, H, W, tid, PH * PW * (CA / S), map, store);
         }
         {
             const int s = tid % (CZ / S);
-            SlotCtx<T> ctx;
-            slot_ctx<T>(ctx, &p.dz, 1, p.Cout, g, nbase + s * S);
-            for (int idx = tid; idx < TH * TW * (CZ / S); idx += 256) {
+            const SlotCtx<T>& ctx = ctx_z;
+            auto map = [&](int idx, int& y, int& x) -> bool {
                 const int pix = idx / (CZ / S);
                 const int py = pix / TW, px = pix - py * TW;
-                const uint4 u = gather_slot<T>(&p.dz, ctx, n, y0 + py, x0 + px, H, W);
+                y = y0 + py;
+                x = x0 + px;
+                return y < H && x < W;
+            };
+            auto store = [&](int idx, const uint4& u) {
+                const int pix = idx / (CZ / S);
                 *reinterpret_cast<uint4*>(s_z + pix * CZ + s * S) = u;
-            }
+            };
+            tile_fill<T>(&p.dz, ctx, n, H, W, tid, TH * TW * (CZ / S), map, store);
         }
         __syncthreads();
         if constexpr (sizeof(T) == 2) {

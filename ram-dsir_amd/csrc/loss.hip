@@ -78,17 +78,22 @@ __global__ __launch_bounds__(256) void seg_loss_sums_kernel(const rd_seg_loss_t 
         p.partial[(size_t)blockIdx.x * NS_MAX + threadIdx.x] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
 }
 
-__global__ void seg_loss_final_kernel(const rd_seg_loss_t p, int nblocks) {
+// 16 waves: wave w reduces sums w, w+16 over the per-block partials (lanes stride over blocks, fp64)
+__global__ __launch_bounds__(1024) void seg_loss_final_kernel(const rd_seg_loss_t p, int nblocks) {
     __shared__ double sd[NS_MAX];
-    const int j = threadIdx.x;
-    if (j < NS_MAX) {
+    const int lane = threadIdx.x & 63;
+    for (int j = threadIdx.x >> 6; j < NS_MAX; j += 16) {
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += (double)p.partial[(size_t)b * NS_MAX + j];
-        sd[j] = s;
-        p.partial[(size_t)nblocks * NS_MAX + j] = (float)s;             // sums for the gradient pass
+        for (int b = lane; b < nblocks; b += 64) s += (double)p.partial[(size_t)b * NS_MAX + j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            sd[j] = s;
+            p.partial[(size_t)nblocks * NS_MAX + j] = (float)s;             // sums for the gradient pass
+        }
     }
     __syncthreads();
-    if (j == 0) {
+    if (threadIdx.x == 0) {
         const double eps = 1e-5;
         double seg1, seg2, d1, d2, cons;
         if (p.kind == 0) {
@@ -291,7 +296,7 @@ int rd_seg_loss(const rd_seg_loss_t* p, int dtype, void* stream) {
     const int NS = p->kind == 0 ? 8 : 3 + 5 * (p->K - 1);
     if (dtype == RD_BF16) hipLaunchKernelGGL(seg_loss_sums_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, *p, NS);
     else hipLaunchKernelGGL(seg_loss_sums_kernel<float>, dim3(nb), dim3(256), 0, st, *p, NS);
-    hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(64), 0, st, *p, nb);
+    hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(1024), 0, st, *p, nb);
     if (p->dlogits) {
         if (dtype == RD_BF16) hipLaunchKernelGGL(seg_loss_grad_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, *p, nb);
         else hipLaunchKernelGGL(seg_loss_grad_kernel<float>, dim3(nb), dim3(256), 0, st, *p, nb);

@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, 'libramdsir_hip.so')
 
 RD_F32, RD_BF16 = 0, 1
 MAXG = 8
+STAT_SLOTS = 64
 SRC_RAW, SRC_AFF, SRC_AFFACT, SRC_POOL, SRC_UP, SRC_BNBWD = range(6)
 DST_PLAIN, DST_POOL, DST_UPY, DST_NONE = range(4)
 

@@ -183,8 +183,8 @@ class Act:
         self.g_written = False
         G = plan.G
         if norm is not None:
-            self.stats = plan.alloc_stat(G * Cc * 2)
-            self.bstats = plan.alloc_stat(G * Cc * 2)
+            self.stats = plan.alloc_stat(G * L.STAT_SLOTS * Cc * 2)
+            self.bstats = plan.alloc_stat(G * L.STAT_SLOTS * Cc * 2)
             self.scale, self.shift = plan.alloc_f32(G * Cc), plan.alloc_f32(G * Cc)
             self.mean, self.invstd = plan.alloc_f32(G * Cc), plan.alloc_f32(G * Cc)
             self.P, self.Q, self.R = plan.alloc_f32(G * Cc), plan.alloc_f32(G * Cc), plan.alloc_f32(G * Cc)
@@ -250,7 +250,7 @@ class Plan:
 
     def stat_view(self, handle, G, Cc):
         o = self._stat_off[handle[1]]
-        return self.stat_arena[o:o + G * Cc * 2].view(G, Cc, 2)
+        return self.stat_arena[o:o + G * L.STAT_SLOTS * Cc * 2].view(G, L.STAT_SLOTS, Cc, 2).sum(1)
 
     # ---- graph construction
     def conv(self, mname, name, inputs, Cout, taps, norm=None, act=False, up_out=False, H=None, W=None, N=None):

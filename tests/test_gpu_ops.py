@@ -17,6 +17,14 @@ import gpu_util as U                   # noqa: E402
 DTYPES = ['f32', 'bf16']
 
 
+def _slotted(t_gc2):
+    """[G][C][2] sums spread over the RD_STAT_SLOTS copies (uneven on purpose)."""
+    G, Cc, _ = t_gc2.shape
+    w = torch.rand(L.STAT_SLOTS)
+    w = w / w.sum()
+    return t_gc2[:, None] * w[None, :, None, None]
+
+
 def _params(G, Cc, gen):
     return 1.0 + 0.3 * torch.randn(G, Cc, generator=gen), 0.2 * torch.randn(G, Cc, generator=gen)
 
@@ -78,7 +86,7 @@ def test_conv_forward(case, dtype):
     ref = F.conv2d(a, w, bias, padding=k // 2)
     p = _conv_desc(keep, srcs, w, bias, N, H, W, gstart, dtype, taps)
     out = torch.full((N, H, W, Cout), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
-    stats = torch.zeros(G, Cout, 2, device=U.dev())
+    stats = torch.zeros(G, L.STAT_SLOTS, Cout, 2, device=U.dev())
     p.emode, p.out, p.stats = 0, out.data_ptr(), stats.data_ptr()
     L.check(L.lib().rd_conv(C.byref(p), U.DT[dtype][0], None), name)
     torch.cuda.synchronize()
@@ -87,7 +95,7 @@ def test_conv_forward(case, dtype):
                                           ref[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1) for g in range(G)])
     npx = H * W * max(gstart[g + 1] - gstart[g] for g in range(G))
     # sums of npx values: compare relative to sqrt(npx)*rms (stats are taken from the fp32 accumulators)
-    assert float((stats.cpu() - ref_stats).abs().max()) <= (1e-3 if dtype == 'bf16' else 1e-4) * npx * float(ref.abs().max() + 1) ** 2
+    assert float((stats.sum(1).cpu() - ref_stats).abs().max()) <= (1e-3 if dtype == 'bf16' else 1e-4) * npx * float(ref.abs().max() + 1) ** 2
 
 
 # ------------------------------------------------------------------------------------ conv gradient (dgrad + epilogues)
@@ -142,7 +150,7 @@ def test_conv_gradient_epilogues(case, dtype):
         d = L.RdDst()
         old = U.rnd(torch.randn(ys[i].shape, generator=gen), dtype) if accumulate else torch.zeros(ys[i].shape)
         gbuf = keep(U.nhwc(old if accumulate else torch.full(ys[i].shape, float('nan')), dtype))
-        bst = keep(torch.zeros(G, Cd, 2, device=U.dev()))
+        bst = keep(torch.zeros(G, L.STAT_SLOTS, Cd, 2, device=U.dev()))
         d.g, d.z = gbuf.data_ptr(), keep(U.nhwc(z, dtype)).data_ptr()
         d.scale, d.shift = keep(U.fdev(sc)).data_ptr(), keep(U.fdev(sh)).data_ptr()
         d.bstats, d.kind, d.act, d.accumulate, d.Cd, d.slope, d.n_off, d.g_fixed = bst.data_ptr(), kind, act, accumulate, Cd, slope, 0, -1
@@ -160,7 +168,7 @@ def test_conv_gradient_epilogues(case, dtype):
         rs = torch.stack([torch.stack([gref[gstart[g]:gstart[g + 1]].sum((0, 2, 3)),
                                        (gref * zz)[gstart[g]:gstart[g + 1]].sum((0, 2, 3))], -1) for g in range(G)])
         tol = (3e-2 if dtype == 'bf16' else 2e-4) * float(rs.abs().max() + gref.abs().sum() / Cd / G * 0.05 + 1e-3)
-        assert float((bst.cpu() - rs).abs().max()) <= tol, '%s bstats' % name
+        assert float((bst.sum(1).cpu() - rs).abs().max()) <= tol, '%s bstats' % name
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -186,7 +194,7 @@ def test_conv_bnbwd_loader_and_image_offsets(dtype):
     p.emode, p.c_split = 1, Ca
     old = U.rnd(torch.randn(4, Ca, H, W, generator=gen), dtype)
     gbuf = U.nhwc(old, dtype)
-    bst = torch.zeros(2, Ca, 2, device=U.dev())
+    bst = torch.zeros(2, L.STAT_SLOTS, Ca, 2, device=U.dev())
     d = L.RdDst()
     d.g, d.z = gbuf.data_ptr(), keep(U.nhwc(zprod, dtype)).data_ptr()
     d.scale, d.shift = keep(U.fdev(sc)).data_ptr(), keep(U.fdev(sh)).data_ptr()
@@ -199,7 +207,7 @@ def test_conv_bnbwd_loader_and_image_offsets(dtype):
     ref[2:4] += y.grad
     U.assert_close(U.from_nhwc(gbuf), ref, dtype, 'bnbwd', scale=3.0)
     assert float(bst[0].abs().max()) == 0.0                 # only producer group 1 was touched
-    np.testing.assert_allclose(bst[1, :, 0].cpu(), y.grad.sum((0, 2, 3)), rtol=0, atol=(0.5 if dtype == 'bf16' else 5e-3))
+    np.testing.assert_allclose(bst.sum(1)[1, :, 0].cpu(), y.grad.sum((0, 2, 3)), rtol=0, atol=(0.5 if dtype == 'bf16' else 5e-3))
 
 
 # ------------------------------------------------------------------------------------ wgrad
@@ -271,7 +279,8 @@ def test_bn_finalize_forward_and_backward():
     x = torch.randn(N, Cc, H, W, generator=gen) * 2 + 0.5
     gam, bet = _params(1, Cc, gen)
     stats = torch.stack([torch.stack([x[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), x[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
-                         for g in range(G)]).to(U.dev())
+                         for g in range(G)])
+    stats = _slotted(stats).to(U.dev())
     bufs = {k: torch.zeros(G, Cc, device=U.dev()) for k in ('scale', 'shift', 'mean', 'invstd')}
     gd, bd = gam[0].to(U.dev()), bet[0].to(U.dev())
     rm, rv = torch.zeros(Cc, device=U.dev()), torch.ones(Cc, device=U.dev())
@@ -312,7 +321,8 @@ def test_bn_finalize_forward_and_backward():
     L.check(L.lib().rd_bn_finalize_fwd(C.byref(p), None), 'bnf2')
     gy = torch.randn(N, Cc, H, W, generator=gen)
     bst = torch.stack([torch.stack([gy[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), (gy * x)[gstart[g]:gstart[g + 1]].sum((0, 2, 3))], -1)
-                       for g in range(G)]).to(U.dev())
+                       for g in range(G)])
+    bst = _slotted(bst).to(U.dev())
     q = L.RdBnBwd()
     dgam, dbet = torch.zeros(Cc, device=U.dev()), torch.zeros(Cc, device=U.dev())
     PQR = [torch.zeros(G, Cc, device=U.dev()) for _ in range(3)]
@@ -344,13 +354,13 @@ def test_upsample_stats_and_backward(dtype):
     t = U.rnd(torch.randn(N, Cc, h, w, generator=gen), dtype).requires_grad_(True)
     y = F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False)
     td = U.nhwc(t.detach(), dtype)
-    stats = torch.zeros(2, Cc, 2, device=U.dev())
+    stats = torch.zeros(2, L.STAT_SLOTS, Cc, 2, device=U.dev())
     gs = L.gstart_array(gstart)
     L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats), N, h, w, Cc, 2, gs, U.DT[dtype][0], None), 'upstats')
     torch.cuda.synchronize()
     ref = torch.stack([torch.stack([y[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), y[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
                        for g in range(2)]).detach()
-    np.testing.assert_allclose(stats.cpu(), ref, rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(stats.sum(1).cpu(), ref, rtol=1e-3, atol=1e-2)
     P, R = _params(2, Cc, gen)
     Q = 0.1 * torch.randn(2, Cc, generator=gen)
     g2 = U.rnd(torch.randn(N, Cc, 2 * h, 2 * w, generator=gen), dtype)
@@ -484,7 +494,7 @@ def test_layout_boundary_kernels(dtype):
     dy = torch.randn(N, Cc, H, W, generator=gen)
     old = U.rnd(torch.randn(N, Cc, H, W, generator=gen), dtype)
     gbuf = U.nhwc(old, dtype)
-    bst = torch.zeros(2, Cc, 2, device=U.dev())
+    bst = torch.zeros(2, L.STAT_SLOTS, Cc, 2, device=U.dev())
     dyd = dy.to(U.dev())
     L.check(L.lib().rd_grad_in(L.ptr(dyd), L.ptr(y), L.ptr(gbuf), L.ptr(scd), L.ptr(shd), L.ptr(bst), 1, 0.0, 1, N, Cc, H, W, 2, gs,
                                U.DT[dtype][0], None), 'grad_in')
@@ -493,7 +503,7 @@ def test_layout_boundary_kernels(dtype):
     U.assert_close(U.from_nhwc(gbuf), old + gnew, dtype, 'grad_in')
     rs = torch.stack([torch.stack([gnew[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), (gnew * x)[gstart[g]:gstart[g + 1]].sum((0, 2, 3))], -1)
                       for g in range(2)])
-    np.testing.assert_allclose(bst.cpu(), rs, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(bst.sum(1).cpu(), rs, rtol=1e-3, atol=1e-3)
     # column sums (bias gradient of out1)
     t3 = U.rnd(torch.randn(2, 3, 20, 30, generator=gen), dtype)
     t3d = U.nhwc(t3, dtype)
