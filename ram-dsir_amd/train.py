@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's code/train.py: same flags, same data layout, same checkpoint files, same
+training semantics (code/train.py:195-361, 363-528, 530-601) -- on the fused HIP training step.
+
+    python train.py --data_root ../dataset --dataset fundus --domain_idxs 1,2,3 --test_domain_idx 0 \\
+                    --ram --rec --is_out_domain --consistency --consistency_type kd --save_path outdir/fundus/target0
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...      # data parallel (RCCL)
+
+Differences, all deliberate: (i) RAM runs on the GPU per batch (the DataLoader workers only pick the partner
+image and lambda); (ii) the step is one captured hipGraph, so the five loss scalars are read every
+--log_every iterations instead of forcing a device sync every iteration (train.py:298-304); (iii) multi-GPU is
+one process per GPU with an RCCL gradient all-reduce instead of nn.DataParallel; (iv) tensorboard image
+grids and the source-tree snapshot (train.py:306-329,534-536) are not reproduced.
+"""
+import argparse
+import os
+import os.path as osp
+import random
+import sys
+from itertools import cycle
+
+HERE = osp.dirname(osp.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+
+import dataset.transform as trans
+from dataset.fundus import Fundus_Multi, Fundus
+from dataset.prostate import Prostate_Multi
+from networks.unet import Encoder, Decoder, Rec_Decoder, count_params
+from utils.metrics import postprocessing, dice_coeff_2label
+
+fundus_batch_list = [[3, 6, 7], [2, 7, 7], [2, 4, 10], [2, 4, 10]]              # train.py:35-38
+prostate_batch_list = [[2, 2, 2, 2, 2]] * 6                                       # train.py:40-45
+
+
+class Compose(object):
+    def __init__(self, ts):
+        self.ts = ts
+
+    def __call__(self, s):
+        for t in self.ts:
+            s = t(s)
+        return s
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='DG Medical Segmentation Train')
+    p.add_argument('--data_root', type=str, default='../dataset')
+    p.add_argument('--dataset', type=str, default='fundus', choices=['fundus', 'prostate'])
+    p.add_argument('--batch_size', type=int, default=8, help='parsed but unused, as in the reference (train.py:35-45)')
+    p.add_argument('--test_batch_size', type=int, default=8)
+    p.add_argument('--lr', type=float, default=None)
+    p.add_argument('--epochs', type=int, default=None)
+    p.add_argument('--domain_idxs', type=str, default='0,1,2')
+    p.add_argument('--test_domain_idx', type=int, default=3)
+    p.add_argument('--in_channels', type=int, default=3)
+    p.add_argument('--num_classes', type=int, default=None)
+    p.add_argument('--seed', type=int, default=1337)
+    p.add_argument('--lambda_rec', type=float, default=0.1)
+    p.add_argument('--deterministic', action='store_true')
+    p.add_argument('--ram', action='store_true')
+    p.add_argument('--rec', action='store_true')
+    p.add_argument('--is_out_domain', action='store_true')
+    p.add_argument('--consistency', action='store_true')
+    p.add_argument('--consistency_type', type=str, default='mse')
+    p.add_argument('--save_path', type=str, default=None, required=True)
+    p.add_argument('--norm', type=str, default='bn')
+    p.add_argument('--activation', type=str, default='relu')
+    p.add_argument('--gpu', type=str, default='0')
+    # additions
+    p.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f32'], help='activation storage type of the fused step')
+    p.add_argument('--log_every', type=int, default=20)
+    p.add_argument('--num_workers', type=int, default=8)
+    p.add_argument('--max_iters', type=int, default=None, help='stop early (smoke runs)')
+    return p.parse_args(argv)
+
+
+def seed_worker(worker_id):
+    worker_seed = torch.initial_seed() % 2 ** 32
+    np.random.seed(worker_seed)
+    random.seed(worker_seed)
+
+
+def test_fundus(encoder, seg_decoder, epoch, data_dir, datasetTest, output_path, batch_size=8, dataset='fundus'):
+    """train.py:91-132 (BN in eval mode here, as in the reference's in-training evaluation)."""
+    encoder.eval()
+    seg_decoder.eval()
+    testset = Fundus(base_dir=data_dir, split='test', domain_idx=datasetTest,
+                     transform=Compose([trans.Resize((256, 256)), trans.Normalize()]))
+    loader = DataLoader(testset, batch_size=batch_size, num_workers=2, shuffle=False, drop_last=False)
+    cup = disc = 0.0
+    n = 0
+    with torch.no_grad():
+        for data, target, target_orig, ids in loader:
+            pred = torch.sigmoid(seg_decoder(encoder(data.cuda())))
+            pred = torch.nn.functional.interpolate(pred, size=(target_orig.size(2), target_orig.size(3)), mode='bilinear')
+            for i in range(pred.shape[0]):
+                post = postprocessing(pred[i], dataset=dataset, threshold=0.75)
+                c, d = dice_coeff_2label(post, target_orig[i])
+                cup, disc, n = cup + c, disc + d, n + 1
+    cup, disc = cup / max(n, 1), disc / max(n, 1)
+    print('val_cup_dice : {}, val_disc_dice : {}'.format(cup, disc))
+    with open(osp.join(output_path, str(datasetTest) + '_val_log.csv'), 'a') as f:
+        f.write(','.join(map(str, [['batch-size: '] + [batch_size] + [epoch] + ['cup dice coefficence: '] + [cup] +
+                                   ['disc dice coefficence: '] + [disc]])) + '\n')
+    return (cup + disc) * 100.0 / 2
+
+
+def save_checkpoint(path, encoder, seg_decoder, rec_decoder):
+    """train.py:342-360: unwrapped state_dicts under the reference's three keys."""
+    torch.save({'encoder_state_dict': encoder.state_dict(), 'seg_decoder_state_dict': seg_decoder.state_dict(),
+                'rec_decoder_state_dict': rec_decoder.state_dict()}, path)
+
+
+def main(args):
+    if not (args.ram and args.rec):
+        # the reference only runs end-to-end with --ram --rec (train.py:591 / :315 raise otherwise)
+        raise ValueError('only the --ram --rec flag combination exists in the reference; got ram=%s rec=%s' % (args.ram, args.rec))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    data_root = os.path.join(args.data_root, args.dataset)
+    os.makedirs(args.save_path, exist_ok=True)
+
+    zoo = {'fundus': Fundus_Multi, 'prostate': Prostate_Multi}
+    transform = {'fundus': Compose([trans.Resize((256, 256)), trans.RandomScaleCrop((256, 256))]), 'prostate': None}
+    bsl = fundus_batch_list[args.test_domain_idx] if args.dataset == 'fundus' else prostate_batch_list[args.test_domain_idx]
+    domain_idx_list = [int(i) for i in args.domain_idxs.split(',')]
+    loaders, max_len, max_id = [], -1, 0
+    raw = []
+    for idx, i in enumerate(domain_idx_list):
+        ds = zoo[args.dataset](base_dir=data_root, split='train', domain_idx_list=[i], transform=transform[args.dataset],
+                               is_out_domain=args.is_out_domain, test_domain_idx=args.test_domain_idx)
+        dl = DataLoader(ds, batch_size=bsl[idx], num_workers=args.num_workers, shuffle=True, drop_last=True, pin_memory=True,
+                        worker_init_fn=seed_worker)
+        raw.append(dl)
+        loaders.append(cycle(dl))                       # train.py:560: replays the first pass of the shorter loaders
+        if max_len < len(dl):
+            max_len, max_id = len(dl), idx
+    loaders[max_id] = raw[max_id]
+
+    encoder = Encoder(c=args.in_channels, norm=args.norm, activation=args.activation).cuda()
+    seg_decoder = Decoder(num_classes=args.num_classes, norm=args.norm, activation=args.activation).cuda()
+    rec_decoder = Rec_Decoder(num_classes=args.in_channels, norm='dsbn', activation=args.activation,
+                              num_domains=len(domain_idx_list)).cuda()
+    print('\nEncoder Params: %.3fM' % count_params(encoder))
+    print('\nSeg Decoder Params: %.3fM' % count_params(seg_decoder))
+    print('\nRec Decoder Params: %.3fM' % count_params(rec_decoder))
+
+    from ramdsir.trainer import FusedTrainer
+    sample = next(iter(raw[0]))
+    H, W = sample[0].shape[1:3]
+    total_iters = max_len * args.epochs
+    cons = args.consistency_type if args.consistency else None
+    assert cons in (None, 'mse', 'kd'), args.consistency_type
+    trainer = FusedTrainer(encoder, seg_decoder, rec_decoder, bsl[:len(domain_idx_list)], H, W, dataset=args.dataset,
+                           consistency=cons, lambda_rec=args.lambda_rec, lr=args.lr, total_iters=total_iters,
+                           dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+
+    previous_best, iter_num = 0.0, 0
+    for epoch in range(args.epochs):
+        if rank == 0:
+            print('\n==> Epoch %i, learning rate = %.6f' % (epoch, args.lr if iter_num == 0 else trainer.lr()))
+        for m in (encoder, seg_decoder, rec_decoder):
+            m.train()
+        for i, batches in enumerate(zip(*loaders)):
+            src = torch.cat([b[0] for b in batches], 0).cuda(non_blocking=True)
+            trg = torch.cat([b[1] for b in batches], 0).cuda(non_blocking=True)
+            lam = torch.cat([b[2] for b in batches], 0).cuda(non_blocking=True)
+            mask = torch.cat([b[3] for b in batches], 0).cuda(non_blocking=True)
+            trainer.step(src, trg, lam, mask)
+            if rank == 0 and iter_num % args.log_every == 0:
+                l = trainer.losses()
+                print('iter %d lr %.6f ' % (iter_num, trainer.lr()) + ' '.join('%s %.4f' % (k, v) for k, v in l.items() if k != 'rec')
+                      + ' loss_rec %.4f' % (sum(l['rec']) / 4))               # train.py:304 logs avg/4
+            iter_num += 1
+            if args.max_iters and iter_num >= args.max_iters:
+                break
+        if args.dataset == 'fundus' and rank == 0 and os.path.exists(os.path.join(data_root, 'Domain%d_test.list' % (args.test_domain_idx + 1))):
+            print('Test on target domain {}'.format(args.test_domain_idx))
+            avg_dice = test_fundus(encoder, seg_decoder, epoch, data_root, args.test_domain_idx, args.save_path, args.test_batch_size)
+            if avg_dice >= previous_best:
+                if previous_best != 0:
+                    old = os.path.join(args.save_path, 'model_%.2f.pth' % previous_best)
+                    if os.path.exists(old):
+                        os.remove(old)
+                save_checkpoint(os.path.join(args.save_path, 'model_%.2f.pth' % avg_dice), encoder, seg_decoder, rec_decoder)
+                previous_best = avg_dice
+        if args.max_iters and iter_num >= args.max_iters:
+            break
+    if rank == 0:
+        save_checkpoint(os.path.join(args.save_path, 'final_model.pth'), encoder, seg_decoder, rec_decoder)
+        print('\nSave Final Model to {}'.format(args.save_path))
+    if world > 1:
+        dist.barrier()
+
+
+if __name__ == '__main__':
+    args = parse_args()
+    if 'LOCAL_RANK' not in os.environ:
+        os.environ['CUDA_VISIBLE_DEVICES'] = args.gpu                  # train.py:606
+    if args.deterministic:
+        random.seed(args.seed)
+        np.random.seed(args.seed)
+        torch.manual_seed(args.seed)
+    if args.epochs is None:
+        args.epochs = {'fundus': 400, 'prostate': 200}[args.dataset]
+    if args.lr is None:
+        args.lr = {'fundus': 2e-3, 'prostate': 1e-3}[args.dataset]
+    if args.num_classes is None:
+        args.num_classes = {'fundus': 2, 'prostate': 2}[args.dataset]
+    print(args)
+    main(args)

@@ -1,0 +1,67 @@
+"""-m gpu: the train.py CLI end to end on a tiny synthetic Fundus tree (PNG files + list files in the
+reference's two list locations): 6 iterations, in-training evaluation, checkpoint layout."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make_fundus(root, n_per_domain=8, size=64):
+    rng = np.random.RandomState(0)
+    base = os.path.join(root, 'fundus')
+    for d in range(1, 5):
+        for split in ('train', 'test'):
+            os.makedirs(os.path.join(base, 'Domain%d' % d, split, 'ROIs', 'image'), exist_ok=True)
+            os.makedirs(os.path.join(base, 'Domain%d' % d, split, 'ROIs', 'mask'), exist_ok=True)
+            lines, partner = [], []
+            for i in range(n_per_domain):
+                img = rng.randint(0, 255, (size, size, 3)).astype(np.uint8)
+                yy, xx = np.mgrid[0:size, 0:size]
+                r2 = (yy - size / 2) ** 2 + (xx - size / 2) ** 2
+                m = np.full((size, size), 255, np.uint8)
+                m[r2 < (size * 0.35) ** 2] = 128
+                m[r2 < (size * 0.15) ** 2] = 0
+                rel_i = 'Domain%d/%s/ROIs/image/%d.png' % (d, split, i)
+                rel_m = 'Domain%d/%s/ROIs/mask/%d.png' % (d, split, i)
+                Image.fromarray(img).save(os.path.join(base, rel_i))
+                Image.fromarray(m).save(os.path.join(base, rel_m))
+                lines.append('%s %s' % (rel_i, rel_m))
+                partner.append('%s/ROIs/image/%d.png %s/ROIs/mask/%d.png' % (split, i, split, i))
+            with open(os.path.join(base, 'Domain%d_%s.list' % (d, split)), 'w') as f:
+                f.write('\n'.join(lines) + '\n')
+            if split == 'train':
+                with open(os.path.join(base, 'Domain%d' % d, 'train.list'), 'w') as f:
+                    f.write('\n'.join(partner) + '\n')
+    return root
+
+
+def test_train_cli_smoke(tmp_path):
+    data = _make_fundus(str(tmp_path / 'data'))
+    out = str(tmp_path / 'out')
+    cmd = [sys.executable, os.path.join(ROOT, 'ram-dsir_amd', 'train.py'), '--data_root', data, '--dataset', 'fundus',
+           '--domain_idxs', '1,2,3', '--test_domain_idx', '0', '--ram', '--rec', '--is_out_domain', '--consistency',
+           '--consistency_type', 'kd', '--save_path', out, '--epochs', '3', '--max_iters', '6', '--num_workers', '2',
+           '--log_every', '2', '--dtype', 'f32']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    log = r.stdout.decode()
+    assert r.returncode == 0, log[-3000:]
+    assert 'Encoder Params: 1.968M' in log and 'val_cup_dice' in log
+    ck = torch.load(os.path.join(out, 'final_model.pth'), map_location='cpu')
+    assert sorted(ck) == ['encoder_state_dict', 'rec_decoder_state_dict', 'seg_decoder_state_dict']
+    assert len(ck['encoder_state_dict']) == 105 and len(ck['seg_decoder_state_dict']) == 79 and len(ck['rec_decoder_state_dict']) == 206
+    assert int(ck['encoder_state_dict']['convd1.bn1.num_batches_tracked']) == 12          # 6 iterations x 2 passes
+    assert all(torch.isfinite(v.float()).all() for v in ck['encoder_state_dict'].values())
+    assert os.path.exists(os.path.join(out, '0_val_log.csv'))
+
+
+def test_train_cli_rejects_flag_sets_the_reference_cannot_run(tmp_path):
+    cmd = [sys.executable, os.path.join(ROOT, 'ram-dsir_amd', 'train.py'), '--save_path', str(tmp_path), '--epochs', '1', '--ram']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode != 0 and b'--ram --rec' in r.stdout
