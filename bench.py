@@ -26,7 +26,7 @@ for p in (ROOT, os.path.join(ROOT, 'ram-dsir_amd')):
 import numpy as np
 import torch
 
-DOMINANT = 'conv_kernel<bf16,9,1>'       # largest share of step time in profiles/ (the 16/32-channel 3x3 layers)
+DOMINANT = 'conv_small_kernel<bf16,9,*>'   # largest share of step time in profiles/ (3x3 layers with <=32 channels)
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 

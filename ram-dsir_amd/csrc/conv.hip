@@ -1525,26 +1525,26 @@ __global__ __launch_bounds__(256, 3) void wgrad_c16_kernel(const rd_wgrad_t p, i
     }
 }
 
-// block = 64 outputs x 4 split lanes: each thread sums every 4th split, LDS folds the 4 lanes (fixed order)
+// block = 32 outputs x 8 split lanes: each thread sums every 8th split, LDS folds the 8 lanes in a fixed order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dW, int nsplit, int taps, int Cout,
                                                            int Cin, int CoutPadW, int CinPadW, float beta) {
-    __shared__ float s[4][64];
+    __shared__ float s[8][32];
     const int total = taps * Cout * Cin;
-    const int o = threadIdx.x & 63, ql = threadIdx.x >> 6;
+    const int o = threadIdx.x & 31, ql = threadIdx.x >> 5;
     const size_t stride = (size_t)taps * CoutPadW * CinPadW;
-    for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+    for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
         const int i = base + o;
         float acc = 0.f;
         int c = 0, n = 0, tap = 0;
         if (i < total) {
             c = i % Cin; n = (i / Cin) % Cout; tap = i / (Cin * Cout);
             const float* src = partial + ((size_t)tap * CoutPadW + n) * CinPadW + c;
-            for (int k = ql; k < nsplit; k += 4) acc += src[k * stride];
+            for (int k = ql; k < nsplit; k += 8) acc += src[k * stride];
         }
         s[ql][o] = acc;
         __syncthreads();
         if (ql == 0 && i < total) {
-            const float v = (s[0][o] + s[1][o]) + (s[2][o] + s[3][o]);
+            const float v = ((s[0][o] + s[1][o]) + (s[2][o] + s[3][o])) + ((s[4][o] + s[5][o]) + (s[6][o] + s[7][o]));
             float* d = dW + ((size_t)n * Cin + c) * taps + tap;
             *d = (beta != 0.f ? beta * *d : 0.f) + v;
         }
@@ -1585,7 +1585,9 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     g.CinPadW = cin32 * 32;
     g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const int pairs = (g.CoutPadW / (g.MB * 32)) * (g.CinPadW / (g.NB * 32));
-    int gx = (512 + pairs - 1) / pairs;                     // ~2 workgroups per CU in flight
+    // these kernels hold 144 accumulator registers per lane -> one workgroup per CU is resident: launching more
+    // workgroups than CUs only multiplies the partial-sum traffic (147 KB per workgroup for a 64x64 tile)
+    int gx = (256 + pairs - 1) / pairs;
     if (gx > g.total_tiles) gx = g.total_tiles;
     if (gx < 1) gx = 1;
     g.gx = gx;
@@ -1674,8 +1676,8 @@ int dispatch_wgrad(const rd_wgrad_t& p, hipStream_t st) {
     }
     if (e) return e;
     const int total = p.taps * p.Cout * p.Cin;
-    int blocks = (total + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
+    int blocks = (total + 31) / 32;
+    if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
                        g.CoutPadW, g.CinPadW, p.beta);
     return (int)hipGetLastError();

@@ -415,7 +415,12 @@ class Plan:
         esz = 2 if self.dtype == torch.bfloat16 else 4
         nb = 2 if ((Cout + 31) // 32 * 32) % 64 == 0 else 1
         tname = 'bf16' if self.dtype == torch.bfloat16 else 'f32'
-        return dict(kernel='conv_kernel<%s,%d,%d>' % (tname, node.taps, nb), what=what, layer='%s.%s' % (node.mname, node.name),
+        ck = 32 if self.dtype == torch.bfloat16 else 16
+        if Cin <= ck and Cout <= 32:
+            kname = 'conv_small_kernel<%s,%d,*>' % (tname, node.taps)       # all SRCG/EPI instantiations of the template
+        else:
+            kname = 'conv_kernel<%s,%d,%d>' % (tname, node.taps, nb)
+        return dict(kernel=kname, what=what, layer='%s.%s' % (node.mname, node.name),
                     bytes=N * H * W * (Cin + Cout) * esz, flops=2 * N * H * W * Cin * Cout * node.taps)
 
     def bind_workspace(self, ws):
