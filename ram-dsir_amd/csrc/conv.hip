@@ -382,7 +382,7 @@ __device__ __forceinline__ void store_vec(T* p, const float* v, int cvalid, bool
 
 // S channels (one slot) of the gradient w.r.t. a conv input pixel -> gradient w.r.t. the producer's BN
 // output: activation mask, max-pool scatter or upsample-side mask; b1 += g, b2 += g*z per channel.
-template <typename T>
+template <typename T, int KMASK = 7>
 __device__ __forceinline__ void grad_item(const rd_dst_t& d, int g_img, int n, int y, int x, int H, int W, int cd,
                                           const float* da, const float* sc, const float* sh, float* b1, float* b2) {
     constexpr int S = Slot<T>::N;
@@ -392,7 +392,7 @@ __device__ __forceinline__ void grad_item(const rd_dst_t& d, int g_img, int n, i
     const int cvalid = Cd - cd;
     const bool vec_ok = (Cd % S) == 0;
     n += d.n_off;
-    if (d.kind == RD_DST_PLAIN) {
+    if ((KMASK & 1) && d.kind == RD_DST_PLAIN) {
         const size_t idx = ((size_t)(n * H + y) * W + x) * Cd + cd;
         float z[S], gw[S];
 #pragma unroll
@@ -408,7 +408,7 @@ __device__ __forceinline__ void grad_item(const rd_dst_t& d, int g_img, int n, i
             gw[e] = d.accumulate ? gw[e] + gn : gn;
         }
         store_vec<T>(gp + idx, gw, cvalid, vec_ok);
-    } else if (d.kind == RD_DST_POOL) {
+    } else if ((KMASK & 2) && d.kind == RD_DST_POOL) {
         const int Hd = 2 * H, Wd = 2 * W;
         float zz[4][S], best[S];
         int arg[S];
@@ -439,7 +439,7 @@ __device__ __forceinline__ void grad_item(const rd_dst_t& d, int g_img, int n, i
             }
             store_vec<T>(gp + idx, gw, cvalid, vec_ok);
         }
-    } else if (d.kind == RD_DST_UPY) {
+    } else if ((KMASK & 4) && d.kind == RD_DST_UPY) {
         const int Hs = H >> 1, Ws = W >> 1;
         int yy0, yy1, xx0, xx1;
         float ly, lx;
@@ -489,6 +489,27 @@ __device__ __forceinline__ void grad_plain(const rd_dst_t& d, int n, int y, int 
         gw[e] += gn;
     }
     *reinterpret_cast<uint4*>(gp + idx) = Slot<T>::pack(gw);
+}
+
+// sum b1/b2 over the lanes of a wave that own the same channel slot (lane % SL), then one LDS atomic per
+// wave and channel instead of one per thread (64-way same-address contention otherwise)
+template <int S, int SL>
+__device__ __forceinline__ void flush_bstats(float* s_red, int lane, int sl, float* b1, float* b2) {
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+#pragma unroll
+        for (int o = SL; o < 64; o <<= 1) {
+            b1[e] += __shfl_xor(b1[e], o, 64);
+            b2[e] += __shfl_xor(b2[e], o, 64);
+        }
+    }
+    if (lane < SL) {
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            atomicAdd(&s_red[(sl * S + e) * 2 + 0], b1[e]);
+            atomicAdd(&s_red[(sl * S + e) * 2 + 1], b2[e]);
+        }
+    }
 }
 
 // picks dst[0] or dst[1] field by field (lane-varying di): keeps the kernarg struct out of scratch
@@ -671,14 +692,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
                 else if (d.kind != RD_DST_NONE)
                     grad_item<T>(d, g, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
             }
-            if (p.emode == 1 && d.kind != RD_DST_NONE && d.bstats) {
-#pragma unroll
-                for (int e = 0; e < S; ++e) {
-                    atomicAdd(&s_red[(sl * S + e) * 2 + 0], b1[e]);
-                    atomicAdd(&s_red[(sl * S + e) * 2 + 1], b2[e]);
-                }
-            }
         }
+        // (wave-uniform condition: emode is a launch constant; lanes without a live destination add zeros)
+        if (p.emode == 1) flush_bstats<S, SL>(s_red, lane, sl, b1, b2);
         __syncthreads();
         if (tid < 32 && cb + tid < p.Cout) {
             if (p.emode == 0) {
@@ -771,7 +787,8 @@ __device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_
 }
 
 // SRCG: sources may need the generic (synchronous) loader: max-pool / upsample / odd channel counts.
-// EPI : 0 forward, 1 gradient with plain destinations only, 2 gradient with pool / upsample destinations.
+// EPI : 0 forward, 1 gradient with plain full-slot destinations only (lean path), 3 plain + upsample-side,
+//       4 plain + max-pool, 2 anything.
 template <typename T, int TAPS, bool SRCG, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, int tiles_per_wg) {
     constexpr int S = Slot<T>::N;
@@ -925,7 +942,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
                 } else if constexpr (EPI == 1) {
                     if (d.kind != RD_DST_NONE) grad_plain<T>(d, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
                 } else {
-                    if (d.kind != RD_DST_NONE) grad_item<T>(d, g, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
+                    constexpr int KM = EPI == 3 ? 5 : (EPI == 4 ? 3 : 7);
+                    if (d.kind != RD_DST_NONE) grad_item<T, KM>(d, g, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
                 }
             }
         }
@@ -942,12 +960,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
                 atomicAdd(&s_red[li * 2 + 1], s2);
             }
         }
-    } else if (c < p.Cout && d.kind != RD_DST_NONE && d.bstats) {
-#pragma unroll
-        for (int e = 0; e < S; ++e) {
-            atomicAdd(&s_red[(sl * S + e) * 2 + 0], b1[e]);
-            atomicAdd(&s_red[(sl * S + e) * 2 + 1], b2[e]);
-        }
+    } else {
+        flush_bstats<S, SL>(s_red, lane, sl, b1, b2);
     }
     __syncthreads();
     if (tid < 32 && tid < p.Cout) {
@@ -1003,16 +1017,29 @@ int dispatch_conv_small(const rd_conv_t& p, hipStream_t st) {
     int epi = 0;
     if (p.emode == 1) {
         epi = 1;
+        bool pool = false, upy = false, narrow = false;
         for (int i = 0; i < 2; ++i) {
             const rd_dst_t& d = p.dst[i];
             if (d.kind == RD_DST_NONE) continue;
-            if (d.kind != RD_DST_PLAIN || (d.Cd % S)) epi = 2;
+            pool |= d.kind == RD_DST_POOL;
+            upy |= d.kind == RD_DST_UPY;
+            narrow |= (d.Cd % S) != 0;
         }
+        if (pool && upy) epi = 2;
+        else if (upy) epi = 3;
+        else if (pool) epi = 4;
+        else if (narrow) epi = 2;
     } else if (p.Cout % S) {
         epi = 0;                                           // store_vec handles narrow outputs
     }
 #define RD_CS(SG, EP) return launch_conv_small<T, TAPS, SG, EP>(p, st)
-    if (!srcg) { if (epi == 0) RD_CS(false, 0); if (epi == 1) RD_CS(false, 1); RD_CS(false, 2); }
+    if (!srcg) {
+        if (epi == 0) RD_CS(false, 0);
+        if (epi == 1) RD_CS(false, 1);
+        if (epi == 3) RD_CS(false, 3);
+        if (epi == 4) RD_CS(false, 4);
+        RD_CS(false, 2);
+    }
     if (epi == 0) RD_CS(true, 0);
     if (epi == 1) RD_CS(true, 1);
     RD_CS(true, 2);
