@@ -160,7 +160,12 @@ def main():
     ts.load_raw(src, trg, lam)
     ts.load_target(mask)
     torch.cuda.synchronize()
-    if world > 1:
+    force_ddp = os.environ.get('RD_FORCE_DDP') == '1'          # exercise the 3-graph + bucket path on one GPU
+    if force_ddp and world == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    if world > 1 or force_ddp:
         runner = D.DataParallelStep(ts)
         if not args.no_graph:
             runner.capture()

@@ -304,7 +304,40 @@ __device__ __forceinline__ void tile_fill(const rd_src_t* src, const SlotCtx<T>&
     }
     const rd_src_t s = select_src(src, k.si);
     const bool fast = (s.C % S) == 0 && (s.C - k.c) >= S;
-    if (!fast) {                                           // odd channel counts (3-channel image, 2/3-class dlogits)
+    if (!fast && s.mode == RD_SRC_RAW && s.C <= 4 && k.c == 0) {
+        // narrow raw tensors (3-channel image, 2/3-class dlogits): element loads, still loads-first
+        const T* base = reinterpret_cast<const T*>(s.ptr);
+        const int C = s.C, nn = n + s.n_off;
+        constexpr int NB_ = 6;
+        for (int idx0 = tid; idx0 < total; idx0 += STRIDE * NB_) {
+            T e[NB_][4];
+#pragma unroll
+            for (int b = 0; b < NB_; ++b) {
+                const int idx = idx0 + b * STRIDE;
+                int y = 0, x = 0;
+                const bool in = idx < total && map(idx, y, x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[b][j] = from_f<T>(0.f);
+                if (in) {
+                    const T* pp = base + ((size_t)(nn * H + y) * W + x) * C;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < C) e[b][j] = pp[j];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB_; ++b) {
+                const int idx = idx0 + b * STRIDE;
+                if (idx >= total) continue;
+                float v[S];
+#pragma unroll
+                for (int j = 0; j < S; ++j) v[j] = j < 4 ? to_f<T>(e[b][j]) : 0.f;
+                store(idx, Slot<T>::pack(v));
+            }
+        }
+        return;
+    }
+    if (!fast) {                                           // other odd channel counts: generic per-item path
         for (int idx = tid; idx < total; idx += STRIDE) {
             int y = 0, x = 0;
             float v[S];

@@ -27,7 +27,7 @@ class GradBuckets:
         self._avg = dist.ReduceOp.AVG if (dist.is_initialized() and dist.get_backend(group) == 'nccl') else dist.ReduceOp.SUM
 
     def _reduce(self, t, async_op):
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             return None
         w = dist.all_reduce(t, op=self._avg, group=self.group, async_op=async_op)
         if self._avg == dist.ReduceOp.SUM:

@@ -8,6 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from ramdsir import step as S, engine as E, _lib as L      # noqa: E402
+S_ = S
 from oracle import step as OS, unet as OU                   # noqa: E402
 from golden_util import (assert_sig_close, load_step, step_states, bn_shadowed_bias, sig)   # noqa: E402
 
@@ -193,3 +194,47 @@ def test_step_bf16_loss_band_and_graph_replay(golden_dir):
     assert int(ts2.iter) == 1
     rel = float((bank2.params - bank.params).abs().max())
     assert rel < 5e-3            # Adam moves every weight by ~lr; eager and replay agree up to atomics order
+
+
+@pytest.mark.parametrize('dataset,bs,S', [('fundus', [2, 3, 3], 400), ('prostate', [2, 2, 2, 2, 2], 384), ('fundus', [2, 2, 2, 2], 512)])
+def test_step_at_baseline_config_shapes(dataset, bs, S):
+    """BASELINE.json configs 1/3/5 at full size (bf16, hipGraph, RAM on the GPU): size-independent properties --
+    finite losses, RAM output in range and identity for lambda=1, loss decreasing on a fixed batch, running
+    statistics tracked twice per step for the shared BNs and once per step for each domain's DSBN."""
+    torch.manual_seed(0)
+    B = sum(bs)
+    K = 2
+    bank, mods = S_.make_bank(DEV, 3, 16, K, len(bs))
+    g = torch.Generator().manual_seed(1)
+    for (m, k), (off, shape) in bank.index.items():
+        v = bank.p(m, k)
+        if len(shape) == 4:
+            v.copy_((torch.randn(shape, generator=g) * (2.0 / (shape[0] * shape[2] * shape[3])) ** 0.5).to(DEV))
+        elif '.bn' in k and k.endswith('weight'):
+            v.fill_(1.0)
+    ts = S_.TrainStep(bank, mods, torch.bfloat16, bs, S, S, dataset=dataset, consistency='kd', lr=1e-3, total_iters=100, ram=True)
+    ts.wpack.refresh()
+    if dataset == 'fundus':
+        src = torch.rand(B, S, S, 3, device=DEV) * 255
+        trg = torch.rand(B, S, S, 3, device=DEV) * 255
+        tgt = (torch.rand(B, 2, S, S, device=DEV) > 0.5).float()
+    else:
+        src = torch.rand(B, S, S, 3, device=DEV) * 2 - 1
+        trg = torch.rand(B, S, S, 3, device=DEV) * 2 - 1
+        tgt = (torch.rand(B, S, S, device=DEV) > 0.7).long()
+    lam = torch.tensor([1.0] + [0.1 * (1 + i % 9) for i in range(B - 1)], device=DEV)
+    ts.load_raw(src, trg, lam)
+    ts.load_target(tgt)
+    ts.capture()
+    hist = []
+    for _ in range(6):
+        ts.step()
+        hist.append(ts.loss_dict()['loss'])
+    assert all(np.isfinite(hist)), hist
+    assert hist[-1] < hist[0], hist
+    x = ts.x.buf.float()
+    assert float(x.min()) >= -1.0 and float(x.max()) <= 1.0
+    assert torch.equal(x[0], x[B])                                  # lambda = 1: img_freq == img
+    assert int(bank.b('enc', 'convd1.bn1.num_batches_tracked')) == 12
+    assert int(bank.b('rec', 'convu1.bn3.bns.%d.num_batches_tracked' % (len(bs) - 1))) == 6
+    assert int(ts.iter) == 6
