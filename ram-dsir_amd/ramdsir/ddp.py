@@ -71,7 +71,7 @@ class DataParallelStep:
                 with torch.cuda.graph(g, stream=st):
                     if i == 0:
                         ts.zero()
-                    E.Plan.run(seg, st.cuda_stream)
+                    ts.run_segment(seg, st)
                 self.graphs.append(g)
         torch.cuda.synchronize()
         ts._restore(saved)
@@ -84,14 +84,14 @@ class DataParallelStep:
             self.graphs[0].replay()
         else:
             ts.zero()
-            E.Plan.run(ts.seg_a, main.cuda_stream)
+            ts.run_segment(ts.seg_a, main)
         self.comm.wait_stream(main)
         with torch.cuda.stream(self.comm):
             w0 = self.buckets.reduce_decoder_side(async_op=True)
         if self.graphs is not None:
             self.graphs[1].replay()
         else:
-            E.Plan.run(ts.seg_b, main.cuda_stream)
+            ts.run_segment(ts.seg_b, main)
         w1 = self.buckets.reduce_encoder(async_op=True)
         for w in (w0, w1):
             if w is not None:
@@ -100,4 +100,4 @@ class DataParallelStep:
         if self.graphs is not None:
             self.graphs[2].replay()
         else:
-            E.Plan.run(ts.seg_c, main.cuda_stream)
+            ts.run_segment(ts.seg_c, main)

@@ -363,11 +363,11 @@ class Plan:
             ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
             self.keep.append(wg)
             node.wg = wg
-            self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt), dict(kernel='wgrad', layer='%s.%s' % (node.mname, node.name))))
+            self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt), dict(kernel='wgrad', side=True, layer='%s.%s' % (node.mname, node.name))))
             if node.has_bias_grad:
                 node.bias_ws = self.alloc_f32(8192)
                 self.bwd.append((lib.rd_colsum, (o.grad_buf().data_ptr(), self.bank.g(node.mname, node.name + '.bias').data_ptr(),
-                                                 node.bias_ws.data_ptr(), N * H * W, o.C, 0.0, dt)))
+                                                 node.bias_ws.data_ptr(), N * H * W, o.C, 0.0, dt), dict(kernel='colsum', side=True)))
             # dgrad (skipped when no input needs a gradient, i.e. the first conv on the image)
             dsts = []
             for (a, mode, n_off, g_fixed) in node.inputs:
@@ -436,6 +436,28 @@ class Plan:
             err = fn(*args, stream)
             if err:
                 raise RuntimeError('ramdsir HIP launch failed: %s -> %d' % (fn.__name__, err))
+
+    @staticmethod
+    def run_forked(ops, main, side):
+        """Launch `ops` on the torch stream `main`, except those tagged side=True (weight gradients: nothing in
+        the backward chain depends on them), which go to `side` behind an event recorded at their position in
+        the main stream.  The caller joins `side` before anything reads the parameter gradients.  Works eagerly
+        and under hipGraph capture (fork/join through events)."""
+        used = False
+        for op in ops:
+            fn, args = op[0], op[1]
+            meta = op[2] if len(op) > 2 else None
+            if meta is not None and meta.get('side'):
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                err = fn(*args, side.cuda_stream)
+                used = True
+            else:
+                err = fn(*args, main.cuda_stream)
+            if err:
+                raise RuntimeError('ramdsir HIP launch failed: %s -> %d' % (fn.__name__, err))
+        return used
 
 
 class WeightPack:

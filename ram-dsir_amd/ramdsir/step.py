@@ -86,6 +86,8 @@ class TrainStep:
             self.ram = R.RamMixer(B, H, W, dtype, dev, dataset)
             self.ram.bind(self.src, self.trg, self.lam, self.x.buf[:B], self.x.buf[B:])
         self.graph = None
+        self.side = torch.cuda.Stream(device=dev)          # weight-gradient kernels run beside the dgrad chain
+        self.fork = True
         self._ops = self._build_ops()
 
     def _build_ops(self):
@@ -140,9 +142,20 @@ class TrainStep:
         self.rec.stat_arena.zero_()
         self.bank.grads.zero_()
 
+    def run_segment(self, ops, main=None):
+        """One segment with the weight-gradient fork; the side stream is joined before returning."""
+        main = torch.cuda.current_stream() if main is None else main
+        if not self.fork:
+            E.Plan.run(ops, main.cuda_stream)
+            return
+        if E.Plan.run_forked(ops, main, self.side):
+            main.wait_stream(self.side)
+
     def run_eager(self):
         self.zero()
-        E.Plan.run(self._ops, self._stream())
+        self.run_segment(self.seg_a)
+        self.run_segment(self.seg_b)
+        self.run_segment(self.seg_c)
 
     def capture(self):
         """Capture one step (zeroing + every launch) into a hipGraph on a side stream."""
