@@ -193,40 +193,41 @@ __device__ __forceinline__ void tile_fill_mode(const rd_src_t& s, const SlotCtx<
     const T* base2 = reinterpret_cast<const T*>(s.ptr2) + k.c;
     const int nn = n + s.n_off;
     for (int idx0 = tid; idx0 < total; idx0 += STRIDE * BATCH) {
+        // Phase A is branch-free on purpose: a load inside `if (inside image)` makes the compiler wait for it at
+        // the join, i.e. one exposed memory latency per item.  Out-of-range items load a clamped (valid) address
+        // and are zeroed in phase B.
         uint4 raw[BATCH][NQ];
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
-            const int idx = idx0 + b * STRIDE;
+            const int idx = min(idx0 + b * STRIDE, total - 1);
             int y = 0, x = 0;
-            const bool in = idx < total && map(idx, y, x);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) raw[b][q] = make_uint4(0, 0, 0, 0);
-            if (in) {
-                if constexpr (MODE == RD_SRC_RAW || MODE == RD_SRC_AFF || MODE == RD_SRC_AFFACT) {
-                    raw[b][0] = ld16(base + ((size_t)(nn * H + y) * W + x) * C);
-                } else if constexpr (MODE == RD_SRC_BNBWD) {
-                    const size_t off = ((size_t)(nn * H + y) * W + x) * C;
-                    raw[b][0] = ld16(base + off);
-                    raw[b][1] = ld16(base2 + off);
-                } else if constexpr (MODE == RD_SRC_POOL) {
-                    const int Ws = 2 * W;
-                    const T* p00 = base + ((size_t)(nn * 2 * H + 2 * y) * Ws + 2 * x) * C;
-                    raw[b][0] = ld16(p00);
-                    raw[b][1] = ld16(p00 + C);
-                    raw[b][2] = ld16(p00 + (size_t)Ws * C);
-                    raw[b][3] = ld16(p00 + (size_t)Ws * C + C);
-                } else {  // UP
-                    const int Hs = H >> 1, Ws = W >> 1;
-                    int y0, y1, x0, x1;
-                    float ly, lx;
-                    up2_coord(y, Hs, y0, y1, ly);
-                    up2_coord(x, Ws, x0, x1, lx);
-                    const T* pn = base + (size_t)nn * Hs * Ws * C;
-                    raw[b][0] = ld16(pn + ((size_t)y0 * Ws + x0) * C);
-                    raw[b][1] = ld16(pn + ((size_t)y0 * Ws + x1) * C);
-                    raw[b][2] = ld16(pn + ((size_t)y1 * Ws + x0) * C);
-                    raw[b][3] = ld16(pn + ((size_t)y1 * Ws + x1) * C);
-                }
+            map(idx, y, x);
+            y = min(max(y, 0), H - 1);
+            x = min(max(x, 0), W - 1);
+            if constexpr (MODE == RD_SRC_RAW || MODE == RD_SRC_AFF || MODE == RD_SRC_AFFACT) {
+                raw[b][0] = ld16(base + ((size_t)(nn * H + y) * W + x) * C);
+            } else if constexpr (MODE == RD_SRC_BNBWD) {
+                const size_t off = ((size_t)(nn * H + y) * W + x) * C;
+                raw[b][0] = ld16(base + off);
+                raw[b][1] = ld16(base2 + off);
+            } else if constexpr (MODE == RD_SRC_POOL) {
+                const int Ws = 2 * W;
+                const T* p00 = base + ((size_t)(nn * 2 * H + 2 * y) * Ws + 2 * x) * C;
+                raw[b][0] = ld16(p00);
+                raw[b][1] = ld16(p00 + C);
+                raw[b][2] = ld16(p00 + (size_t)Ws * C);
+                raw[b][3] = ld16(p00 + (size_t)Ws * C + C);
+            } else {  // UP
+                const int Hs = H >> 1, Ws = W >> 1;
+                int y0, y1, x0, x1;
+                float ly, lx;
+                up2_coord(y, Hs, y0, y1, ly);
+                up2_coord(x, Ws, x0, x1, lx);
+                const T* pn = base + (size_t)nn * Hs * Ws * C;
+                raw[b][0] = ld16(pn + ((size_t)y0 * Ws + x0) * C);
+                raw[b][1] = ld16(pn + ((size_t)y0 * Ws + x1) * C);
+                raw[b][2] = ld16(pn + ((size_t)y1 * Ws + x0) * C);
+                raw[b][3] = ld16(pn + ((size_t)y1 * Ws + x1) * C);
             }
         }
 #pragma unroll
@@ -623,8 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
                 const int idx = tid + b * 256;
                 const int s = idx & 3, rec = idx >> 2;
                 const int nn = rec % NT, tap = rec / NT;
-                wr[b] = make_uint4(0, 0, 0, 0);
-                if (idx < WTOT) wr[b] = ld16(wbase + ((size_t)(tap * p.CoutPad + n0 + nn) * p.CinPad + c0 + s * S));
+                wr[b] = ld16(wbase + ((size_t)(min(tap, TAPS - 1) * p.CoutPad + n0 + nn) * p.CinPad + c0 + s * S));
             }
 #pragma unroll
             for (int b = 0; b < WIT; ++b) {
@@ -762,26 +762,24 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
 template <typename T, int NIT>
 __device__ __forceinline__ void pf_issue(uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, int n, int H, int W, int tid,
                                          int total, int yh, int xh, int PW) {
+    // branch-free (clamped addresses): conditional loads would be waited for one by one (see tile_fill_mode)
     const int C = s.C;
     const T* base = reinterpret_cast<const T*>(s.ptr) + k.c;
     const T* base2 = reinterpret_cast<const T*>(s.ptr2) + k.c;
     const int nn = n + s.n_off;
-    const bool two = s.mode == RD_SRC_BNBWD;
+    size_t off[NIT];
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
-        const int idx = tid + b * 256;
-        raw[b][0] = make_uint4(0, 0, 0, 0);
-        raw[b][1] = make_uint4(0, 0, 0, 0);
-        if (idx < total) {
-            const int pix = idx >> 2;
-            const int py = pix / PW, px = pix - py * PW;
-            const int y = yh + py, x = xh + px;
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-                const size_t off = ((size_t)(nn * H + y) * W + x) * C;
-                raw[b][0] = ld16(base + off);
-                if (two) raw[b][1] = ld16(base2 + off);
-            }
-        }
+        const int idx = min(tid + b * 256, total - 1);
+        const int pix = idx >> 2;
+        const int py = pix / PW, px = pix - py * PW;
+        const int y = min(max(yh + py, 0), H - 1), x = min(max(xh + px, 0), W - 1);
+        off[b] = ((size_t)(nn * H + y) * W + x) * C;
+        raw[b][0] = ld16(base + off[b]);
+    }
+    if (s.mode == RD_SRC_BNBWD) {
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) raw[b][1] = ld16(base2 + off[b]);
     }
 }
 
@@ -797,7 +795,7 @@ __device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_
         const int py = pix / PW, px = pix - py * PW;
         const int y = yh + py, x = xh + px;
         const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        uint4 u = raw[b][0];
+        uint4 u = in ? raw[b][0] : make_uint4(0, 0, 0, 0);
         if (s.mode != RD_SRC_RAW) {
             float v[S];
             Slot<T>::unpack(raw[b][0], v);
@@ -856,8 +854,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
             const int idx = tid + b * 256;
             const int sw = idx & 3, rec = idx >> 2;
             const int nn = rec % NT, tap = rec / NT;
-            wr[b] = make_uint4(0, 0, 0, 0);
-            if (idx < WTOT) wr[b] = ld16(wbase + ((size_t)(tap * p.CoutPad + nn) * p.CinPad + sw * S));
+            wr[b] = ld16(wbase + ((size_t)(min(tap, TAPS - 1) * p.CoutPad + nn) * p.CinPad + sw * S));
         }
 #pragma unroll
         for (int b = 0; b < WIT; ++b) {
@@ -904,13 +901,20 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
     T* out = reinterpret_cast<T*>(p.out);
 
     uint4 raw[NIT][2];
-    if (pre && t_begin < t_end)
-        pf_issue<T, NIT>(raw, ssrc, ctx, n, live_slot ? H : 0, W, tid, TOTAL, (t_begin / tiles_x) * TH - HALO, (t_begin % tiles_x) * TW - HALO, PW);
+    if (pre && live_slot && t_begin < t_end)
+        pf_issue<T, NIT>(raw, ssrc, ctx, n, H, W, tid, TOTAL, (t_begin / tiles_x) * TH - HALO, (t_begin % tiles_x) * TW - HALO, PW);
 
     for (int t = t_begin; t < t_end; ++t) {
         const int x0 = (t % tiles_x) * TW, y0 = (t / tiles_x) * TH;
         if (pre) {
-            pf_consume<T, NIT>(raw, ssrc, ctx, live_slot ? H : 0, W, tid, TOTAL, y0 - HALO, x0 - HALO, PW, s_in, sslot);
+            if (live_slot) {
+                pf_consume<T, NIT>(raw, ssrc, ctx, H, W, tid, TOTAL, y0 - HALO, x0 - HALO, PW, s_in, sslot);
+            } else {
+                for (int idx = tid; idx < TOTAL; idx += 256) {
+                    const int pix = idx >> 2;
+                    s_in[pix * 4 + (sslot ^ ((pix >> 2) & 3))] = make_uint4(0, 0, 0, 0);
+                }
+            }
         } else if constexpr (SRCG) {
             auto map = [&](int idx, int& y, int& x) -> bool {
                 const int pix = idx >> 2;
@@ -926,8 +930,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
             tile_fill<T>(p.src, ctx, n, H, W, tid, TOTAL, map, store);
         }
         __syncthreads();
-        if (pre && t + 1 < t_end)
-            pf_issue<T, NIT>(raw, ssrc, ctx, n, live_slot ? H : 0, W, tid, TOTAL, ((t + 1) / tiles_x) * TH - HALO, ((t + 1) % tiles_x) * TW - HALO, PW);
+        if (pre && live_slot && t + 1 < t_end)
+            pf_issue<T, NIT>(raw, ssrc, ctx, n, H, W, tid, TOTAL, ((t + 1) / tiles_x) * TH - HALO, ((t + 1) % tiles_x) * TW - HALO, PW);
 
         f32x16 acc[2];
 #pragma unroll
