@@ -183,7 +183,7 @@ __device__ __forceinline__ rd_src_t select_src(const rd_src_t* src, int si) {
 
 __device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <typename T, int MODE, int BATCH, int STRIDE, typename MapFn, typename StoreFn>
+template <typename T, int MODE, int BATCH, int STRIDE, bool BF, typename MapFn, typename StoreFn>
 __device__ __forceinline__ void tile_fill_mode(const rd_src_t& s, const SlotCtx<T>& k, int n, int H, int W, int tid, int total,
                                                MapFn map, StoreFn store) {
     constexpr int S = Slot<T>::N;
@@ -201,9 +201,16 @@ __device__ __forceinline__ void tile_fill_mode(const rd_src_t& s, const SlotCtx<
         for (int b = 0; b < BATCH; ++b) {
             const int idx = min(idx0 + b * STRIDE, total - 1);
             int y = 0, x = 0;
-            map(idx, y, x);
+            const bool in0 = map(idx, y, x);
             y = min(max(y, 0), H - 1);
             x = min(max(x, 0), W - 1);
+            if constexpr (!BF) {
+                // small images (25x25, 50x50 under 8x32 tiles): a large share of the items is outside the image;
+                // there the skipped loads are worth more than the exposed latency
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) raw[b][q] = make_uint4(0, 0, 0, 0);
+                if (!(in0 && idx0 + b * STRIDE < total)) continue;
+            }
             if constexpr (MODE == RD_SRC_RAW || MODE == RD_SRC_AFF || MODE == RD_SRC_AFFACT) {
                 raw[b][0] = ld16(base + ((size_t)(nn * H + y) * W + x) * C);
             } else if constexpr (MODE == RD_SRC_BNBWD) {
@@ -295,7 +302,7 @@ __device__ __forceinline__ void tile_fill_mode(const rd_src_t& s, const SlotCtx<
 
 // fills `total` items (item idx -> (pixel, this thread's channel slot)); map(idx, y, x) gives the conv-frame
 // pixel and whether it lies inside the image; store(idx, u) writes the 16-byte slot to LDS.
-template <typename T, int STRIDE = 256, typename MapFn, typename StoreFn>
+template <typename T, int STRIDE = 256, bool BF = true, typename MapFn, typename StoreFn>
 __device__ __forceinline__ void tile_fill(const rd_src_t* src, const SlotCtx<T>& k, int n, int H, int W, int tid, int total,
                                           MapFn map, StoreFn store) {
     constexpr int S = Slot<T>::N;
@@ -350,12 +357,12 @@ __device__ __forceinline__ void tile_fill(const rd_src_t* src, const SlotCtx<T>&
         return;
     }
     switch (s.mode) {
-    case RD_SRC_RAW: tile_fill_mode<T, RD_SRC_RAW, 6, STRIDE>(s, k, n, H, W, tid, total, map, store); break;
-    case RD_SRC_AFF: tile_fill_mode<T, RD_SRC_AFF, 6, STRIDE>(s, k, n, H, W, tid, total, map, store); break;
-    case RD_SRC_AFFACT: tile_fill_mode<T, RD_SRC_AFFACT, 6, STRIDE>(s, k, n, H, W, tid, total, map, store); break;
-    case RD_SRC_BNBWD: tile_fill_mode<T, RD_SRC_BNBWD, 3, STRIDE>(s, k, n, H, W, tid, total, map, store); break;
-    case RD_SRC_POOL: tile_fill_mode<T, RD_SRC_POOL, 2, STRIDE>(s, k, n, H, W, tid, total, map, store); break;
-    default: tile_fill_mode<T, RD_SRC_UP, 2, STRIDE>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_RAW: tile_fill_mode<T, RD_SRC_RAW, 6, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_AFF: tile_fill_mode<T, RD_SRC_AFF, 6, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_AFFACT: tile_fill_mode<T, RD_SRC_AFFACT, 6, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_BNBWD: tile_fill_mode<T, RD_SRC_BNBWD, 3, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_POOL: tile_fill_mode<T, RD_SRC_POOL, 2, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    default: tile_fill_mode<T, RD_SRC_UP, 2, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
     }
 }
 
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
                 const int pix = idx >> 2;
                 s_in[pix * 4 + (s ^ ((pix >> 2) & 3))] = u;
             };
-            tile_fill<T>(p.src, ctx, n, H, W, tid, PH * PW * 4, map, store);
+            tile_fill<T, 256, false>(p.src, ctx, n, H, W, tid, PH * PW * 4, map, store);
         }
         {
             constexpr int WTOT = TAPS * NT * 4, WIT = (WTOT + 255) / 256;
@@ -759,22 +766,26 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
 // raw 16-byte slots of tile t+1 are requested into registers BEFORE the MFMAs and the epilogue of tile t
 // and are transformed / written to LDS afterwards (register double buffering).  BN sums are kept in
 // registers across the tiles and flushed with one set of atomics per workgroup.
+// per-thread item geometry of the halo tile (constant for the whole kernel: hoisted out of the tile loop)
+template <int NIT>
+struct ItemGeom {
+    short py[NIT], px[NIT];
+    int lds[NIT];          // slot index in s_in, -1: item does not exist
+};
+
 template <typename T, int NIT>
-__device__ __forceinline__ void pf_issue(uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, int n, int H, int W, int tid,
-                                         int total, int yh, int xh, int PW) {
-    // branch-free (clamped addresses): conditional loads would be waited for one by one (see tile_fill_mode)
+__device__ __forceinline__ void pf_issue(uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, const ItemGeom<NIT>& ig, int n,
+                                         int H, int W, int yh, int xh) {
+    // branch-free (clamped addresses): conditional loads would be waited for one by one (see tile_fill_mode);
+    // 32-bit element offsets from an image base keep the address math off the 64-bit VALU path
     const int C = s.C;
-    const T* base = reinterpret_cast<const T*>(s.ptr) + k.c;
-    const T* base2 = reinterpret_cast<const T*>(s.ptr2) + k.c;
-    const int nn = n + s.n_off;
-    size_t off[NIT];
+    const T* base = reinterpret_cast<const T*>(s.ptr) + k.c + (size_t)(n + s.n_off) * H * W * C;
+    const T* base2 = reinterpret_cast<const T*>(s.ptr2) + k.c + (size_t)(n + s.n_off) * H * W * C;
+    unsigned off[NIT];
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
-        const int idx = min(tid + b * 256, total - 1);
-        const int pix = idx >> 2;
-        const int py = pix / PW, px = pix - py * PW;
-        const int y = min(max(yh + py, 0), H - 1), x = min(max(xh + px, 0), W - 1);
-        off[b] = ((size_t)(nn * H + y) * W + x) * C;
+        const int y = min(max(yh + ig.py[b], 0), H - 1), x = min(max(xh + ig.px[b], 0), W - 1);
+        off[b] = (unsigned)((y * W + x) * C);
         raw[b][0] = ld16(base + off[b]);
     }
     if (s.mode == RD_SRC_BNBWD) {
@@ -784,16 +795,13 @@ __device__ __forceinline__ void pf_issue(uint4 (&raw)[NIT][2], const rd_src_t& s
 }
 
 template <typename T, int NIT>
-__device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, int H, int W, int tid,
-                                           int total, int yh, int xh, int PW, uint4* s_in, int sslot) {
+__device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, const ItemGeom<NIT>& ig,
+                                           int H, int W, int yh, int xh, uint4* s_in) {
     constexpr int S = Slot<T>::N;
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
-        const int idx = tid + b * 256;
-        if (idx >= total) continue;
-        const int pix = idx >> 2;
-        const int py = pix / PW, px = pix - py * PW;
-        const int y = yh + py, x = xh + px;
+        if (ig.lds[b] < 0) continue;
+        const int y = yh + ig.py[b], x = xh + ig.px[b];
         const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         uint4 u = in ? raw[b][0] : make_uint4(0, 0, 0, 0);
         if (s.mode != RD_SRC_RAW) {
@@ -813,7 +821,7 @@ __device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_
             }
             u = in ? Slot<T>::pack(v) : make_uint4(0, 0, 0, 0);
         }
-        s_in[pix * 4 + (sslot ^ ((pix >> 2) & 3))] = u;
+        s_in[ig.lds[b]] = u;
     }
 }
 
@@ -900,15 +908,24 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
     float s1 = 0.f, s2 = 0.f;
     T* out = reinterpret_cast<T*>(p.out);
 
+    ItemGeom<NIT> ig;
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) {
+        const int idx = tid + b * 256;
+        const int pix = min(idx, TOTAL - 1) >> 2;
+        ig.py[b] = (short)(pix / PW);
+        ig.px[b] = (short)(pix - (pix / PW) * PW);
+        ig.lds[b] = idx < TOTAL ? pix * 4 + (sslot ^ ((pix >> 2) & 3)) : -1;
+    }
     uint4 raw[NIT][2];
     if (pre && live_slot && t_begin < t_end)
-        pf_issue<T, NIT>(raw, ssrc, ctx, n, H, W, tid, TOTAL, (t_begin / tiles_x) * TH - HALO, (t_begin % tiles_x) * TW - HALO, PW);
+        pf_issue<T, NIT>(raw, ssrc, ctx, ig, n, H, W, (t_begin / tiles_x) * TH - HALO, (t_begin % tiles_x) * TW - HALO);
 
     for (int t = t_begin; t < t_end; ++t) {
         const int x0 = (t % tiles_x) * TW, y0 = (t / tiles_x) * TH;
         if (pre) {
             if (live_slot) {
-                pf_consume<T, NIT>(raw, ssrc, ctx, H, W, tid, TOTAL, y0 - HALO, x0 - HALO, PW, s_in, sslot);
+                pf_consume<T, NIT>(raw, ssrc, ctx, ig, H, W, y0 - HALO, x0 - HALO, s_in);
             } else {
                 for (int idx = tid; idx < TOTAL; idx += 256) {
                     const int pix = idx >> 2;
@@ -931,7 +948,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
         }
         __syncthreads();
         if (pre && live_slot && t + 1 < t_end)
-            pf_issue<T, NIT>(raw, ssrc, ctx, n, H, W, tid, TOTAL, ((t + 1) / tiles_x) * TH - HALO, ((t + 1) % tiles_x) * TW - HALO, PW);
+            pf_issue<T, NIT>(raw, ssrc, ctx, ig, n, H, W, ((t + 1) / tiles_x) * TH - HALO, ((t + 1) % tiles_x) * TW - HALO);
 
         f32x16 acc[2];
 #pragma unroll
