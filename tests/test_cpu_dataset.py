@@ -78,3 +78,24 @@ def test_metrics_postprocessing():
     assert dice_coefficient_numpy(np.zeros((4, 4)), np.zeros((4, 4))) == 1.0              # +1 smoothing
     p = np.stack([a * 0.9, a * 0.9]).astype(np.float32)
     assert postprocessing(torch.from_numpy(p), threshold=0.75).shape == (2, 10, 10)
+
+
+def test_prostate_multi_pieces(tmp_path):
+    from dataset.prostate import Prostate_Multi
+    rng = np.random.RandomState(2)
+    base = str(tmp_path / 'prostate')
+    for d in range(1, 7):
+        os.makedirs(os.path.join(base, 'Domain%d' % d, 'image'))
+        os.makedirs(os.path.join(base, 'Domain%d' % d, 'mask'))
+        for i in range(3):
+            np.save(os.path.join(base, 'Domain%d' % d, 'image', '%d.npy' % i), np.full((32, 32, 3), d / 10.0, np.float32))
+            np.save(os.path.join(base, 'Domain%d' % d, 'mask', '%d.npy' % i), rng.randint(0, 2, (32, 32)).astype(np.uint8))
+    ds = Prostate_Multi(domain_idx_list=[2], base_dir=base, split='train', is_out_domain=True, test_domain_idx=0)
+    np.random.seed(0); random.seed(0)
+    doms = set()
+    for k in range(30):
+        img, other, lam, mask = ds[k % 3]
+        assert img.shape == (32, 32, 3) and mask.dtype == torch.int64 and mask.shape == (32, 32)
+        assert abs(float(img[0, 0, 0]) - 0.3) < 1e-6
+        doms.add(int(round(float(other[0, 0, 0]) * 10)))
+    assert doms == {2, 4, 5, 6}                                        # not the test domain (1), not its own (3)

@@ -1,6 +1,7 @@
 """-m gpu: every HIP kernel, called through the C ABI, against a plain torch fp32 restatement of the
-same op on the same seeded inputs (fp32: 2e-5 x RMS; bf16: inputs pre-rounded to bf16, 2.5e-2 x RMS =
-a few bf16 ulps of the accumulated value -- the tolerance is the one written in gpu_util.RTOL)."""
+same op on the same seeded inputs.  Tolerance = 4 x gpu_util.RTOL x RMS(reference): fp32 8e-5 x RMS (the f32 MFMA is a
+bit-exact fmaf chain; only the summation order differs), bf16 4e-2 x RMS (inputs pre-rounded to bf16, operands of
+the MFMA and the stored result rounded once each: a few bf16 ulps of the largest elements)."""
 import ctypes as C
 import zlib
 

@@ -59,6 +59,12 @@ def test_train_cli_smoke(tmp_path):
     assert int(ck['encoder_state_dict']['convd1.bn1.num_batches_tracked']) == 12          # 6 iterations x 2 passes
     assert all(torch.isfinite(v.float()).all() for v in ck['encoder_state_dict'].values())
     assert os.path.exists(os.path.join(out, '0_val_log.csv'))
+    # offline evaluation script on that checkpoint (BN back in train mode, test_fundus_slice.py:75-83)
+    ev = [sys.executable, os.path.join(ROOT, 'ram-dsir_amd', 'test_fundus_slice.py'), '--model_file', os.path.join(out, 'final_model.pth'),
+          '--data_dir', data, '--datasetTest', '0', '--test_prediction_save_path', str(tmp_path / 'pred'), '--batch_size', '4']
+    r2 = subprocess.run(ev, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r2.returncode == 0, r2.stdout.decode()[-3000:]
+    assert 'val_cup_dice' in r2.stdout.decode() and os.path.exists(str(tmp_path / 'pred' / 'test0_log.csv'))
 
 
 def test_train_cli_rejects_flag_sets_the_reference_cannot_run(tmp_path):
