@@ -1,0 +1,114 @@
+// conv_api.hip -- extern "C" entry points of the convolution family (rd_conv, rd_wgrad, weight packing).
+#include "common.h"
+#include "../../include/ramdsir.h"
+#include "conv_dispatch.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ void pack_weights_kernel(const float* w, T* out, int Cout, int Cin, int taps, int transpose, int RowPad, int ColPad) {
+    // forward:   out[tap][n<RowPad(Cout)][c<ColPad(Cin)]   = w[n][c][tap]
+    // transpose: out[tap'][c<RowPad(Cin)][n<ColPad(Cout)]  = w[n][c][taps-1-tap']
+    const int total = taps * RowPad * ColPad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int col = i % ColPad, row = (i / ColPad) % RowPad, tap = i / (ColPad * RowPad);
+        float v = 0.f;
+        if (!transpose) {
+            if (row < Cout && col < Cin) v = w[((size_t)row * Cin + col) * taps + tap];
+        } else {
+            if (row < Cin && col < Cout) v = w[((size_t)col * Cin + row) * taps + (taps - 1 - tap)];
+        }
+        out[i] = from_f<T>(v);
+    }
+}
+
+// all convs of the network in one launch: entry e owns packed elements [start_e, start_{e+1})
+template <typename T>
+__global__ void pack_weights_batched_kernel(const float* params, T* packed, const rd_pack_entry_t* tab, int n_entries,
+                                            int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_entries - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid].start <= i) lo = mid; else hi = mid - 1;
+        }
+        const rd_pack_entry_t e = tab[lo];
+        const int j = (int)(i - e.start);
+        const int col = j % e.ColPad, row = (j / e.ColPad) % e.RowPad, tap = j / (e.ColPad * e.RowPad);
+        const float* w = params + e.src_off;
+        float v = 0.f;
+        if (!e.transpose) {
+            if (row < e.Cout && col < e.Cin) v = w[((size_t)row * e.Cin + col) * e.taps + tap];
+        } else {
+            if (row < e.Cin && col < e.Cout) v = w[((size_t)col * e.Cin + row) * e.taps + (e.taps - 1 - tap)];
+        }
+        packed[e.dst_off + j] = from_f<T>(v);
+    }
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+
+extern "C" {
+
+int64_t rd_packed_elems(int Cout, int Cin, int taps, int transpose, int dtype) {
+    const int ck = dtype == RD_BF16 ? 32 : 16;
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    return (int64_t)taps * round_up(rows, 32) * round_up(cols, ck);
+}
+
+int rd_pack_weights(const float* w_oihw, void* packed, int Cout, int Cin, int taps, int transpose, int dtype, void* stream) {
+    const int ck = dtype == RD_BF16 ? 32 : 16;
+    const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+    const int RowPad = round_up(rows, 32), ColPad = round_up(cols, ck);
+    const int total = taps * RowPad * ColPad;
+    int blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, w_oihw, (bf16_t*)packed, Cout, Cin, taps,
+                           transpose, RowPad, ColPad);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w_oihw, (float*)packed, Cout, Cin, taps,
+                           transpose, RowPad, ColPad);
+    return (int)hipGetLastError();
+}
+
+int rd_pack_weights_batched(const float* params, void* packed, const rd_pack_entry_t* table_dev, int n_entries, int64_t total,
+                            int dtype, void* stream) {
+    if (n_entries < 1 || total < 1) return -1;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, st, params, (bf16_t*)packed, table_dev,
+                           n_entries, total);
+    else
+        hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3((int)blocks), dim3(256), 0, st, params, (float*)packed, table_dev,
+                           n_entries, total);
+    return (int)hipGetLastError();
+}
+
+int rd_conv(const rd_conv_t* p, int dtype, void* stream) {
+    if (!p || (p->taps != 9 && p->taps != 1) || p->G < 1 || p->G > RD_MAX_GROUPS || p->nsrc < 1 || p->nsrc > 2) return -1;
+    const int ck = dtype == RD_BF16 ? 32 : 16;
+    if (p->CinPad % ck || p->CoutPad % 32 || p->CinPad < p->Cin || p->CoutPad < p->Cout) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    if (p->CinPad == ck && p->CoutPad == 32) return rd_conv_small_dispatch(*p, dtype, st);   // one K chunk, one N block
+    return rd_conv_big_dispatch(*p, dtype, st);
+}
+
+int64_t rd_wgrad_workspace(const rd_wgrad_t* p, int dtype) {
+    return rd_wgrad_ws_bytes(*p, dtype);
+}
+
+int rd_wgrad(const rd_wgrad_t* p, int dtype, void* stream) {
+    if (!p || (p->taps != 9 && p->taps != 1) || p->G < 1 || p->G > RD_MAX_GROUPS || p->na < 1 || p->na > 2) return -1;
+    return rd_wgrad_dispatch(*p, dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"
+

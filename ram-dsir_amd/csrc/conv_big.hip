@@ -1,0 +1,237 @@
+// conv_big.hip -- direct (im2col-free) 3x3 / 1x1 convolution on gfx950 MFMA: the generic multi-chunk forward / dgrad kernel.
+//
+// Replaces the ATen/cuDNN conv2d forward/dgrad/wgrad the reference reaches through nn.Conv2d
+// (code/networks/unet.py:37-43,81-88,124-131,281,307) together with everything that sits between two
+// convs in the reference graph -- BatchNorm apply, ReLU/LeakyReLU, MaxPool2d(2), bilinear x2,
+// torch.cat -- which is folded into the tile loader (forward) or the epilogue (backward).
+//
+// Implicit GEMM, M = pixels, N = output channels, K = taps x input channels:
+//   workgroup  = 256 threads = 4 wave64, output tile 8 rows x 32 columns of one image x NT channels
+//   wave w     = tile rows 2w, 2w+1  -> two 32-pixel M-blocks; NB = NT/32 N-blocks
+//   LDS        = halo tile (10 x 34 pixels) x 64 B of channels (16 fp32 / 32 bf16 per chunk),
+//                16-byte slots XOR-swizzled by (pixel>>2)&3 so that ds_read_b128 of 16 consecutive
+//                pixels is bank-conflict free; the weight chunk [tap][n][64 B] swizzled the same way
+//   MFMA       = v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, bit-exact fmaf chain)
+
+#include "conv_device.h"
+#include "conv_dispatch.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ conv kernel
+template <typename T, int TAPS, int NB>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
+    constexpr int S = Slot<T>::N;
+    constexpr int CK = 4 * S;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int NT = NB * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* s_in = reinterpret_cast<uint4*>(smem);          // [PH*PW][4]
+    uint4* s_w = s_in + PH * PW * 4;                       // [TAPS][NT][4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int x0 = (blockIdx.x % tiles_x) * TW, y0 = (blockIdx.x / tiles_x) * TH;
+    const int n0 = blockIdx.y * NT;
+    const int n = blockIdx.z;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+    const int g = group_of(gm, n);
+    const int H = p.H, W = p.W;
+    const int slot = (blockIdx.x + 7 * blockIdx.z) % RD_STAT_SLOTS;
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    const T* wbase = reinterpret_cast<const T*>(p.w);
+    for (int c0 = 0; c0 < p.CinPad; c0 += CK) {
+        __syncthreads();
+        {
+            const int s = tid & 3;                         // idx & 3 is constant per thread (stride 256)
+            SlotCtx<T> ctx;
+            slot_ctx<T>(ctx, p.src, p.nsrc, p.Cin, g, c0 + s * S);
+            auto map = [&](int idx, int& y, int& x) -> bool {
+                const int pix = idx >> 2;
+                const int py = pix / PW, px = pix - py * PW;
+                y = y0 - HALO + py;
+                x = x0 - HALO + px;
+                return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            };
+            auto store = [&](int idx, const uint4& u) {
+                const int pix = idx >> 2;
+                s_in[pix * 4 + (s ^ ((pix >> 2) & 3))] = u;
+            };
+            tile_fill<T, 256, false>(p.src, ctx, n, H, W, tid, PH * PW * 4, map, store);
+        }
+        {
+            constexpr int WTOT = TAPS * NT * 4, WIT = (WTOT + 255) / 256;
+            uint4 wr[WIT];
+#pragma unroll
+            for (int b = 0; b < WIT; ++b) {
+                const int idx = tid + b * 256;
+                const int s = idx & 3, rec = idx >> 2;
+                const int nn = rec % NT, tap = rec / NT;
+                wr[b] = ld16(wbase + ((size_t)(min(tap, TAPS - 1) * p.CoutPad + n0 + nn) * p.CinPad + c0 + s * S));
+            }
+#pragma unroll
+            for (int b = 0; b < WIT; ++b) {
+                const int idx = tid + b * 256;
+                const int s = idx & 3, rec = idx >> 2;
+                const int nn = rec % NT;
+                if (idx < WTOT) s_w[rec * 4 + (s ^ ((nn >> 2) & 3))] = wr[b];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int pix = (wave * 2 + mb + kh) * PW + li + kw;
+                const uint4* a_rec = s_in + pix * 4;
+                const int a_sw = (pix >> 2) & 3;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int nn = nb * 32 + li;
+                    Mma<T>::chunk(a_rec, a_sw, s_w + (tap * NT + nn) * 4, (nn >> 2) & 3, h, acc[mb][nb]);
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // C/D layout of the 32x32 MFMA: column (N, channel) = lane&31, row (M, pixel) = (r&3)+8*(r>>2)+4*(lane>>5).
+    // Each 32-channel block is staged through LDS as fp32 [256 pixels][32 ch] so that the global side runs
+    // on 16-byte slots (coalesced stores; vector reads of z / old gradients in the backward epilogues).
+    constexpr int SL = 32 / S;                             // slots per 32 channels
+    float* s_out = reinterpret_cast<float*>(smem);         // [TH*TW][32]
+    float* s_red = s_out + TH * TW * 32;                   // [32][2]
+    T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        __syncthreads();
+        const int cb = n0 + nb * 32;
+        if (tid < 64) s_red[tid] = 0.f;
+        {
+            const int cch = cb + li;
+            const bool cok = cch < p.Cout;
+            const float bsv = (p.emode == 0 && cok && p.bias) ? p.bias[cch] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int y = y0 + wave * 2 + mb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = acc[mb][nb][r] + bsv;
+                    s_out[((wave * 2 + mb) * TW + col) * 32 + li] = v;
+                    if (cok && y < H && x0 + col < W) { s1 += v; s2 += v * v; }
+                }
+            }
+            __syncthreads();
+            if (p.emode == 0 && p.stats) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0 && cok) {
+                    atomicAdd(&s_red[li * 2 + 0], s1);
+                    atomicAdd(&s_red[li * 2 + 1], s2);
+                }
+            }
+        }
+        const int sl = tid % SL;                           // constant per thread: 256 % SL == 0
+        const int c = cb + sl * S;
+        float b1[S], b2[S];
+#pragma unroll
+        for (int e = 0; e < S; ++e) b1[e] = b2[e] = 0.f;
+        const int di = (p.emode == 1 && c >= p.c_split) ? 1 : 0;
+        const rd_dst_t d = select_dst(p, di);
+        const int cd = c - (di ? p.c_split : 0);
+        float dsc[S], dsh[S];
+        {
+            const int gd = d.g_fixed >= 0 ? d.g_fixed : g;
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                const bool ok = p.emode == 1 && c < p.Cout && d.kind != RD_DST_NONE && d.scale && (cd + e < d.Cd);
+                dsc[e] = ok ? d.scale[gd * d.Cd + cd + e] : 1.f;
+                dsh[e] = ok ? d.shift[gd * d.Cd + cd + e] : 0.f;
+            }
+        }
+        if (c < p.Cout) {
+            for (int idx = tid; idx < TH * TW * SL; idx += 256) {
+                const int pix = idx / SL;
+                const int y = y0 + pix / TW, x = x0 + pix % TW;
+                if (y >= H || x >= W) continue;
+                float v[S];
+#pragma unroll
+                for (int e = 0; e < S; e += 4) {
+                    const float4 f = *reinterpret_cast<const float4*>(s_out + pix * 32 + sl * S + e);
+                    v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
+                }
+                if (p.emode == 0)
+                    store_vec<T>(out + ((size_t)(n * H + y) * W + x) * p.Cout + c, v, p.Cout - c, (p.Cout % S) == 0);
+                else if (d.kind != RD_DST_NONE)
+                    grad_item<T>(d, g, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
+            }
+        }
+        // (wave-uniform condition: emode is a launch constant; lanes without a live destination add zeros)
+        if (p.emode == 1) flush_bstats<S, SL>(s_red, lane, sl, b1, b2);
+        __syncthreads();
+        if (tid < 32 && cb + tid < p.Cout) {
+            if (p.emode == 0) {
+                if (p.stats) {
+                    const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + cb + tid) * 2;
+                    atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
+                }
+            } else {
+                const int cch = cb + tid;
+                const int dj = cch >= p.c_split ? 1 : 0;
+                const rd_dst_t dd = select_dst(p, dj);
+                if (dd.kind != RD_DST_NONE && dd.bstats) {
+                    const int cdd = cch - (dj ? p.c_split : 0);
+                    const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
+                    const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
+                    atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int TAPS, int NB>
+int launch_conv(const rd_conv_t& p, hipStream_t st) {
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    size_t lds = (size_t)(PH * PW * 4 + TAPS * NB * 32 * 4) * sizeof(uint4);
+    const size_t lds_epi = (size_t)(TH * TW * 32 + 64) * sizeof(float);
+    if (lds < lds_epi) lds = lds_epi;
+    dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), p.CoutPad / (NB * 32), p.N);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, TAPS, NB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_kernel<T, TAPS, NB>), grid, dim3(256), lds, st, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int rd_conv_big_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
+    const bool nb2 = (p.CoutPad % 64) == 0;
+    if (dtype == RD_BF16) {
+        if (p.taps == 9) return nb2 ? launch_conv<bf16_t, 9, 2>(p, st) : launch_conv<bf16_t, 9, 1>(p, st);
+        return nb2 ? launch_conv<bf16_t, 1, 2>(p, st) : launch_conv<bf16_t, 1, 1>(p, st);
+    }
+    if (p.taps == 9) return nb2 ? launch_conv<float, 9, 2>(p, st) : launch_conv<float, 9, 1>(p, st);
+    return nb2 ? launch_conv<float, 1, 2>(p, st) : launch_conv<float, 1, 1>(p, st);
+}
+

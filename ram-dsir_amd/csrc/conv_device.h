@@ -1,0 +1,639 @@
+// conv_device.h -- device-side building blocks shared by the conv / wgrad translation units: tile loaders with the
+// fused BN / activation / pool / upsample transforms, MFMA atoms, gradient epilogues, register prefetch helpers.
+#pragma once
+#include "common.h"
+#include "../../include/ramdsir.h"
+#include <stdlib.h>
+
+namespace {
+
+
+constexpr int TH = 8, TW = 32;
+
+// ------------------------------------------------------------------------------------ tile loader
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, int cvalid, bool vec_ok, float* f) {
+    constexpr int S = Slot<T>::N;
+    if (vec_ok && cvalid >= S) {
+        uint4 u = *reinterpret_cast<const uint4*>(p);
+        Slot<T>::unpack(u, f);
+    } else {
+#pragma unroll
+        for (int e = 0; e < S; ++e) f[e] = (e < cvalid) ? to_f<T>(p[e]) : 0.f;
+    }
+}
+
+// Per-thread, per-chunk constants of the tile loader: which source the thread's channel slot belongs to
+// and that slot's BN coefficients (each thread keeps ONE slot index for a whole chunk, so these are loaded
+// once per chunk instead of once per pixel).
+template <typename T>
+struct SlotCtx {
+    static constexpr int S = Slot<T>::N;
+    int si;        // source index, -1: channel slot beyond Cin (zeros)
+    int c;         // channel within the source
+    float sc[S], sh[S], q[S];
+};
+
+template <typename T>
+__device__ __forceinline__ void slot_ctx(SlotCtx<T>& k, const rd_src_t* src, int nsrc, int Cin, int g_img, int c) {
+    constexpr int S = Slot<T>::N;
+    k.si = -1;
+    k.c = 0;
+    if (c >= Cin) return;
+    k.si = (nsrc == 1 || c < src[0].C) ? 0 : 1;
+    k.c = c - (k.si ? src[0].C : 0);
+    // field-by-field select keeps the kernarg struct out of scratch
+    const int C = k.si ? src[1].C : src[0].C;
+    const int mode = k.si ? src[1].mode : src[0].mode;
+    const int gf = k.si ? src[1].g_fixed : src[0].g_fixed;
+    const float* scp = k.si ? src[1].scale : src[0].scale;
+    const float* shp = k.si ? src[1].shift : src[0].shift;
+    const float* qp = k.si ? src[1].q : src[0].q;
+    const int cvalid = C - k.c;
+    const int g = gf >= 0 ? gf : g_img;
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        const bool ok = (e < cvalid) && mode != RD_SRC_RAW;
+        k.sc[e] = ok ? scp[g * C + k.c + e] : 0.f;
+        k.sh[e] = ok ? shp[g * C + k.c + e] : 0.f;
+        k.q[e] = (ok && mode == RD_SRC_BNBWD) ? qp[g * C + k.c + e] : 0.f;
+    }
+}
+
+// One 16-byte slot of conv-input pixel (n, y, x) of source s, transformed.  (y, x) are in the conv's
+// H x W frame and inside the image.
+template <typename T>
+__device__ __forceinline__ void load_slot(const rd_src_t& s, const SlotCtx<T>& k, int n, int y, int x, int H, int W, float* v) {
+    constexpr int S = Slot<T>::N;
+    const int C = s.C, c = k.c;
+    const int cvalid = C - c;
+    const bool vec_ok = (C % S) == 0;
+    const T* base = reinterpret_cast<const T*>(s.ptr);
+    n += s.n_off;
+    switch (s.mode) {
+    case RD_SRC_RAW: {
+        load_vec<T>(base + ((size_t)(n * H + y) * W + x) * C + c, cvalid, vec_ok, v);
+    } break;
+    case RD_SRC_AFF: {
+        load_vec<T>(base + ((size_t)(n * H + y) * W + x) * C + c, cvalid, vec_ok, v);
+#pragma unroll
+        for (int e = 0; e < S; ++e) v[e] = v[e] * k.sc[e] + k.sh[e];
+    } break;
+    case RD_SRC_AFFACT: {
+        load_vec<T>(base + ((size_t)(n * H + y) * W + x) * C + c, cvalid, vec_ok, v);
+#pragma unroll
+        for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * k.sc[e] + k.sh[e], s.slope);
+    } break;
+    case RD_SRC_POOL: {
+        const int Hs = 2 * H, Ws = 2 * W;
+        float t[4][S];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            load_vec<T>(base + ((size_t)(n * Hs + 2 * y + (j >> 1)) * Ws + 2 * x + (j & 1)) * C + c, cvalid, vec_ok, t[j]);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            float m = act_fn(t[0][e] * k.sc[e] + k.sh[e], s.slope);
+#pragma unroll
+            for (int j = 1; j < 4; ++j) m = fmaxf(m, act_fn(t[j][e] * k.sc[e] + k.sh[e], s.slope));
+            v[e] = m;
+        }
+    } break;
+    case RD_SRC_UP: {
+        const int Hs = H >> 1, Ws = W >> 1;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        up2_coord(y, Hs, y0, y1, ly);
+        up2_coord(x, Ws, x0, x1, lx);
+        float t00[S], t01[S], t10[S], t11[S];
+        load_vec<T>(base + ((size_t)(n * Hs + y0) * Ws + x0) * C + c, cvalid, vec_ok, t00);
+        load_vec<T>(base + ((size_t)(n * Hs + y0) * Ws + x1) * C + c, cvalid, vec_ok, t01);
+        load_vec<T>(base + ((size_t)(n * Hs + y1) * Ws + x0) * C + c, cvalid, vec_ok, t10);
+        load_vec<T>(base + ((size_t)(n * Hs + y1) * Ws + x1) * C + c, cvalid, vec_ok, t11);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            float top = t00[e] + lx * (t01[e] - t00[e]);
+            float bot = t10[e] + lx * (t11[e] - t10[e]);
+            float u = top + ly * (bot - top);
+            v[e] = act_fn(u * k.sc[e] + k.sh[e], s.slope);
+        }
+    } break;
+    case RD_SRC_BNBWD: {
+        const T* zb = reinterpret_cast<const T*>(s.ptr2);
+        const size_t off = ((size_t)(n * H + y) * W + x) * C + c;
+        float gz[S], zz[S];
+        load_vec<T>(base + off, cvalid, vec_ok, gz);
+        load_vec<T>(zb + off, cvalid, vec_ok, zz);
+#pragma unroll
+        for (int e = 0; e < S; ++e) v[e] = k.sc[e] * gz[e] + k.q[e] * zz[e] + k.sh[e];
+    } break;
+    default:
+#pragma unroll
+        for (int e = 0; e < S; ++e) v[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < S; ++e)
+        if (e >= cvalid) v[e] = 0.f;
+}
+
+// slot of conv-input pixel (n,y,x) for the thread's channel slot; zero outside the image / channels
+template <typename T>
+__device__ __forceinline__ uint4 gather_slot(const rd_src_t* src, const SlotCtx<T>& k, int n, int y, int x, int H, int W) {
+    constexpr int S = Slot<T>::N;
+    float v[S];
+#pragma unroll
+    for (int e = 0; e < S; ++e) v[e] = 0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && k.si >= 0) {
+        if (k.si == 0)
+            load_slot<T>(src[0], k, n, y, x, H, W, v);
+        else
+            load_slot<T>(src[1], k, n, y, x, H, W, v);
+    }
+    return Slot<T>::pack(v);
+}
+
+// ------------------------------------------------------------------------------------ loads-first tile fill
+// The tile loaders keep many independent 16-byte loads in flight per thread (the layers are HBM-bound):
+// phase A issues the loads of a whole batch of items, phase B transforms and stores them to LDS.  The
+// source mode is resolved OUTSIDE the item loops so that each loop body is straight-line code.
+__device__ __forceinline__ rd_src_t select_src(const rd_src_t* src, int si) {
+    rd_src_t s;
+    s.ptr = si ? src[1].ptr : src[0].ptr;
+    s.ptr2 = si ? src[1].ptr2 : src[0].ptr2;
+    s.scale = si ? src[1].scale : src[0].scale;
+    s.shift = si ? src[1].shift : src[0].shift;
+    s.q = si ? src[1].q : src[0].q;
+    s.mode = si ? src[1].mode : src[0].mode;
+    s.C = si ? src[1].C : src[0].C;
+    s.slope = si ? src[1].slope : src[0].slope;
+    s.n_off = si ? src[1].n_off : src[0].n_off;
+    s.g_fixed = si ? src[1].g_fixed : src[0].g_fixed;
+    s.pad_ = 0;
+    return s;
+}
+
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <typename T, int MODE, int BATCH, int STRIDE, bool BF, typename MapFn, typename StoreFn>
+__device__ __forceinline__ void tile_fill_mode(const rd_src_t& s, const SlotCtx<T>& k, int n, int H, int W, int tid, int total,
+                                               MapFn map, StoreFn store) {
+    constexpr int S = Slot<T>::N;
+    constexpr int NQ = (MODE == RD_SRC_POOL || MODE == RD_SRC_UP) ? 4 : (MODE == RD_SRC_BNBWD ? 2 : 1);
+    const int C = s.C;
+    const T* base = reinterpret_cast<const T*>(s.ptr) + k.c;
+    const T* base2 = reinterpret_cast<const T*>(s.ptr2) + k.c;
+    const int nn = n + s.n_off;
+    for (int idx0 = tid; idx0 < total; idx0 += STRIDE * BATCH) {
+        // Phase A is branch-free on purpose: a load inside `if (inside image)` makes the compiler wait for it at
+        // the join, i.e. one exposed memory latency per item.  Out-of-range items load a clamped (valid) address
+        // and are zeroed in phase B.
+        uint4 raw[BATCH][NQ];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int idx = min(idx0 + b * STRIDE, total - 1);
+            int y = 0, x = 0;
+            const bool in0 = map(idx, y, x);
+            y = min(max(y, 0), H - 1);
+            x = min(max(x, 0), W - 1);
+            if constexpr (!BF) {
+                // small images (25x25, 50x50 under 8x32 tiles): a large share of the items is outside the image;
+                // there the skipped loads are worth more than the exposed latency
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) raw[b][q] = make_uint4(0, 0, 0, 0);
+                if (!(in0 && idx0 + b * STRIDE < total)) continue;
+            }
+            if constexpr (MODE == RD_SRC_RAW || MODE == RD_SRC_AFF || MODE == RD_SRC_AFFACT) {
+                raw[b][0] = ld16(base + ((size_t)(nn * H + y) * W + x) * C);
+            } else if constexpr (MODE == RD_SRC_BNBWD) {
+                const size_t off = ((size_t)(nn * H + y) * W + x) * C;
+                raw[b][0] = ld16(base + off);
+                raw[b][1] = ld16(base2 + off);
+            } else if constexpr (MODE == RD_SRC_POOL) {
+                const int Ws = 2 * W;
+                const T* p00 = base + ((size_t)(nn * 2 * H + 2 * y) * Ws + 2 * x) * C;
+                raw[b][0] = ld16(p00);
+                raw[b][1] = ld16(p00 + C);
+                raw[b][2] = ld16(p00 + (size_t)Ws * C);
+                raw[b][3] = ld16(p00 + (size_t)Ws * C + C);
+            } else {  // UP
+                const int Hs = H >> 1, Ws = W >> 1;
+                int y0, y1, x0, x1;
+                float ly, lx;
+                up2_coord(y, Hs, y0, y1, ly);
+                up2_coord(x, Ws, x0, x1, lx);
+                const T* pn = base + (size_t)nn * Hs * Ws * C;
+                raw[b][0] = ld16(pn + ((size_t)y0 * Ws + x0) * C);
+                raw[b][1] = ld16(pn + ((size_t)y0 * Ws + x1) * C);
+                raw[b][2] = ld16(pn + ((size_t)y1 * Ws + x0) * C);
+                raw[b][3] = ld16(pn + ((size_t)y1 * Ws + x1) * C);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int idx = idx0 + b * STRIDE;
+            if (idx >= total) continue;
+            int y = 0, x = 0;
+            const bool in = map(idx, y, x);
+            float v[S];
+#pragma unroll
+            for (int e = 0; e < S; ++e) v[e] = 0.f;
+            if (in) {
+                if constexpr (MODE == RD_SRC_RAW) {
+                    store(idx, raw[b][0]);
+                    continue;
+                } else if constexpr (MODE == RD_SRC_AFF) {
+                    Slot<T>::unpack(raw[b][0], v);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) v[e] = v[e] * k.sc[e] + k.sh[e];
+                } else if constexpr (MODE == RD_SRC_AFFACT) {
+                    Slot<T>::unpack(raw[b][0], v);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * k.sc[e] + k.sh[e], s.slope);
+                } else if constexpr (MODE == RD_SRC_BNBWD) {
+                    float zz[S];
+                    Slot<T>::unpack(raw[b][0], v);
+                    Slot<T>::unpack(raw[b][1], zz);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) v[e] = k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e];
+                } else if constexpr (MODE == RD_SRC_POOL) {
+                    float t[S];
+                    Slot<T>::unpack(raw[b][0], v);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * k.sc[e] + k.sh[e], s.slope);
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) {
+                        Slot<T>::unpack(raw[b][j], t);
+#pragma unroll
+                        for (int e = 0; e < S; ++e) v[e] = fmaxf(v[e], act_fn(t[e] * k.sc[e] + k.sh[e], s.slope));
+                    }
+                } else {  // UP
+                    const int Hs = H >> 1, Ws = W >> 1;
+                    int y0, y1, x0, x1;
+                    float ly, lx;
+                    up2_coord(y, Hs, y0, y1, ly);
+                    up2_coord(x, Ws, x0, x1, lx);
+                    float t00[S], t01[S], t10[S], t11[S];
+                    Slot<T>::unpack(raw[b][0], t00);
+                    Slot<T>::unpack(raw[b][1], t01);
+                    Slot<T>::unpack(raw[b][2], t10);
+                    Slot<T>::unpack(raw[b][3], t11);
+#pragma unroll
+                    for (int e = 0; e < S; ++e) {
+                        const float top = t00[e] + lx * (t01[e] - t00[e]);
+                        const float bot = t10[e] + lx * (t11[e] - t10[e]);
+                        const float u = top + ly * (bot - top);
+                        v[e] = act_fn(u * k.sc[e] + k.sh[e], s.slope);
+                    }
+                }
+            }
+            store(idx, Slot<T>::pack(v));
+        }
+    }
+}
+
+// fills `total` items (item idx -> (pixel, this thread's channel slot)); map(idx, y, x) gives the conv-frame
+// pixel and whether it lies inside the image; store(idx, u) writes the 16-byte slot to LDS.
+template <typename T, int STRIDE = 256, bool BF = true, typename MapFn, typename StoreFn>
+__device__ __forceinline__ void tile_fill(const rd_src_t* src, const SlotCtx<T>& k, int n, int H, int W, int tid, int total,
+                                          MapFn map, StoreFn store) {
+    constexpr int S = Slot<T>::N;
+    if (k.si < 0) {
+        for (int idx = tid; idx < total; idx += STRIDE) store(idx, make_uint4(0, 0, 0, 0));
+        return;
+    }
+    const rd_src_t s = select_src(src, k.si);
+    const bool fast = (s.C % S) == 0 && (s.C - k.c) >= S;
+    if (!fast && s.mode == RD_SRC_RAW && s.C <= 4 && k.c == 0) {
+        // narrow raw tensors (3-channel image, 2/3-class dlogits): element loads, still loads-first
+        const T* base = reinterpret_cast<const T*>(s.ptr);
+        const int C = s.C, nn = n + s.n_off;
+        constexpr int NB_ = 6;
+        for (int idx0 = tid; idx0 < total; idx0 += STRIDE * NB_) {
+            T e[NB_][4];
+#pragma unroll
+            for (int b = 0; b < NB_; ++b) {
+                const int idx = idx0 + b * STRIDE;
+                int y = 0, x = 0;
+                const bool in = idx < total && map(idx, y, x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[b][j] = from_f<T>(0.f);
+                if (in) {
+                    const T* pp = base + ((size_t)(nn * H + y) * W + x) * C;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < C) e[b][j] = pp[j];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB_; ++b) {
+                const int idx = idx0 + b * STRIDE;
+                if (idx >= total) continue;
+                float v[S];
+#pragma unroll
+                for (int j = 0; j < S; ++j) v[j] = j < 4 ? to_f<T>(e[b][j]) : 0.f;
+                store(idx, Slot<T>::pack(v));
+            }
+        }
+        return;
+    }
+    if (!fast) {                                           // other odd channel counts: generic per-item path
+        for (int idx = tid; idx < total; idx += STRIDE) {
+            int y = 0, x = 0;
+            float v[S];
+#pragma unroll
+            for (int e = 0; e < S; ++e) v[e] = 0.f;
+            if (map(idx, y, x)) load_slot<T>(s, k, n, y, x, H, W, v);
+            store(idx, Slot<T>::pack(v));
+        }
+        return;
+    }
+    switch (s.mode) {
+    case RD_SRC_RAW: tile_fill_mode<T, RD_SRC_RAW, 6, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_AFF: tile_fill_mode<T, RD_SRC_AFF, 6, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_AFFACT: tile_fill_mode<T, RD_SRC_AFFACT, 6, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_BNBWD: tile_fill_mode<T, RD_SRC_BNBWD, 3, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    case RD_SRC_POOL: tile_fill_mode<T, RD_SRC_POOL, 2, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    default: tile_fill_mode<T, RD_SRC_UP, 2, STRIDE, BF>(s, k, n, H, W, tid, total, map, store); break;
+    }
+}
+
+__device__ __forceinline__ GroupMap make_gm(const int32_t* gstart, int G) {
+    GroupMap gm;
+    gm.G = G;
+#pragma unroll
+    for (int i = 0; i <= RD_MAX_GROUPS; ++i) gm.gs[i] = gstart[i];
+    return gm;
+}
+
+// ------------------------------------------------------------------------------------ MFMA atoms
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // one 64-byte chunk = 32 channels = 2 k-steps of 16; lane-half h owns 8 channels per k-step
+    static __device__ __forceinline__ void chunk(const uint4* a_rec, int a_sw, const uint4* b_rec, int b_sw, int h,
+                                                 f32x16& acc, int nks = 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks >= nks) break;                          // wave-uniform: <=16 input channels need one k-step
+            const int slot = ks * 2 + h;
+            uint4 au = a_rec[slot ^ a_sw];
+            uint4 bu = b_rec[slot ^ b_sw];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, au), __builtin_bit_cast(bf16x8, bu),
+                                                          acc, 0, 0, 0);
+        }
+    }
+};
+template <> struct Mma<float> {
+    // one 64-byte chunk = 16 channels; lane-half h owns channels 8h..8h+7 (k order is a permutation,
+    // identical for A and B); 8 x v_mfma_f32_32x32x2_f32
+    static __device__ __forceinline__ void chunk(const uint4* a_rec, int a_sw, const uint4* b_rec, int b_sw, int h,
+                                                 f32x16& acc, int nks = 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int slot = 2 * h + q;
+            uint4 au = a_rec[slot ^ a_sw];
+            uint4 bu = b_rec[slot ^ b_sw];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au.x), __uint_as_float(bu.x), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au.y), __uint_as_float(bu.y), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au.z), __uint_as_float(bu.z), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au.w), __uint_as_float(bu.w), acc, 0, 0, 0);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------ gradient epilogue
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const float* v, int cvalid, bool vec_ok) {
+    constexpr int S = Slot<T>::N;
+    if (vec_ok && cvalid >= S) {
+        *reinterpret_cast<uint4*>(p) = Slot<T>::pack(v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < S; ++e)
+            if (e < cvalid) p[e] = from_f<T>(v[e]);
+    }
+}
+
+// S channels (one slot) of the gradient w.r.t. a conv input pixel -> gradient w.r.t. the producer's BN
+// output: activation mask, max-pool scatter or upsample-side mask; b1 += g, b2 += g*z per channel.
+template <typename T, int KMASK = 7>
+__device__ __forceinline__ void grad_item(const rd_dst_t& d, int g_img, int n, int y, int x, int H, int W, int cd,
+                                          const float* da, const float* sc, const float* sh, float* b1, float* b2) {
+    constexpr int S = Slot<T>::N;
+    T* gp = reinterpret_cast<T*>(d.g);
+    const T* zp = reinterpret_cast<const T*>(d.z);
+    const int Cd = d.Cd;
+    const int cvalid = Cd - cd;
+    const bool vec_ok = (Cd % S) == 0;
+    n += d.n_off;
+    if ((KMASK & 1) && d.kind == RD_DST_PLAIN) {
+        const size_t idx = ((size_t)(n * H + y) * W + x) * Cd + cd;
+        float z[S], gw[S];
+#pragma unroll
+        for (int e = 0; e < S; ++e) z[e] = 0.f;
+        if (zp) load_vec<T>(zp + idx, cvalid, vec_ok, z);
+        if (d.accumulate) load_vec<T>(gp + idx, cvalid, vec_ok, gw);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const float m = (d.act && zp) ? act_grad(z[e] * sc[e] + sh[e], d.slope) : 1.f;
+            const float gn = da[e] * m;
+            b1[e] += gn;
+            b2[e] += gn * z[e];
+            gw[e] = d.accumulate ? gw[e] + gn : gn;
+        }
+        store_vec<T>(gp + idx, gw, cvalid, vec_ok);
+    } else if ((KMASK & 2) && d.kind == RD_DST_POOL) {
+        const int Hd = 2 * H, Wd = 2 * W;
+        float zz[4][S], best[S];
+        int arg[S];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t idx = ((size_t)(n * Hd + 2 * y + (k >> 1)) * Wd + 2 * x + (k & 1)) * Cd + cd;
+            load_vec<T>(zp + idx, cvalid, vec_ok, zz[k]);
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                const float a = act_fn(zz[k][e] * sc[e] + sh[e], d.slope);
+                if (k == 0 || a > best[e]) { best[e] = a; arg[e] = k; }      // first max wins (ATen max_pool2d)
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t idx = ((size_t)(n * Hd + 2 * y + (k >> 1)) * Wd + 2 * x + (k & 1)) * Cd + cd;
+            float gw[S];
+            if (d.accumulate) load_vec<T>(gp + idx, cvalid, vec_ok, gw);
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                float gn = 0.f;
+                if (arg[e] == k) {
+                    gn = da[e] * (d.act ? act_grad(zz[k][e] * sc[e] + sh[e], d.slope) : 1.f);
+                    b1[e] += gn;
+                    b2[e] += gn * zz[k][e];
+                }
+                gw[e] = d.accumulate ? gw[e] + gn : gn;
+            }
+            store_vec<T>(gp + idx, gw, cvalid, vec_ok);
+        }
+    } else if ((KMASK & 4) && d.kind == RD_DST_UPY) {
+        const int Hs = H >> 1, Ws = W >> 1;
+        int yy0, yy1, xx0, xx1;
+        float ly, lx;
+        up2_coord(y, Hs, yy0, yy1, ly);
+        up2_coord(x, Ws, xx0, xx1, lx);
+        float t00[S], t01[S], t10[S], t11[S], gw[S];
+        load_vec<T>(zp + ((size_t)(n * Hs + yy0) * Ws + xx0) * Cd + cd, cvalid, vec_ok, t00);
+        load_vec<T>(zp + ((size_t)(n * Hs + yy0) * Ws + xx1) * Cd + cd, cvalid, vec_ok, t01);
+        load_vec<T>(zp + ((size_t)(n * Hs + yy1) * Ws + xx0) * Cd + cd, cvalid, vec_ok, t10);
+        load_vec<T>(zp + ((size_t)(n * Hs + yy1) * Ws + xx1) * Cd + cd, cvalid, vec_ok, t11);
+        const size_t idx = ((size_t)(n * H + y) * W + x) * Cd + cd;
+        if (d.accumulate) load_vec<T>(gp + idx, cvalid, vec_ok, gw);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const float top = t00[e] + lx * (t01[e] - t00[e]), bot = t10[e] + lx * (t11[e] - t10[e]);
+            const float u = top + ly * (bot - top);
+            const float m = d.act ? act_grad(u * sc[e] + sh[e], d.slope) : 1.f;
+            const float gn = da[e] * m;
+            b1[e] += gn;
+            b2[e] += gn * u;
+            gw[e] = d.accumulate ? gw[e] + gn : gn;
+        }
+        store_vec<T>(gp + idx, gw, cvalid, vec_ok);
+    }
+}
+
+// plain destination, full 16-byte slots: g = da * act'(z*sc+sh) (+ old g); b1 += g, b2 += g*z
+template <typename T>
+__device__ __forceinline__ void grad_plain(const rd_dst_t& d, int n, int y, int x, int H, int W, int cd, const float* da,
+                                           const float* sc, const float* sh, float* b1, float* b2) {
+    constexpr int S = Slot<T>::N;
+    T* gp = reinterpret_cast<T*>(d.g);
+    const T* zp = reinterpret_cast<const T*>(d.z);
+    const size_t idx = ((size_t)((n + d.n_off) * H + y) * W + x) * d.Cd + cd;
+    float z[S], gw[S];
+    uint4 zu = make_uint4(0, 0, 0, 0), gu = make_uint4(0, 0, 0, 0);
+    if (zp) zu = ld16(zp + idx);
+    if (d.accumulate) gu = ld16(gp + idx);
+    Slot<T>::unpack(zu, z);
+    Slot<T>::unpack(gu, gw);
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        const float m = (d.act && zp) ? act_grad(z[e] * sc[e] + sh[e], d.slope) : 1.f;
+        const float gn = da[e] * m;
+        b1[e] += gn;
+        b2[e] += gn * z[e];
+        gw[e] += gn;
+    }
+    *reinterpret_cast<uint4*>(gp + idx) = Slot<T>::pack(gw);
+}
+
+// sum b1/b2 over the lanes of a wave that own the same channel slot (lane % SL), then one LDS atomic per
+// wave and channel instead of one per thread (64-way same-address contention otherwise)
+template <int S, int SL>
+__device__ __forceinline__ void flush_bstats(float* s_red, int lane, int sl, float* b1, float* b2) {
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+#pragma unroll
+        for (int o = SL; o < 64; o <<= 1) {
+            b1[e] += __shfl_xor(b1[e], o, 64);
+            b2[e] += __shfl_xor(b2[e], o, 64);
+        }
+    }
+    if (lane < SL) {
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            atomicAdd(&s_red[(sl * S + e) * 2 + 0], b1[e]);
+            atomicAdd(&s_red[(sl * S + e) * 2 + 1], b2[e]);
+        }
+    }
+}
+
+// picks dst[0] or dst[1] field by field (lane-varying di): keeps the kernarg struct out of scratch
+__device__ __forceinline__ rd_dst_t select_dst(const rd_conv_t& p, int di) {
+    rd_dst_t d;
+    d.g = di ? p.dst[1].g : p.dst[0].g;
+    d.z = di ? p.dst[1].z : p.dst[0].z;
+    d.scale = di ? p.dst[1].scale : p.dst[0].scale;
+    d.shift = di ? p.dst[1].shift : p.dst[0].shift;
+    d.bstats = di ? p.dst[1].bstats : p.dst[0].bstats;
+    d.kind = di ? p.dst[1].kind : p.dst[0].kind;
+    d.act = di ? p.dst[1].act : p.dst[0].act;
+    d.accumulate = di ? p.dst[1].accumulate : p.dst[0].accumulate;
+    d.Cd = di ? p.dst[1].Cd : p.dst[0].Cd;
+    d.slope = di ? p.dst[1].slope : p.dst[0].slope;
+    d.n_off = di ? p.dst[1].n_off : p.dst[0].n_off;
+    d.g_fixed = di ? p.dst[1].g_fixed : p.dst[0].g_fixed;
+    d.pad_ = 0;
+    return d;
+}
+
+// ------------------------------------------------------------------------------------ small-channel persistent kernel
+// Cin <= one 64-byte chunk and Cout <= 32 (every 400x400 / 200x200 layer of the U-Net, forward and dgrad):
+// these layers are HBM-bound, so the kernel is built around keeping loads in flight.  A workgroup walks
+// `tiles_per_wg` consecutive 8x32 tiles of one image; the packed weights stay in LDS for all of them; the
+// raw 16-byte slots of tile t+1 are requested into registers BEFORE the MFMAs and the epilogue of tile t
+// and are transformed / written to LDS afterwards (register double buffering).  BN sums are kept in
+// registers across the tiles and flushed with one set of atomics per workgroup.
+// per-thread item geometry of the halo tile (constant for the whole kernel: hoisted out of the tile loop)
+template <int NIT>
+struct ItemGeom {
+    short py[NIT], px[NIT];
+    int lds[NIT];          // slot index in s_in, -1: item does not exist
+};
+
+template <typename T, int NIT>
+__device__ __forceinline__ void pf_issue(uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, const ItemGeom<NIT>& ig, int n,
+                                         int H, int W, int yh, int xh, int nit = NIT) {
+    // branch-free (clamped addresses): conditional loads would be waited for one by one (see tile_fill_mode);
+    // 32-bit element offsets from an image base keep the address math off the 64-bit VALU path
+    const int C = s.C;
+    const T* base = reinterpret_cast<const T*>(s.ptr) + k.c + (size_t)(n + s.n_off) * H * W * C;
+    const T* base2 = reinterpret_cast<const T*>(s.ptr2) + k.c + (size_t)(n + s.n_off) * H * W * C;
+    unsigned off[NIT];
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) {
+        if (b >= nit) break;                               // wave-uniform: 16-channel layers have half the items
+        const int y = min(max(yh + ig.py[b], 0), H - 1), x = min(max(xh + ig.px[b], 0), W - 1);
+        off[b] = (unsigned)((y * W + x) * C);
+        raw[b][0] = ld16(base + off[b]);
+    }
+    if (s.mode == RD_SRC_BNBWD) {
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            if (b >= nit) break;
+            raw[b][1] = ld16(base2 + off[b]);
+        }
+    }
+}
+
+template <typename T, int NIT>
+__device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, const ItemGeom<NIT>& ig,
+                                           int H, int W, int yh, int xh, uint4* s_in, int nit = NIT) {
+    constexpr int S = Slot<T>::N;
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) {
+        if (b >= nit) break;
+        if (ig.lds[b] < 0) continue;
+        const int y = yh + ig.py[b], x = xh + ig.px[b];
+        const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        uint4 u = in ? raw[b][0] : make_uint4(0, 0, 0, 0);
+        if (s.mode != RD_SRC_RAW) {
+            float v[S];
+            Slot<T>::unpack(raw[b][0], v);
+            if (s.mode == RD_SRC_AFF) {
+#pragma unroll
+                for (int e = 0; e < S; ++e) v[e] = v[e] * k.sc[e] + k.sh[e];
+            } else if (s.mode == RD_SRC_AFFACT) {
+#pragma unroll
+                for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * k.sc[e] + k.sh[e], s.slope);
+            } else {
+                float zz[S];
+                Slot<T>::unpack(raw[b][1], zz);
+#pragma unroll
+                for (int e = 0; e < S; ++e) v[e] = k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e];
+            }
+            u = in ? Slot<T>::pack(v) : make_uint4(0, 0, 0, 0);
+        }
+        s_in[ig.lds[b]] = u;
+    }
+}
+
+
+}  // namespace
+

@@ -1,0 +1,654 @@
+// wgrad.hip -- weight-gradient kernels (K = pixels): generic fp32/bf16, bf16 with transposed LDS tiles, and the
+// 16x16x32-MFMA kernel for 16-channel layers; deterministic two-stage split reduction.
+#include "conv_device.h"
+#include "conv_dispatch.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ wgrad kernel
+// dW[tap][n][c] = sum over pixels of dz[p][n] * a[p + tap][c];  M = n (Cout), N = c (Cin), K = pixels.
+// A workgroup owns a (MB*32) x (NB*32) x TAPS block of dW and walks pixel tiles with stride gridDim.x;
+// its 4 waves are MB*NB output blocks x KS = 4/(MB*NB) pixel-row splits.  Each wave stores its partial
+// block; a second kernel reduces the splits in a fixed order (deterministic, no atomics).
+template <typename T, int TAPS, int MB, int NB>
+__global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+    constexpr int S = Slot<T>::N;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int CA = NB * 32, CZ = MB * 32;
+    constexpr int KS = 4 / (MB * NB);
+    constexpr int ROWS = TH / KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* s_a = reinterpret_cast<T*>(smem);                   // [PH*PW][CA]
+    T* s_z = s_a + PH * PW * CA;                           // [TH*TW][CZ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int kq = wave / (MB * NB), blk = wave % (MB * NB);
+    const int mb = blk / NB, nb = blk % NB;
+    const int nbase = blockIdx.y * CZ, cbase = blockIdx.z * CA;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int H = p.H, W = p.W;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    SlotCtx<T> ctx_a, ctx_z;
+    int g_ctx = -1;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int n = tile / (tiles_x * tiles_y);
+        const int trem = tile - n * tiles_x * tiles_y;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        const int g = group_of(gm, n);
+        __syncthreads();
+        if (g != g_ctx) {                                  // BN coefficients depend on the image's group only
+            slot_ctx<T>(ctx_a, p.a, p.na, p.Cin, g, cbase + (tid % (CA / S)) * S);
+            slot_ctx<T>(ctx_z, &p.dz, 1, p.Cout, g, nbase + (tid % (CZ / S)) * S);
+            g_ctx = g;
+        }
+        {
+            const int s = tid % (CA / S);                  // constant per thread: 256 % (CA/S) == 0
+            const SlotCtx<T>& ctx = ctx_a;
+            auto map = [&](int idx, int& y, int& x) -> bool {
+                const int pix = idx / (CA / S);
+                const int py = pix / PW, px = pix - py * PW;
+                y = y0 - HALO + py;
+                x = x0 - HALO + px;
+                return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            };
+            auto store = [&](int idx, const uint4& u) {
+                const int pix = idx / (CA / S);
+                *reinterpret_cast<uint4*>(s_a + pix * CA + s * S) = u;
+            };
+            tile_fill<T>(p.a, ctx, n, H, W, tid, PH * PW * (CA / S), map, store);
+        }
+        {
+            const int s = tid % (CZ / S);
+            const SlotCtx<T>& ctx = ctx_z;
+            auto map = [&](int idx, int& y, int& x) -> bool {
+                const int pix = idx / (CZ / S);
+                const int py = pix / TW, px = pix - py * TW;
+                y = y0 + py;
+                x = x0 + px;
+                return y < H && x < W;
+            };
+            auto store = [&](int idx, const uint4& u) {
+                const int pix = idx / (CZ / S);
+                *reinterpret_cast<uint4*>(s_z + pix * CZ + s * S) = u;
+            };
+            tile_fill<T>(&p.dz, ctx, n, H, W, tid, TH * TW * (CZ / S), map, store);
+        }
+        __syncthreads();
+        if constexpr (sizeof(T) == 2) {
+            const unsigned short* za = reinterpret_cast<const unsigned short*>(s_z) + mb * 32 + li;
+            const unsigned short* aa = reinterpret_cast<const unsigned short*>(s_a) + nb * 32 + li;
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int row = kq + rr * KS;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int px0 = ks * 16 + 8 * h;                 // this lane-half's 8 pixels (k = 8h+e)
+                    unsigned zp[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned lo = za[(row * TW + px0 + 2 * e) * CZ];
+                        const unsigned hi = za[(row * TW + px0 + 2 * e + 1) * CZ];
+                        zp[e] = lo | (hi << 16);
+                    }
+                    const bf16x8 afrag = __builtin_bit_cast(bf16x8, make_uint4(zp[0], zp[1], zp[2], zp[3]));
+#pragma unroll
+                    for (int kh = 0; kh < (TAPS == 9 ? 3 : 1); ++kh) {
+                        const int base = (row + kh) * PW + px0;     // halo coords: input pixel = output pixel + tap
+                        if constexpr (TAPS == 9) {
+                            unsigned v[10];
+#pragma unroll
+                            for (int e = 0; e < 10; ++e) v[e] = aa[(base + e) * CA];
+                            unsigned P[5], Q[4];
+#pragma unroll
+                            for (int e = 0; e < 5; ++e) P[e] = v[2 * e] | (v[2 * e + 1] << 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) Q[e] = v[2 * e + 1] | (v[2 * e + 2] << 16);
+                            acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                afrag, __builtin_bit_cast(bf16x8, make_uint4(P[0], P[1], P[2], P[3])), acc[kh * 3 + 0], 0, 0, 0);
+                            acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                afrag, __builtin_bit_cast(bf16x8, make_uint4(Q[0], Q[1], Q[2], Q[3])), acc[kh * 3 + 1], 0, 0, 0);
+                            acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                afrag, __builtin_bit_cast(bf16x8, make_uint4(P[1], P[2], P[3], P[4])), acc[kh * 3 + 2], 0, 0, 0);
+                        } else {
+                            unsigned P[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                P[e] = (unsigned)aa[(base + 2 * e) * CA] | ((unsigned)aa[(base + 2 * e + 1) * CA] << 16);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                afrag, __builtin_bit_cast(bf16x8, make_uint4(P[0], P[1], P[2], P[3])), acc[0], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+            const float* za = reinterpret_cast<const float*>(s_z) + mb * 32 + li;
+            const float* aa = reinterpret_cast<const float*>(s_a) + nb * 32 + li;
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int row = kq + rr * KS;
+#pragma unroll 4
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    const int px = 2 * s2 + h;                       // k = h
+                    const float av = za[(row * TW + px) * CZ];
+#pragma unroll
+                    for (int tap = 0; tap < TAPS; ++tap) {
+                        const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+                        const float bv = aa[((row + kh) * PW + px + kw) * CA];
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // waves that split the pixel rows of the tiles (kq > 0) fold their accumulators into wave kq == 0
+    // through LDS, one tap per round; then one partial block per workgroup: partial[split][tap][n][c]
+    if constexpr (KS > 1) {
+        float* s_acc = reinterpret_cast<float*>(smem);     // [(KS-1)][MB*NB][16][64]
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            __syncthreads();
+            if (kq > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_acc[(((kq - 1) * (MB * NB) + blk) * 16 + r) * 64 + lane] = acc[tap][r];
+            }
+            __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int k2 = 0; k2 < KS - 1; ++k2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tap][r] += s_acc[((k2 * (MB * NB) + blk) * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (kq == 0) {
+        float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int ccol = cbase + nb * 32 + li;
+                out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------ bf16 wgrad, transposed LDS tiles
+// Same decomposition as wgrad_kernel, but the tiles are stored [channel][pixel] so that the K (pixel) run of
+// both MFMA operands is contiguous: the dz fragment is one ds_read_b128, the three horizontal taps of a row
+// come from ONE 10-pixel window (ds_read_b128 + ds_read_b32; the odd tap is 4 v_alignbit), instead of
+// 38 ds_read_u16 + packing per k-step.  Channel rows are padded to 16*odd bytes mod 256 so the 16-lane
+// groups of a b128 read hit 64 distinct banks.  Each wave fills whole channel slots (lanes run over
+// pixels), so the transposing ds_write_b16 of a wave land on consecutive pixels of one row.
+template <int TAPS, int MB, int NB>
+__global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+    typedef bf16_t T;
+    constexpr int S = 8;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int PWL = (TAPS == 9) ? 40 : 32;             // LDS row pitch in pixels (16-byte aligned windows)
+    constexpr int AP = PH * PWL + 8;                        // elements per channel row: 816 B (3x3) / 528 B (1x1)
+    constexpr int ZP = TH * TW + 8;                         // 528 B
+    constexpr int CA = NB * 32, CZ = MB * 32;
+    constexpr int KS = 4 / (MB * NB);
+    constexpr int ROWS = TH / KS;
+    constexpr int NSA = CA / S, NSZ = CZ / S;               // channel slots per tile
+    constexpr int SPA = (NSA + 3) / 4, SPZ = (NSZ + 3) / 4; // slots per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned short* s_a = reinterpret_cast<unsigned short*>(smem);     // [CA][AP]
+    unsigned short* s_z = s_a + CA * AP;                                // [CZ][ZP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int kq = wave / (MB * NB), blk = wave % (MB * NB);
+    const int mb = blk / NB, nb = blk % NB;
+    const int nbase = blockIdx.y * CZ, cbase = blockIdx.z * CA;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int H = p.H, W = p.W;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    SlotCtx<T> ctx_a[SPA], ctx_z[SPZ];
+    int g_ctx = -1;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int n = tile / (tiles_x * tiles_y);
+        const int trem = tile - n * tiles_x * tiles_y;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        const int g = group_of(gm, n);
+        if (g != g_ctx) {
+#pragma unroll
+            for (int q = 0; q < SPA; ++q) slot_ctx<T>(ctx_a[q], p.a, p.na, p.Cin, g, cbase + (wave + 4 * q) * S);
+#pragma unroll
+            for (int q = 0; q < SPZ; ++q) slot_ctx<T>(ctx_z[q], &p.dz, 1, p.Cout, g, nbase + (wave + 4 * q) * S);
+            g_ctx = g;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SPA; ++q) {
+            const int sl = wave + 4 * q;
+            if (sl < NSA) {
+                auto map = [&](int pix, int& y, int& x) -> bool {
+                    const int py = pix / PW, px = pix - py * PW;
+                    y = y0 - HALO + py;
+                    x = x0 - HALO + px;
+                    return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                };
+                auto store = [&](int pix, const uint4& u) {
+                    const int py = pix / PW, px = pix - py * PW;
+                    unsigned short* d = s_a + (sl * S) * AP + py * PWL + px;
+                    d[0 * AP] = (unsigned short)(u.x & 0xffff); d[1 * AP] = (unsigned short)(u.x >> 16);
+                    d[2 * AP] = (unsigned short)(u.y & 0xffff); d[3 * AP] = (unsigned short)(u.y >> 16);
+                    d[4 * AP] = (unsigned short)(u.z & 0xffff); d[5 * AP] = (unsigned short)(u.z >> 16);
+                    d[6 * AP] = (unsigned short)(u.w & 0xffff); d[7 * AP] = (unsigned short)(u.w >> 16);
+                };
+                tile_fill<T, 64>(p.a, ctx_a[q], n, H, W, lane, PH * PW, map, store);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < SPZ; ++q) {
+            const int sl = wave + 4 * q;
+            if (sl < NSZ) {
+                auto map = [&](int pix, int& y, int& x) -> bool {
+                    const int py = pix / TW, px = pix - py * TW;
+                    y = y0 + py;
+                    x = x0 + px;
+                    return y < H && x < W;
+                };
+                auto store = [&](int pix, const uint4& u) {
+                    unsigned short* d = s_z + (sl * S) * ZP + pix;
+                    d[0 * ZP] = (unsigned short)(u.x & 0xffff); d[1 * ZP] = (unsigned short)(u.x >> 16);
+                    d[2 * ZP] = (unsigned short)(u.y & 0xffff); d[3 * ZP] = (unsigned short)(u.y >> 16);
+                    d[4 * ZP] = (unsigned short)(u.z & 0xffff); d[5 * ZP] = (unsigned short)(u.z >> 16);
+                    d[6 * ZP] = (unsigned short)(u.w & 0xffff); d[7 * ZP] = (unsigned short)(u.w >> 16);
+                };
+                tile_fill<T, 64>(&p.dz, ctx_z[q], n, H, W, lane, TH * TW, map, store);
+            }
+        }
+        __syncthreads();
+        const unsigned short* zr = s_z + (mb * 32 + li) * ZP;
+        const unsigned short* ar = s_a + (nb * 32 + li) * AP;
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int row = kq + rr * KS;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int px0 = ks * 16 + 8 * h;                  // this lane-half's 8 pixels (k = 8h+e)
+                const bf16x8 afrag = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(zr + row * TW + px0));
+#pragma unroll
+                for (int kh = 0; kh < (TAPS == 9 ? 3 : 1); ++kh) {
+                    const unsigned short* wp = ar + (row + kh) * PWL + px0;     // halo coords: input = output + tap
+                    const uint4 dq = *reinterpret_cast<const uint4*>(wp);
+                    if constexpr (TAPS == 9) {
+                        const unsigned d4 = *reinterpret_cast<const unsigned*>(wp + 8);
+                        const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(dq.y, dq.x, 16), __builtin_amdgcn_alignbit(dq.z, dq.y, 16),
+                                                    __builtin_amdgcn_alignbit(dq.w, dq.z, 16), __builtin_amdgcn_alignbit(d4, dq.w, 16));
+                        const uint4 m2 = make_uint4(dq.y, dq.z, dq.w, d4);
+                        acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kh * 3 + 0], 0, 0, 0);
+                        acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kh * 3 + 1], 0, 0, 0);
+                        acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kh * 3 + 2], 0, 0, 0);
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[0], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (KS > 1) {
+        float* s_acc = reinterpret_cast<float*>(smem);     // [(KS-1)][MB*NB][16][64]
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            __syncthreads();
+            if (kq > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_acc[(((kq - 1) * (MB * NB) + blk) * 16 + r) * 64 + lane] = acc[tap][r];
+            }
+            __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int k2 = 0; k2 < KS - 1; ++k2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tap][r] += s_acc[((k2 * (MB * NB) + blk) * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (kq == 0) {
+        float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int ccol = cbase + nb * 32 + li;
+                out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------ bf16 wgrad, <= 32 channels
+// The HBM-bound layers (16/32 channels at 400x400 / 200x200): v_mfma_f32_16x16x32_bf16 with K = the 32 pixels
+// of one tile row, 16x16 channel blocks (no padding of 16-channel layers to 32), 4 accumulator VGPRs per tap
+// (36 for a 3x3) instead of 144 -> 4 workgroups per CU keep enough loads in flight.  MB x NB 16-channel
+// blocks per workgroup; the 4 waves are MB*NB blocks x KS = 4/(MB*NB) row splits.
+template <int TAPS, int MB, int NB>
+__global__ __launch_bounds__(256, 3) void wgrad_c16_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+    typedef bf16_t T;
+    typedef __attribute__((ext_vector_type(4))) float f32x4v;
+    constexpr int S = 8;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int PWL = (TAPS == 9) ? 40 : 32;
+    constexpr int AP = PH * PWL + 8, ZP = TH * TW + 8;
+    constexpr int CA = NB * 16, CZ = MB * 16;
+    constexpr int KS = 4 / (MB * NB);
+    constexpr int ROWS = TH / KS;
+    constexpr int NSA = CA / S, NSZ = CZ / S, NJOB = NSA + NSZ;      // fill jobs: one 8-channel slot each
+    constexpr int JPW = (NJOB + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned short* s_a = reinterpret_cast<unsigned short*>(smem);     // [CA][AP]
+    unsigned short* s_z = s_a + CA * AP;                                // [CZ][ZP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int kq = wave / (MB * NB), blk = wave % (MB * NB);
+    const int mb = blk / NB, nb = blk % NB;
+    const int nbase = blockIdx.y * CZ, cbase = blockIdx.z * CA;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int H = p.H, W = p.W;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+
+    f32x4v acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    SlotCtx<T> ctx[JPW];
+    int g_ctx = -1;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int n = tile / (tiles_x * tiles_y);
+        const int trem = tile - n * tiles_x * tiles_y;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        const int g = group_of(gm, n);
+        if (g != g_ctx) {
+#pragma unroll
+            for (int q = 0; q < JPW; ++q) {
+                const int job = wave + 4 * q;
+                if (job < NSA) slot_ctx<T>(ctx[q], p.a, p.na, p.Cin, g, cbase + job * S);
+                else if (job < NJOB) slot_ctx<T>(ctx[q], &p.dz, 1, p.Cout, g, nbase + (job - NSA) * S);
+            }
+            g_ctx = g;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < JPW; ++q) {
+            const int job = wave + 4 * q;
+            if (job < NSA) {
+                auto map = [&](int pix, int& y, int& x) -> bool {
+                    const int py = pix / PW, px = pix - py * PW;
+                    y = y0 - HALO + py;
+                    x = x0 - HALO + px;
+                    return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                };
+                auto store = [&](int pix, const uint4& u) {
+                    const int py = pix / PW, px = pix - py * PW;
+                    unsigned short* d = s_a + (job * S) * AP + py * PWL + px;
+                    d[0 * AP] = (unsigned short)(u.x & 0xffff); d[1 * AP] = (unsigned short)(u.x >> 16);
+                    d[2 * AP] = (unsigned short)(u.y & 0xffff); d[3 * AP] = (unsigned short)(u.y >> 16);
+                    d[4 * AP] = (unsigned short)(u.z & 0xffff); d[5 * AP] = (unsigned short)(u.z >> 16);
+                    d[6 * AP] = (unsigned short)(u.w & 0xffff); d[7 * AP] = (unsigned short)(u.w >> 16);
+                };
+                tile_fill<T, 64>(p.a, ctx[q], n, H, W, lane, PH * PW, map, store);
+            } else if (job < NJOB) {
+                const int sl = job - NSA;
+                auto map = [&](int pix, int& y, int& x) -> bool {
+                    const int py = pix / TW, px = pix - py * TW;
+                    y = y0 + py;
+                    x = x0 + px;
+                    return y < H && x < W;
+                };
+                auto store = [&](int pix, const uint4& u) {
+                    unsigned short* d = s_z + (sl * S) * ZP + pix;
+                    d[0 * ZP] = (unsigned short)(u.x & 0xffff); d[1 * ZP] = (unsigned short)(u.x >> 16);
+                    d[2 * ZP] = (unsigned short)(u.y & 0xffff); d[3 * ZP] = (unsigned short)(u.y >> 16);
+                    d[4 * ZP] = (unsigned short)(u.z & 0xffff); d[5 * ZP] = (unsigned short)(u.z >> 16);
+                    d[6 * ZP] = (unsigned short)(u.w & 0xffff); d[7 * ZP] = (unsigned short)(u.w >> 16);
+                };
+                tile_fill<T, 64>(&p.dz, ctx[q], n, H, W, lane, TH * TW, map, store);
+            }
+        }
+        __syncthreads();
+        const unsigned short* zr = s_z + (mb * 16 + li) * ZP + kg * 8;
+        const unsigned short* ar = s_a + (nb * 16 + li) * AP + kg * 8;
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int row = kq + rr * KS;
+            const bf16x8 afrag = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(zr + row * TW));
+#pragma unroll
+            for (int kh = 0; kh < (TAPS == 9 ? 3 : 1); ++kh) {
+                const unsigned short* wp = ar + (row + kh) * PWL;
+                const uint4 dq = *reinterpret_cast<const uint4*>(wp);
+                if constexpr (TAPS == 9) {
+                    const unsigned d4 = *reinterpret_cast<const unsigned*>(wp + 8);
+                    const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(dq.y, dq.x, 16), __builtin_amdgcn_alignbit(dq.z, dq.y, 16),
+                                                __builtin_amdgcn_alignbit(dq.w, dq.z, 16), __builtin_amdgcn_alignbit(d4, dq.w, 16));
+                    const uint4 m2 = make_uint4(dq.y, dq.z, dq.w, d4);
+                    acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kh * 3 + 0], 0, 0, 0);
+                    acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kh * 3 + 1], 0, 0, 0);
+                    acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kh * 3 + 2], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[0], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if constexpr (KS > 1) {
+        float* s_acc = reinterpret_cast<float*>(smem);     // [(KS-1)][MB*NB][TAPS][4][64]
+        __syncthreads();
+        if (kq > 0) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_acc[((((kq - 1) * (MB * NB) + blk) * TAPS + tap) * 4 + r) * 64 + lane] = acc[tap][r];
+        }
+        __syncthreads();
+        if (kq == 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < KS - 1; ++k2)
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tap][r] += s_acc[(((k2 * (MB * NB) + blk) * TAPS + tap) * 4 + r) * 64 + lane];
+        }
+    }
+    if (kq == 0) {
+        // D layout of the 16x16 MFMA: column (N, cin) = lane&15, row (M, cout) = 4*(lane>>4) + r
+        float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nrow = nbase + mb * 16 + 4 * kg + r;
+                const int ccol = cbase + nb * 16 + li;
+                out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
+            }
+    }
+}
+
+// block = 32 outputs x 8 split lanes: each thread sums every 8th split, LDS folds the 8 lanes in a fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dW, int nsplit, int taps, int Cout,
+                                                           int Cin, int CoutPadW, int CinPadW, float beta) {
+    __shared__ float s[8][32];
+    const int total = taps * Cout * Cin;
+    const int o = threadIdx.x & 31, ql = threadIdx.x >> 5;
+    const size_t stride = (size_t)taps * CoutPadW * CinPadW;
+    for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
+        const int i = base + o;
+        float acc = 0.f;
+        int c = 0, n = 0, tap = 0;
+        if (i < total) {
+            c = i % Cin; n = (i / Cin) % Cout; tap = i / (Cin * Cout);
+            const float* src = partial + ((size_t)tap * CoutPadW + n) * CinPadW + c;
+            for (int k = ql; k < nsplit; k += 8) acc += src[k * stride];
+        }
+        s[ql][o] = acc;
+        __syncthreads();
+        if (ql == 0 && i < total) {
+            const float v = ((s[0][o] + s[1][o]) + (s[2][o] + s[3][o])) + ((s[4][o] + s[5][o]) + (s[6][o] + s[7][o]));
+            float* d = dW + ((size_t)n * Cin + c) * taps + tap;
+            *d = (beta != 0.f ? beta * *d : 0.f) + v;
+        }
+        __syncthreads();
+    }
+}
+
+struct WgradGeom {
+    int MB, NB, KS, CoutPadW, CinPadW, gx, total_tiles, nsplit;
+    bool c16;
+};
+
+template <typename T>
+WgradGeom wgrad_geom(const rd_wgrad_t& p) {
+    WgradGeom g;
+    g.c16 = false;
+    // 16-channel blocks only where the kernel stays spill-free at 3 workgroups/CU (one block per workgroup)
+    if (sizeof(T) == 2 && p.Cout <= 16 && p.Cin <= 16) {
+        g.c16 = true;
+        g.MB = p.Cout > 16 ? 2 : 1;
+        g.NB = p.Cin > 16 ? 2 : 1;
+        g.KS = 4 / (g.MB * g.NB);
+        g.CoutPadW = g.MB * 16;
+        g.CinPadW = g.NB * 16;
+        g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+        int gx = 1024;                                      // 4 workgroups per CU
+        if (gx > g.total_tiles) gx = g.total_tiles;
+        g.gx = gx < 1 ? 1 : gx;
+        g.nsplit = g.gx;
+        return g;
+    }
+    const int cout32 = (p.Cout + 31) / 32, cin32 = (p.Cin + 31) / 32;
+    // fp32 keeps 32x32 blocks (LDS budget); bf16 uses 64-wide tiles where the layer has them
+    g.MB = (sizeof(T) == 2 && cout32 % 2 == 0) ? 2 : 1;
+    g.NB = (sizeof(T) == 2 && cin32 % 2 == 0) ? 2 : 1;
+    g.KS = 4 / (g.MB * g.NB);
+    g.CoutPadW = cout32 * 32;
+    g.CinPadW = cin32 * 32;
+    g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    const int pairs = (g.CoutPadW / (g.MB * 32)) * (g.CinPadW / (g.NB * 32));
+    // these kernels hold 144 accumulator registers per lane -> one workgroup per CU is resident: launching more
+    // workgroups than CUs only multiplies the partial-sum traffic (147 KB per workgroup for a 64x64 tile)
+    int gx = (256 + pairs - 1) / pairs;
+    if (gx > g.total_tiles) gx = g.total_tiles;
+    if (gx < 1) gx = 1;
+    g.gx = gx;
+    g.nsplit = gx;
+    return g;
+}
+
+template <typename T, int TAPS, int MB, int NB>
+int launch_wgrad(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    size_t lds = (size_t)(PH * PW * NB * 32 + TH * TW * MB * 32) * sizeof(T);
+    const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * 16 * 64 * sizeof(float);
+    if (lds < lds_red) lds = lds_red;
+    dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TAPS, MB, NB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<T, TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    return (int)hipGetLastError();
+}
+
+template <int TAPS, int MB, int NB>
+int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO;
+    constexpr int PWL = (TAPS == 9) ? 40 : 32;
+    size_t lds = (size_t)(NB * 16 * (PH * PWL + 8) + MB * 16 * (TH * TW + 8)) * 2;
+    const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * TAPS * 4 * 64 * sizeof(float);
+    if (lds < lds_red) lds = lds_red;
+    dim3 grid(g.gx, g.CoutPadW / (MB * 16), g.CinPadW / (NB * 16));
+    hipLaunchKernelGGL((wgrad_c16_kernel<TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    return (int)hipGetLastError();
+}
+
+template <int TAPS, int MB, int NB>
+int launch_wgrad_t(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO;
+    constexpr int PWL = (TAPS == 9) ? 40 : 32;
+    size_t lds = (size_t)(NB * 32 * (PH * PWL + 8) + MB * 32 * (TH * TW + 8)) * 2;
+    const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * 16 * 64 * sizeof(float);
+    if (lds < lds_red) lds = lds_red;
+    dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int dispatch_wgrad(const rd_wgrad_t& p, hipStream_t st) {
+    const WgradGeom g = wgrad_geom<T>(p);
+    int e;
+    if (g.c16) {
+#define RD_WGC(TAPS_)                                                                \
+    if (g.MB == 2 && g.NB == 2) e = launch_wgrad_c16<TAPS_, 2, 2>(p, g, st);         \
+    else if (g.MB == 2) e = launch_wgrad_c16<TAPS_, 2, 1>(p, g, st);                 \
+    else if (g.NB == 2) e = launch_wgrad_c16<TAPS_, 1, 2>(p, g, st);                 \
+    else e = launch_wgrad_c16<TAPS_, 1, 1>(p, g, st);
+        if (p.taps == 9) { RD_WGC(9) } else { RD_WGC(1) }
+#undef RD_WGC
+    } else if constexpr (sizeof(T) == 2) {
+#define RD_WGT(TAPS_)                                                                \
+    if (g.MB == 2 && g.NB == 2) e = launch_wgrad_t<TAPS_, 2, 2>(p, g, st);           \
+    else if (g.MB == 2) e = launch_wgrad_t<TAPS_, 2, 1>(p, g, st);                   \
+    else if (g.NB == 2) e = launch_wgrad_t<TAPS_, 1, 2>(p, g, st);                   \
+    else e = launch_wgrad_t<TAPS_, 1, 1>(p, g, st);
+        if (p.taps == 9) { RD_WGT(9) } else { RD_WGT(1) }
+#undef RD_WGT
+    } else {
+#define RD_WG(TAPS_)                                                                 \
+    if (g.MB == 2 && g.NB == 2) e = launch_wgrad<T, TAPS_, 2, 2>(p, g, st);          \
+    else if (g.MB == 2) e = launch_wgrad<T, TAPS_, 2, 1>(p, g, st);                  \
+    else if (g.NB == 2) e = launch_wgrad<T, TAPS_, 1, 2>(p, g, st);                  \
+    else e = launch_wgrad<T, TAPS_, 1, 1>(p, g, st);
+        if (p.taps == 9) { RD_WG(9) } else { RD_WG(1) }
+#undef RD_WG
+    }
+    if (e) return e;
+    const int total = p.taps * p.Cout * p.Cin;
+    int blocks = (total + 31) / 32;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
+                       g.CoutPadW, g.CinPadW, p.beta);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int rd_wgrad_dispatch(const rd_wgrad_t& p, int dtype, hipStream_t st) {
+    return dtype == RD_BF16 ? dispatch_wgrad<bf16_t>(p, st) : dispatch_wgrad<float>(p, st);
+}
+
+int64_t rd_wgrad_ws_bytes(const rd_wgrad_t& p, int dtype) {
+    const WgradGeom g = dtype == RD_BF16 ? wgrad_geom<bf16_t>(p) : wgrad_geom<float>(p);
+    return (int64_t)g.nsplit * p.taps * g.CoutPadW * g.CinPadW * (int64_t)sizeof(float);
+}
+
