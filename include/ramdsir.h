@@ -193,7 +193,8 @@ int rd_up_bwd(const void* g, const void* t, void* dt, const float* P, const floa
               int w, int C, int G, const int32_t* gstart_host, int dtype, void* stream);
 
 /* layout / materialisation at the module boundary (torch NCHW fp32 <-> NHWC dtype) */
-int rd_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int N, int C, int H, int W, int dtype, void* stream);
+/* cstride: elements between pixels of y (0 or C: dense; larger: zero-initialised pad channels are left untouched) */
+int rd_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int N, int C, int H, int W, int cstride, int dtype, void* stream);
 /* y_nchw = act(z*scale+shift)  (act: 0 none, 1 activation with `slope`); scale==NULL -> identity */
 int rd_nhwc_to_nchw(const void* z_nhwc, float* y_nchw, const float* scale, const float* shift, int act, float slope,
                     int N, int C, int H, int W, int G, const int32_t* gstart_host, int dtype, void* stream);
@@ -202,8 +203,8 @@ int rd_grad_in(const float* dy_nchw, const void* z_nhwc, void* g_nhwc, const flo
                float* bstats, int act, float slope, int accumulate, int N, int C, int H, int W, int G,
                const int32_t* gstart_host, int dtype, void* stream);
 /* column sums of an NHWC tensor: out[c] (+)= sum over pixels (bias gradient of the two out1 convs) */
-int rd_colsum(const void* x_nhwc, float* out, float* partial_ws /* >= 8192 floats */, int64_t npix, int C, float beta,
-              int dtype, void* stream);
+int rd_colsum(const void* x_nhwc, float* out, float* partial_ws /* >= 8192 floats */, int64_t npix, int C, int cstride /* 0: C */,
+              float beta, int dtype, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------------
@@ -224,7 +225,7 @@ typedef struct {
     int32_t kind;           /* 0 fundus (sigmoid/BCE/dice), 1 prostate (softmax/CE/dice_multi) */
     int32_t consistency;    /* 0 none, 1 kd, 2 mse */
     float cons_weight;      /* 0.5 (train.py:283) */
-    int32_t pad_;
+    int32_t dlogits_cstride; /* elements between pixels of dlogits (0 or K: dense); the pad is never written */
 } rd_seg_loss_t;
 int64_t rd_seg_loss_workspace(const rd_seg_loss_t* p);
 int rd_seg_loss(const rd_seg_loss_t* p, int dtype, void* stream);
@@ -232,8 +233,8 @@ int rd_seg_loss(const rd_seg_loss_t* p, int dtype, void* stream);
 /* Restoration loss (train.py:265-276): per domain group d, MSELoss(tanh(rec_logits[d]), img[d]);
  * loss += lambda_rec * mse_d.  rec_logits / target / dlogits: NHWC [B][H][W][C].  mse_out[G] device. */
 int rd_rec_loss(const void* rec_logits, const void* target, void* dlogits, float* mse_out, float* partial_ws,
-                int B, int H, int W, int C, int G, const int32_t* gstart_host, float lambda_rec, int dtype,
-                void* stream);
+                int B, int H, int W, int C, int target_cstride /* 0: C */, int dlogits_cstride /* 0: C */, int G,
+                const int32_t* gstart_host, float lambda_rec, int dtype, void* stream);
 int64_t rd_rec_loss_workspace(int B, int H, int W, int C);
 
 /* ------------------------------------------------------------------------------------------------
@@ -273,7 +274,8 @@ typedef struct {
     const float* tw_w; const float* tw_h;
     int32_t B, H, W, C, b;
     float clip_lo, clip_hi, scale, offset;
-    int32_t pad_;
+    int32_t out_cstride;        /* elements between pixels of out_img / out_freq (0 or 3: dense; e.g. 8: padded so the
+                                 * first conv reads whole 16-byte channel vectors; the pad is never written) */
 } rd_ram_t;
 int64_t rd_ram_workspace(int B, int H, int W, int b);
 int rd_ram_mix(const rd_ram_t* p, int dtype, void* stream);

@@ -200,13 +200,13 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const T* g2, const T* t, T*
 }
 
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int N, int C, int H, int W) {
+__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int N, int C, int H, int W, int Cs) {
     const size_t total = (size_t)N * C * H * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % C;
         const size_t pix = i / C;
         const int xw = pix % W, yh = (pix / W) % H, n = pix / ((size_t)W * H);
-        y[i] = from_f<T>(x[(((size_t)n * C + c) * H + yh) * W + xw]);
+        y[pix * Cs + c] = from_f<T>(x[(((size_t)n * C + c) * H + yh) * W + xw]);
     }
 }
 
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float* dy, const T* 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial, int64_t npix, int C) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial, int64_t npix, int C, int Cs) {
     // C <= 8; partial[block][C]
     float acc[8];
 #pragma unroll
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* partial,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x)
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            if (c < C) acc[c] += to_f<T>(x[i * C + c]);
+            if (c < C) acc[c] += to_f<T>(x[i * Cs + c]);
     __shared__ float s[4][8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -352,12 +352,14 @@ int rd_up_bwd(const void* g, const void* t, void* dt, const float* P, const floa
     return (int)hipGetLastError();
 }
 
-int rd_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int dtype, void* stream) {
+int rd_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int cstride, int dtype, void* stream) {
+    const int Cs = cstride > 0 ? cstride : C;
+    if (Cs < C) return -1;
     const size_t total = (size_t)N * C * H * W;
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, N, C, H, W);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, N, C, H, W, Cs);
     else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (float*)y, N, C, H, W);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (float*)y, N, C, H, W, Cs);
     return (int)hipGetLastError();
 }
 
@@ -388,13 +390,14 @@ int rd_grad_in(const float* dy, const void* z, void* g, const float* scale, cons
     return (int)hipGetLastError();
 }
 
-int rd_colsum(const void* x, float* out, float* partial_ws, int64_t npix, int C, float beta, int dtype, void* stream) {
+int rd_colsum(const void* x, float* out, float* partial_ws, int64_t npix, int C, int cstride, float beta, int dtype, void* stream) {
+    const int Cs = cstride > 0 ? cstride : C;
     if (C > 8) return -2;
     const int nb = grid_for((size_t)npix, 256 * 4, 1024);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial_ws, npix, C);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial_ws, npix, C, Cs);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, partial_ws, npix, C);
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, partial_ws, npix, C, Cs);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial_ws, out, nb, C, beta);
     return (int)hipGetLastError();
 }

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(1024) void seg_loss_final_kernel(const rd_seg_loss_
 
 template <typename T>
 __global__ __launch_bounds__(256) void seg_loss_grad_kernel(const rd_seg_loss_t p, int nblocks) {
-    const int HW = p.H * p.W, K = p.K;
+    const int HW = p.H * p.W, K = p.K, Ks = p.dlogits_cstride > 0 ? p.dlogits_cstride : p.K;
     const int npix = p.B * HW;
     const T* lg = reinterpret_cast<const T*>(p.logits);
     T* dl = reinterpret_cast<T*>(p.dlogits);
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void seg_loss_grad_kernel(const rd_seg_loss_t 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
         const int n = i / HW, pix = i - n * HW;
         const size_t o1 = (size_t)i * K, o2 = ((size_t)(n + p.B) * HW + pix) * K;
+        const size_t e1 = (size_t)i * Ks, e2 = ((size_t)(n + p.B) * HW + pix) * Ks;
         if (p.kind == 0) {
             const float nel = (float)p.B * K * HW;
             const float N1 = 2.f * sm[2] + eps, D1 = sm[3] + sm[6] + eps;
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(256) void seg_loss_grad_kernel(const rd_seg_loss_t 
                     g1 += w * (-2.f * (p2 - p1)) / nel;
                     g2 += w * (2.f * (p2 - p1)) / nel;
                 }
-                dl[o1 + k] = from_f<T>(g1 * p1 * (1.f - p1));
-                dl[o2 + k] = from_f<T>(g2 * p2 * (1.f - p2));
+                dl[e1 + k] = from_f<T>(g1 * p1 * (1.f - p1));
+                dl[e2 + k] = from_f<T>(g2 * p2 * (1.f - p2));
             }
         } else {
             const float npx = (float)p.B * HW, nel = npx * K;
@@ -197,8 +198,8 @@ __global__ __launch_bounds__(256) void seg_loss_grad_kernel(const rd_seg_loss_t 
             for (int k = 0; k < KMAX; ++k)
                 if (k < K) {
                     const float tk = (t == k) ? 1.f : 0.f;
-                    dl[o1 + k] = from_f<T>(a1[k] * (q1[k] - dot1) + (a1[k] - tk) / npx);
-                    dl[o2 + k] = from_f<T>(a2[k] * (q2[k] - dot2) + (a2[k] - tk) / npx);
+                    dl[e1 + k] = from_f<T>(a1[k] * (q1[k] - dot1) + (a1[k] - tk) / npx);
+                    dl[e2 + k] = from_f<T>(a2[k] * (q2[k] - dot2) + (a2[k] - tk) / npx);
                 }
         }
     }
@@ -207,16 +208,18 @@ __global__ __launch_bounds__(256) void seg_loss_grad_kernel(const rd_seg_loss_t 
 // ----------------------------------------------------------------------------------- restoration loss
 template <typename T>
 __global__ __launch_bounds__(256) void rec_loss_kernel(const T* lg, const T* tgt, T* dl, float* partial, int per_img,
-                                                       GroupMap gm, float lambda_rec) {
+                                                       GroupMap gm, float lambda_rec, int C, int Ts, int Ds) {
     const int n = blockIdx.y, g = group_of(gm, n);
     const float cnt = (float)(gm.gs[g + 1] - gm.gs[g]) * (float)per_img;
     const size_t base = (size_t)n * per_img;
     float acc = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_img; i += gridDim.x * blockDim.x) {
+        const int pix = i / C, c = i - pix * C;
+        const size_t px = (size_t)n * (per_img / C) + pix;
         const float r = tanhf(to_f<T>(lg[base + i]));
-        const float d = r - to_f<T>(tgt[base + i]);
+        const float d = r - to_f<T>(tgt[px * Ts + c]);
         acc += d * d;
-        dl[base + i] = from_f<T>(lambda_rec * 2.f * d / cnt * (1.f - r * r));
+        dl[px * Ds + c] = from_f<T>(lambda_rec * 2.f * d / cnt * (1.f - r * r));
     }
     __shared__ float s[4];
     const float v = wave_sum(acc);
@@ -306,19 +309,21 @@ int rd_seg_loss(const rd_seg_loss_t* p, int dtype, void* stream) {
 
 int64_t rd_rec_loss_workspace(int B, int H, int W, int C) { return (int64_t)B * rec_bx(H * W * C) * sizeof(float); }
 
-int rd_rec_loss(const void* lg, const void* tgt, void* dl, float* mse_out, float* partial_ws, int B, int H, int W, int C, int G,
-                const int32_t* gstart_host, float lambda_rec, int dtype, void* stream) {
+int rd_rec_loss(const void* lg, const void* tgt, void* dl, float* mse_out, float* partial_ws, int B, int H, int W, int C,
+                int target_cstride, int dlogits_cstride, int G, const int32_t* gstart_host, float lambda_rec, int dtype, void* stream) {
     if (G < 1 || G > RD_MAX_GROUPS) return -1;
+    const int Ts = target_cstride > 0 ? target_cstride : C, Ds = dlogits_cstride > 0 ? dlogits_cstride : C;
+    if (Ts < C || Ds < C) return -1;
     hipStream_t st = (hipStream_t)stream;
     const int per_img = H * W * C;
     const int bx = rec_bx(per_img);
     const GroupMap gm = host_gm2(G, gstart_host);
     if (dtype == RD_BF16)
         hipLaunchKernelGGL(rec_loss_kernel<bf16_t>, dim3(bx, B), dim3(256), 0, st, (const bf16_t*)lg, (const bf16_t*)tgt, (bf16_t*)dl,
-                           partial_ws, per_img, gm, lambda_rec);
+                           partial_ws, per_img, gm, lambda_rec, C, Ts, Ds);
     else
         hipLaunchKernelGGL(rec_loss_kernel<float>, dim3(bx, B), dim3(256), 0, st, (const float*)lg, (const float*)tgt, (float*)dl,
-                           partial_ws, per_img, gm, lambda_rec);
+                           partial_ws, per_img, gm, lambda_rec, C, Ts, Ds);
     hipLaunchKernelGGL(rec_loss_final_kernel, dim3(1), dim3(64), 0, st, partial_ws, mse_out, bx, per_img, gm);
     return (int)hipGetLastError();
 }

@@ -103,7 +103,7 @@ struct RamArgs {
     void* out_img; void* out_freq;
     float2* rowspec; float2* colout;
     const float2* tw_w; const float2* tw_h;
-    int B, H, W, b;
+    int B, H, W, b, cs;
     float clip_lo, clip_hi, scale, offset;
     FftPlan pw, ph;
 };
@@ -198,16 +198,16 @@ __global__ __launch_bounds__(256) void ram_row_inv_kernel(const RamArgs a) {
     const float2* r2 = buf + (2 + cur) * W;
     const float inv = 1.0f / ((float)H * (float)W);
     const float* srow = a.src + ((size_t)n * H + y) * W * 3;
-    T* oi = reinterpret_cast<T*>(a.out_img) + ((size_t)n * H + y) * W * 3;
-    T* of = reinterpret_cast<T*>(a.out_freq) + ((size_t)n * H + y) * W * 3;
+    T* oi = reinterpret_cast<T*>(a.out_img) + ((size_t)n * H + y) * W * a.cs;
+    T* of = reinterpret_cast<T*>(a.out_freq) + ((size_t)n * H + y) * W * a.cs;
     for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) {
         const int x = i / 3, c = i - 3 * x;
         const float corr = (c == 0 ? r01[x].x : (c == 1 ? r01[x].y : r2[x].x)) * inv;
         const float s = srow[i];
         float f = s + corr;
         f = fminf(fmaxf(f, a.clip_lo), a.clip_hi);
-        oi[i] = from_f<T>(s * a.scale + a.offset);
-        of[i] = from_f<T>(f * a.scale + a.offset);
+        oi[x * a.cs + c] = from_f<T>(s * a.scale + a.offset);
+        of[x * a.cs + c] = from_f<T>(f * a.scale + a.offset);
     }
 }
 
@@ -243,6 +243,8 @@ int rd_ram_mix(const rd_ram_t* p, int dtype, void* stream) {
     a.tw_w = reinterpret_cast<const float2*>(p->tw_w);
     a.tw_h = reinterpret_cast<const float2*>(p->tw_h);
     a.B = p->B; a.H = p->H; a.W = p->W; a.b = p->b;
+    a.cs = p->out_cstride > 0 ? p->out_cstride : 3;
+    if (a.cs < 3) return -1;
     a.clip_lo = p->clip_lo; a.clip_hi = p->clip_hi; a.scale = p->scale; a.offset = p->offset;
     hipStream_t st = (hipStream_t)stream;
     const size_t lw = (size_t)4 * p->W * sizeof(float2), lh = (size_t)4 * p->H * sizeof(float2);

@@ -53,7 +53,7 @@ class RdBnBwd(C.Structure):
 class RdSegLoss(C.Structure):
     _fields_ = [('logits', vp), ('target', vp), ('dlogits', vp), ('partial', fp), ('losses_out', fp), ('B', i32),
                 ('H', i32), ('W', i32), ('K', i32), ('kind', i32), ('consistency', i32), ('cons_weight', f32),
-                ('pad_', i32)]
+                ('dlogits_cstride', i32)]
 
 
 class RdAdam(C.Structure):
@@ -65,7 +65,7 @@ class RdAdam(C.Structure):
 class RdRam(C.Structure):
     _fields_ = [('src', fp), ('trg', fp), ('lam', fp), ('out_img', vp), ('out_freq', vp), ('workspace', vp),
                 ('tw_w', fp), ('tw_h', fp), ('B', i32), ('H', i32), ('W', i32), ('C', i32), ('b', i32),
-                ('clip_lo', f32), ('clip_hi', f32), ('scale', f32), ('offset', f32), ('pad_', i32)]
+                ('clip_lo', f32), ('clip_hi', f32), ('scale', f32), ('offset', f32), ('out_cstride', i32)]
 
 
 class RdPackEntry(C.Structure):
@@ -87,15 +87,15 @@ _SIGS = {
     'rd_up_stats': (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
     'rd_up_bwd': (C.c_int, [vp, vp, vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32),
                             C.c_int, vp]),
-    'rd_nchw_to_nhwc': (C.c_int, [fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'rd_nchw_to_nhwc': (C.c_int, [fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rd_nhwc_to_nchw': (C.c_int, [vp, fp, fp, fp, C.c_int, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(i32), C.c_int, vp]),
     'rd_grad_in': (C.c_int, [fp, vp, vp, fp, fp, fp, C.c_int, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.POINTER(i32), C.c_int, vp]),
-    'rd_colsum': (C.c_int, [vp, fp, fp, i64, C.c_int, f32, C.c_int, vp]),
+    'rd_colsum': (C.c_int, [vp, fp, fp, i64, C.c_int, C.c_int, f32, C.c_int, vp]),
     'rd_seg_loss_workspace': (i64, [C.POINTER(RdSegLoss)]),
     'rd_seg_loss': (C.c_int, [C.POINTER(RdSegLoss), C.c_int, vp]),
-    'rd_rec_loss': (C.c_int, [vp, vp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), f32,
+    'rd_rec_loss': (C.c_int, [vp, vp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), f32,
                               C.c_int, vp]),
     'rd_rec_loss_workspace': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'rd_adam_step': (C.c_int, [C.POINTER(RdAdam), vp]),

@@ -175,10 +175,13 @@ class Norm:
 class Act:
     """A stored raw tensor plus the pending (virtual) BatchNorm + activation applied by its readers."""
 
-    def __init__(self, plan, N, H, W, Cc, norm=None, act=False, up=False, name=''):
+    def __init__(self, plan, N, H, W, Cc, norm=None, act=False, up=False, name='', cstride=None, grad_cstride=None):
         self.plan, self.N, self.H, self.W, self.C = plan, N, H, W, Cc
         self.norm, self.act, self.up, self.name = norm, act, up, name
-        self.buf = plan.alloc_act((N, H, W, Cc))
+        # narrow tensors (3-channel image, 2/3-class dlogits) may be stored with a zero-padded channel tail so
+        # that their readers fetch whole 16-byte channel vectors; producers never write the pad
+        self.Cs, self.gCs = cstride or Cc, grad_cstride or Cc
+        self.buf = plan.alloc_act((N, H, W, self.Cs))
         self.g = None                 # gradient w.r.t. the BN output (hi-res when up)
         self.g_written = False
         G = plan.G
@@ -194,7 +197,7 @@ class Act:
     def grad_buf(self):
         if self.g is None:
             Hh, Ww = (2 * self.H, 2 * self.W) if self.up else (self.H, self.W)
-            self.g = self.plan.alloc_act((self.N, Hh, Ww, self.C))
+            self.g = self.plan.alloc_act((self.N, Hh, Ww, self.gCs))
         return self.g
 
 
@@ -214,6 +217,7 @@ class Plan:
         self.device = bank.device
         self.N, self.gstart, self.G = N, list(gstart), len(gstart) - 1
         self.slope, self.training = slope, training
+        self.pad_narrow = False       # TrainStep: pad the dlogits of the output convs to one 16-byte slot
         self.nodes = []
         self.keep = []
         self._stat_chunks = []
@@ -256,10 +260,15 @@ class Plan:
     def conv(self, mname, name, inputs, Cout, taps, norm=None, act=False, up_out=False, H=None, W=None, N=None):
         """inputs: list of (Act, mode, n_off, g_fixed).  Output dims: H x W of the conv itself."""
         Cin = sum(a.C for a, _, _, _ in inputs)
-        out = Act(self, N if N is not None else self.N, H, W, Cout, norm=norm, act=act, up=up_out, name='%s.%s' % (mname, name))
+        gcs = self.slot_channels() if (self.pad_narrow and norm is None and Cout < self.slot_channels()) else None
+        out = Act(self, N if N is not None else self.N, H, W, Cout, norm=norm, act=act, up=up_out, name='%s.%s' % (mname, name),
+                  grad_cstride=gcs)
         node = ConvNode(mname, name, inputs, out, taps, Cin, Cout, norm is None)
         self.nodes.append(node)
         return out
+
+    def slot_channels(self):
+        return 8 if self.dtype == torch.bfloat16 else 4
 
     # ---- descriptor helpers
     def _src(self, a, mode, n_off, g_fixed):
@@ -267,14 +276,14 @@ class Plan:
         s.ptr = a.buf.data_ptr()
         if mode != L.SRC_RAW:
             s.scale, s.shift = a.scale.data_ptr(), a.shift.data_ptr()
-        s.mode, s.C, s.slope, s.n_off, s.g_fixed = mode, a.C, self.slope, n_off, g_fixed
+        s.mode, s.C, s.slope, s.n_off, s.g_fixed = mode, a.Cs, self.slope, n_off, g_fixed
         return s
 
     def _dz_src(self, node):
         """Source descriptor of the gradient w.r.t. this conv's output."""
         o = node.out
         s = L.RdSrc()
-        s.C, s.slope, s.n_off, s.g_fixed = o.C, 0.0, 0, -1
+        s.C, s.slope, s.n_off, s.g_fixed = (o.gCs if o.norm is None else o.C), 0.0, 0, -1
         if o.norm is None or o.up:
             s.ptr, s.mode = (o.dt_buf if o.up else o.grad_buf()).data_ptr(), L.SRC_RAW
         else:
@@ -367,7 +376,7 @@ class Plan:
             if node.has_bias_grad:
                 node.bias_ws = self.alloc_f32(8192)
                 self.bwd.append((lib.rd_colsum, (o.grad_buf().data_ptr(), self.bank.g(node.mname, node.name + '.bias').data_ptr(),
-                                                 node.bias_ws.data_ptr(), N * H * W, o.C, 0.0, dt), dict(kernel='colsum', side=True)))
+                                                 node.bias_ws.data_ptr(), N * H * W, o.C, o.gCs, 0.0, dt), dict(kernel='colsum', side=True)))
             # dgrad (skipped when no input needs a gradient, i.e. the first conv on the image)
             dsts = []
             for (a, mode, n_off, g_fixed) in node.inputs:

@@ -120,7 +120,7 @@ def _stream():
 def to_nhwc(x, act_buf, dt):
     N, Cc, H, W = x.shape
     x = x.contiguous().float()
-    L.check(L.lib().rd_nchw_to_nhwc(x.data_ptr(), act_buf.data_ptr(), N, Cc, H, W, dt, _stream()), 'nchw_to_nhwc')
+    L.check(L.lib().rd_nchw_to_nhwc(x.data_ptr(), act_buf.data_ptr(), N, Cc, H, W, Cc, dt, _stream()), 'nchw_to_nhwc')
 
 
 def materialize(a, plan):

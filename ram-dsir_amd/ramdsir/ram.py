@@ -43,9 +43,12 @@ class RamMixer:
         self.p = p
 
     def bind(self, src, trg, lam, out_img, out_freq):
-        """src/trg: fp32 NHWC [B,H,W,3]; lam: fp32 [B]; outputs: NHWC `dtype` [B,H,W,3] (views are fine)."""
+        """src/trg: fp32 NHWC [B,H,W,3]; lam: fp32 [B]; outputs: NHWC `dtype` [B,H,W,Cs] with Cs >= 3 (views are
+        fine; channels 3..Cs-1 are never written)."""
         self.p.src, self.p.trg, self.p.lam = src.data_ptr(), trg.data_ptr(), lam.data_ptr()
         self.p.out_img, self.p.out_freq = out_img.data_ptr(), out_freq.data_ptr()
+        assert out_img.shape[-1] == out_freq.shape[-1] >= 3
+        self.p.out_cstride = out_img.shape[-1]
         self._keep = (src, trg, lam, out_img, out_freq)
 
     def op(self):

@@ -32,13 +32,16 @@ class TrainStep:
         self.wpack = wpack if wpack is not None else E.WeightPack(bank, mods, dtype)
         # ---- graphs
         self.seg = E.Plan(bank, dtype, 2 * B, [0, B, 2 * B], slope=slope)
-        self.x = E.Act(self.seg, 2 * B, H, W, in_channels, name='input')
+        self.seg.pad_narrow = True
+        slot = self.seg.slot_channels()
+        self.x = E.Act(self.seg, 2 * B, H, W, in_channels, name='input', cstride=slot if in_channels < slot else None)
         self.feats = E.build_encoder(self.seg, self.x, n=n)
         self.logits = E.build_decoder(self.seg, self.feats, n=n, num_classes=num_classes)
         gs = [0]
         for b in batch_sizes:
             gs.append(gs[-1] + b)
         self.rec = E.Plan(bank, dtype, B, gs, slope=slope)
+        self.rec.pad_narrow = True
         self.rec_logits = E.build_rec_decoder(self.rec, self.feats[4], n_off=B, g_fixed=1, domains=list(range(len(batch_sizes))),
                                               n=n, num_classes=in_channels)
         self.seg.build(self.wpack)
@@ -58,6 +61,7 @@ class TrainStep:
         sl.logits, sl.target = self.logits.buf.data_ptr(), self.target.data_ptr()
         sl.dlogits, sl.losses_out = self.logits.grad_buf().data_ptr(), self.losses.data_ptr()
         sl.B, sl.H, sl.W, sl.K = B, H, W, num_classes
+        sl.dlogits_cstride = self.logits.gCs
         sl.kind = 0 if dataset == 'fundus' else 1
         sl.consistency = {None: 0, 'kd': 1, 'mse': 2}[consistency]
         sl.cons_weight = 0.5
@@ -104,7 +108,8 @@ class TrainStep:
         a += self.rec.fwd
         a.append((lib.rd_seg_loss, (C.byref(self.sl), self.dt)))
         a.append((lib.rd_rec_loss, (self.rec_logits.buf.data_ptr(), self.x.buf.data_ptr(), self.rec_logits.grad_buf().data_ptr(),
-                                    self.rec_mse.data_ptr(), self.rec_ws.data_ptr(), B, H, W, self.c, self.rec.G, self.rec.gs_arr,
+                                    self.rec_mse.data_ptr(), self.rec_ws.data_ptr(), B, H, W, self.c, self.x.Cs, self.rec_logits.gCs,
+                                    self.rec.G, self.rec.gs_arr,
                                     self.lambda_rec, self.dt)))
         a += self.seg.bwd[:split]
         a += self.rec.bwd
@@ -119,8 +124,8 @@ class TrainStep:
         lib, B = L.lib(), self.B
         s = self._stream() if stream is None else stream
         half = self.x.buf[B:]
-        L.check(lib.rd_nchw_to_nhwc(img_nchw.data_ptr(), self.x.buf.data_ptr(), B, self.c, self.H, self.W, self.dt, s), 'load img')
-        L.check(lib.rd_nchw_to_nhwc(img_freq_nchw.data_ptr(), half.data_ptr(), B, self.c, self.H, self.W, self.dt, s), 'load img_freq')
+        L.check(lib.rd_nchw_to_nhwc(img_nchw.data_ptr(), self.x.buf.data_ptr(), B, self.c, self.H, self.W, self.x.Cs, self.dt, s), 'load img')
+        L.check(lib.rd_nchw_to_nhwc(img_freq_nchw.data_ptr(), half.data_ptr(), B, self.c, self.H, self.W, self.x.Cs, self.dt, s), 'load img_freq')
 
     def load_raw(self, src_nhwc, trg_nhwc, lam):
         """RAM inputs: what Fundus_Multi.__getitem__ holds before the FFTs (fundus.py:209-212): the

@@ -410,22 +410,30 @@ def test_seg_loss_prostate(dtype, cons):
 
 
 def _run_seg(lg, target_dev, B, K, H, W, kind, cons, dtype, ref_losses):
+    for cs in (K, 8):                        # dense dlogits, and dlogits padded to one 16-byte slot
+        _run_seg_stride(lg, target_dev, B, K, H, W, kind, cons, dtype, ref_losses, cs)
+
+
+def _run_seg_stride(lg, target_dev, B, K, H, W, kind, cons, dtype, ref_losses, cs):
     lgd = U.nhwc(lg.detach(), dtype)
-    dl = torch.full((2 * B, H, W, K), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
+    dl = torch.full((2 * B, H, W, cs), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
     losses = torch.zeros(8, device=U.dev())
     p = L.RdSegLoss()
     p.logits, p.target, p.dlogits, p.losses_out = lgd.data_ptr(), target_dev.data_ptr(), dl.data_ptr(), losses.data_ptr()
     p.B, p.H, p.W, p.K, p.kind, p.consistency, p.cons_weight = B, H, W, K, kind, cons, 0.5
+    p.dlogits_cstride = 0 if cs == K else cs
     ws = torch.empty(L.lib().rd_seg_loss_workspace(C.byref(p)) // 4, device=U.dev())
     p.partial = ws.data_ptr()
     L.check(L.lib().rd_seg_loss(C.byref(p), U.DT[dtype][0], None), 'segloss')
     torch.cuda.synchronize()
     np.testing.assert_allclose(losses[:6].cpu(), [float(v) for v in ref_losses], rtol=2e-5, atol=1e-7)
-    U.assert_close(U.from_nhwc(dl), lg.grad, dtype, 'dlogits', scale=0.5 if dtype == 'bf16' else 5.0)
+    U.assert_close(U.from_nhwc(dl[..., :K]), lg.grad, dtype, 'dlogits', scale=0.5 if dtype == 'bf16' else 5.0)
+    assert bool(torch.isnan(dl[..., K:].float()).all())          # the pad is never written
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_rec_loss(dtype):
+@pytest.mark.parametrize('cs', [3, 8])
+def test_rec_loss(dtype, cs):
     gen = torch.Generator().manual_seed(41)
     B, Cc, H, W = 5, 3, 8, 12
     gstart = [0, 2, 3, 5]
@@ -434,14 +442,16 @@ def test_rec_loss(dtype):
     mses = [F.mse_loss(torch.tanh(lg[gstart[g]:gstart[g + 1]]), tgt[gstart[g]:gstart[g + 1]]) for g in range(3)]
     (0.1 * sum(mses)).backward()
     lgd, td = U.nhwc(lg.detach(), dtype), U.nhwc(tgt, dtype)
-    dl = torch.empty_like(lgd)
+    if cs != Cc:                              # padded target (the network input) and padded dlogits
+        td = torch.cat([td, torch.full((B, H, W, cs - Cc), 7.0, dtype=td.dtype, device=td.device)], -1).contiguous()
+    dl = torch.full((B, H, W, cs), float('nan'), dtype=lgd.dtype, device=lgd.device)
     out = torch.zeros(3, device=U.dev())
     ws = torch.empty(L.lib().rd_rec_loss_workspace(B, H, W, Cc) // 4, device=U.dev())
-    L.check(L.lib().rd_rec_loss(L.ptr(lgd), L.ptr(td), L.ptr(dl), L.ptr(out), L.ptr(ws), B, H, W, Cc, 3, L.gstart_array(gstart), 0.1,
+    L.check(L.lib().rd_rec_loss(L.ptr(lgd), L.ptr(td), L.ptr(dl), L.ptr(out), L.ptr(ws), B, H, W, Cc, cs, cs, 3, L.gstart_array(gstart), 0.1,
                                 U.DT[dtype][0], None), 'recloss')
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu(), [float(m) for m in mses], rtol=2e-5)
-    U.assert_close(U.from_nhwc(dl), lg.grad, dtype, 'rec dlogits', scale=0.5 if dtype == 'bf16' else 5.0)
+    U.assert_close(U.from_nhwc(dl[..., :Cc]), lg.grad, dtype, 'rec dlogits', scale=0.5 if dtype == 'bf16' else 5.0)
 
 
 def test_adam_matches_torch_optim_with_poly_lr():
@@ -480,9 +490,13 @@ def test_layout_boundary_kernels(dtype):
     x = U.rnd(torch.randn(N, Cc, H, W, generator=gen), dtype)
     xd = x.to(U.dev())
     y = torch.empty(N, H, W, Cc, dtype=U.DT[dtype][1], device=U.dev())
-    L.check(L.lib().rd_nchw_to_nhwc(L.ptr(xd), L.ptr(y), N, Cc, H, W, U.DT[dtype][0], None), 'to_nhwc')
+    L.check(L.lib().rd_nchw_to_nhwc(L.ptr(xd), L.ptr(y), N, Cc, H, W, 0, U.DT[dtype][0], None), 'to_nhwc')
     torch.cuda.synchronize()
     assert torch.equal(U.from_nhwc(y), x)
+    yp = torch.zeros(N, H, W, 8, dtype=U.DT[dtype][1], device=U.dev())        # 3 channels into a padded slot
+    L.check(L.lib().rd_nchw_to_nhwc(L.ptr(xd[:, :3].contiguous()), L.ptr(yp), N, 3, H, W, 8, U.DT[dtype][0], None), 'to_nhwc pad')
+    torch.cuda.synchronize()
+    assert torch.equal(U.from_nhwc(yp[..., :3]), x[:, :3]) and float(yp[..., 3:].float().abs().max()) == 0.0
     sc, sh = _params(2, Cc, gen)
     scd, shd = U.fdev(sc), U.fdev(sh)
     back = torch.empty(N, Cc, H, W, device=U.dev())
@@ -510,6 +524,10 @@ def test_layout_boundary_kernels(dtype):
     t3d = U.nhwc(t3, dtype)
     outc = torch.ones(3, device=U.dev())
     wsb = torch.empty(8192, device=U.dev())
-    L.check(L.lib().rd_colsum(L.ptr(t3d), L.ptr(outc), L.ptr(wsb), 2 * 20 * 30, 3, 1.0, U.DT[dtype][0], None), 'colsum')
+    L.check(L.lib().rd_colsum(L.ptr(t3d), L.ptr(outc), L.ptr(wsb), 2 * 20 * 30, 3, 0, 1.0, U.DT[dtype][0], None), 'colsum')
     torch.cuda.synchronize()
     np.testing.assert_allclose(outc.cpu(), 1 + t3.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    t3p = torch.cat([t3d, torch.ones(2, 20, 30, 5, dtype=t3d.dtype, device=t3d.device)], -1).contiguous()
+    L.check(L.lib().rd_colsum(L.ptr(t3p), L.ptr(outc), L.ptr(wsb), 2 * 20 * 30, 3, 8, 0.0, U.DT[dtype][0], None), 'colsum pad')
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(outc.cpu(), t3.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)

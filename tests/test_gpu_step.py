@@ -232,7 +232,7 @@ def test_step_at_baseline_config_shapes(dataset, bs, S):
         hist.append(ts.loss_dict()['loss'])
     assert all(np.isfinite(hist)), hist
     assert hist[-1] < hist[0], hist
-    x = ts.x.buf.float()
+    x = ts.x.buf[..., :ts.c].float()
     assert float(x.min()) >= -1.0 and float(x.max()) <= 1.0
     assert torch.equal(x[0], x[B])                                  # lambda = 1: img_freq == img
     assert int(bank.b('enc', 'convd1.bn1.num_batches_tracked')) == 12
