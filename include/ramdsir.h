@@ -183,8 +183,11 @@ typedef struct {
 int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream);
 
 /* statistics of y = bilinear_x2(t) (nn.Upsample(scale_factor=2, 'bilinear', align_corners=False),
- * unet.py:84) without materialising y: stats[G][C][2] += (sum y, sum y^2).  t: NHWC [N][h][w][C]. */
-int rd_up_stats(const void* t, float* stats, int N, int h, int w, int C, int G, const int32_t* gstart_host,
+ * unet.py:84): stats[G][C][2] += (sum y, sum y^2).  t: NHWC [N][h][w][C].  y_out == NULL: y is not
+ * materialised (its readers interpolate t on the fly, RD_SRC_UP / RD_DST_UPY); otherwise y is also written to
+ * y_out NHWC [N][2h][2w][C] in `dtype` and the statistics are those of the STORED (rounded) values, so that
+ * plain RD_SRC_AFFACT / RD_DST_PLAIN readers normalise exactly what was measured. */
+int rd_up_stats(const void* t, float* stats, void* y_out, int N, int h, int w, int C, int G, const int32_t* gstart_host,
                 int dtype, void* stream);
 
 /* backward of y = up2(t) followed by BN: dt = up2^T( P*g + Q*up2(t) + R ), g: NHWC [N][2h][2w][C],

@@ -79,7 +79,7 @@ __device__ __forceinline__ void ldv(const T* p, float* f) {
 
 // sum / sum of squares of the virtual upsampled tensor; grid (blocks, N)
 template <typename T>
-__global__ __launch_bounds__(256) void up_stats_kernel(const T* t, float* stats, int h, int w, int C, GroupMap gm) {
+__global__ __launch_bounds__(256) void up_stats_kernel(const T* t, float* stats, T* y_out, int h, int w, int C, GroupMap gm) {
     constexpr int S = Slot<T>::N;
     extern __shared__ float s_red[];                       // [C][2]
     const int n = blockIdx.y, g = group_of(gm, n);
@@ -105,12 +105,21 @@ __global__ __launch_bounds__(256) void up_stats_kernel(const T* t, float* stats,
         ldv<T>(b + ((size_t)y0 * w + x1) * C, t01);
         ldv<T>(b + ((size_t)y1 * w + x0) * C, t10);
         ldv<T>(b + ((size_t)y1 * w + x1) * C, t11);
+        float uu[S];
 #pragma unroll
         for (int e = 0; e < S; ++e) {
             const float top = t00[e] + lx * (t01[e] - t00[e]), bot = t10[e] + lx * (t11[e] - t10[e]);
-            const float u = top + ly * (bot - top);
-            a1[e] += u;
-            a2[e] += u * u;
+            uu[e] = top + ly * (bot - top);
+        }
+        if (y_out) {
+            const uint4 pk = Slot<T>::pack(uu);
+            *reinterpret_cast<uint4*>(y_out + ((size_t)n * H * W + pix) * C + sl * S) = pk;
+            Slot<T>::unpack(pk, uu);
+        }
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            a1[e] += uu[e];
+            a2[e] += uu[e] * uu[e];
         }
     }
 #pragma unroll
@@ -320,7 +329,7 @@ int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
     return (int)hipGetLastError();
 }
 
-int rd_up_stats(const void* t, float* stats, int N, int h, int w, int C, int G, const int32_t* gstart_host, int dtype,
+int rd_up_stats(const void* t, float* stats, void* y_out, int N, int h, int w, int C, int G, const int32_t* gstart_host, int dtype,
                 void* stream) {
     const int S = dtype == RD_BF16 ? 8 : 4;
     if (C % S || 256 % (C / S)) return -2;
@@ -330,10 +339,10 @@ int rd_up_stats(const void* t, float* stats, int N, int h, int w, int C, int G, 
     dim3 grid(bx, N);
     if (dtype == RD_BF16)
         hipLaunchKernelGGL(up_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
-                           (const bf16_t*)t, stats, h, w, C, gm);
+                           (const bf16_t*)t, stats, (bf16_t*)y_out, h, w, C, gm);
     else
         hipLaunchKernelGGL(up_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
-                           (const float*)t, stats, h, w, C, gm);
+                           (const float*)t, stats, (float*)y_out, h, w, C, gm);
     return (int)hipGetLastError();
 }
 

@@ -32,7 +32,7 @@ class TrainStep:
         self.wpack = wpack if wpack is not None else E.WeightPack(bank, mods, dtype)
         # ---- graphs
         self.seg = E.Plan(bank, dtype, 2 * B, [0, B, 2 * B], slope=slope)
-        self.seg.pad_narrow = True
+        self.seg.pad_narrow = self.seg.materialize_up = True
         slot = self.seg.slot_channels()
         self.x = E.Act(self.seg, 2 * B, H, W, in_channels, name='input', cstride=slot if in_channels < slot else None)
         self.feats = E.build_encoder(self.seg, self.x, n=n)
@@ -41,7 +41,7 @@ class TrainStep:
         for b in batch_sizes:
             gs.append(gs[-1] + b)
         self.rec = E.Plan(bank, dtype, B, gs, slope=slope)
-        self.rec.pad_narrow = True
+        self.rec.pad_narrow = self.rec.materialize_up = True
         self.rec_logits = E.build_rec_decoder(self.rec, self.feats[4], n_off=B, g_fixed=1, domains=list(range(len(batch_sizes))),
                                               n=n, num_classes=in_channels)
         self.seg.build(self.wpack)

@@ -357,11 +357,21 @@ def test_upsample_stats_and_backward(dtype):
     td = U.nhwc(t.detach(), dtype)
     stats = torch.zeros(2, L.STAT_SLOTS, Cc, 2, device=U.dev())
     gs = L.gstart_array(gstart)
-    L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats), N, h, w, Cc, 2, gs, U.DT[dtype][0], None), 'upstats')
+    L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats), None, N, h, w, Cc, 2, gs, U.DT[dtype][0], None), 'upstats')
     torch.cuda.synchronize()
     ref = torch.stack([torch.stack([y[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), y[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
                        for g in range(2)]).detach()
     np.testing.assert_allclose(stats.sum(1).cpu(), ref, rtol=1e-3, atol=1e-2)
+    # materialising variant: y is stored, and the statistics are those of the stored (rounded) values
+    stats2 = torch.zeros_like(stats)
+    yd = torch.full((N, 2 * h, 2 * w, Cc), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
+    L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats2), L.ptr(yd), N, h, w, Cc, 2, gs, U.DT[dtype][0], None), 'upstats+y')
+    torch.cuda.synchronize()
+    U.assert_close(U.from_nhwc(yd), y.detach(), dtype, 'up y')
+    ys = U.from_nhwc(yd)
+    ref2 = torch.stack([torch.stack([ys[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), ys[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
+                        for g in range(2)])
+    np.testing.assert_allclose(stats2.sum(1).cpu(), ref2, rtol=1e-4, atol=1e-3)
     P, R = _params(2, Cc, gen)
     Q = 0.1 * torch.randn(2, Cc, generator=gen)
     g2 = U.rnd(torch.randn(N, Cc, 2 * h, 2 * w, generator=gen), dtype)
