@@ -577,8 +577,8 @@ struct ItemGeom {
     int lds[NIT];          // slot index in s_in, -1: item does not exist
 };
 
-template <typename T, int NIT>
-__device__ __forceinline__ void pf_issue(uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, const ItemGeom<NIT>& ig, int n,
+template <typename T, int NIT, int NQ>
+__device__ __forceinline__ void pf_issue(uint4 (&raw)[NIT][NQ], const rd_src_t& s, const SlotCtx<T>& k, const ItemGeom<NIT>& ig, int n,
                                          int H, int W, int yh, int xh, int nit = NIT) {
     // branch-free (clamped addresses): conditional loads would be waited for one by one (see tile_fill_mode);
     // 32-bit element offsets from an image base keep the address math off the 64-bit VALU path
@@ -593,18 +593,20 @@ __device__ __forceinline__ void pf_issue(uint4 (&raw)[NIT][2], const rd_src_t& s
         off[b] = (unsigned)((y * W + x) * C);
         raw[b][0] = ld16(base + off[b]);
     }
-    if (s.mode == RD_SRC_BNBWD) {
+    if constexpr (NQ == 2) {
+        if (s.mode == RD_SRC_BNBWD) {
 #pragma unroll
-        for (int b = 0; b < NIT; ++b) {
-            if (b >= nit) break;
-            raw[b][1] = ld16(base2 + off[b]);
+            for (int b = 0; b < NIT; ++b) {
+                if (b >= nit) break;
+                raw[b][1] = ld16(base2 + off[b]);
+            }
         }
     }
 }
 
-template <typename T, int NIT>
-__device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, const ItemGeom<NIT>& ig,
-                                           int H, int W, int yh, int xh, uint4* s_in, int nit = NIT) {
+template <typename T, int NIT, int NQ, typename StoreFn>
+__device__ __forceinline__ void pf_consume_fn(const uint4 (&raw)[NIT][NQ], const rd_src_t& s, const SlotCtx<T>& k, const ItemGeom<NIT>& ig,
+                                              int H, int W, int yh, int xh, StoreFn store, int nit = NIT) {
     constexpr int S = Slot<T>::N;
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
@@ -622,7 +624,7 @@ __device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_
             } else if (s.mode == RD_SRC_AFFACT) {
 #pragma unroll
                 for (int e = 0; e < S; ++e) v[e] = act_fn(v[e] * k.sc[e] + k.sh[e], s.slope);
-            } else {
+            } else if constexpr (NQ == 2) {
                 float zz[S];
                 Slot<T>::unpack(raw[b][1], zz);
 #pragma unroll
@@ -630,10 +632,15 @@ __device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_
             }
             u = in ? Slot<T>::pack(v) : make_uint4(0, 0, 0, 0);
         }
-        s_in[ig.lds[b]] = u;
+        store(ig.lds[b], u);
     }
 }
 
+template <typename T, int NIT>
+__device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_src_t& s, const SlotCtx<T>& k, const ItemGeom<NIT>& ig,
+                                           int H, int W, int yh, int xh, uint4* s_in, int nit = NIT) {
+    pf_consume_fn<T, NIT, 2>(raw, s, k, ig, H, W, yh, xh, [&](int l, const uint4& u) { s_in[l] = u; }, nit);
+}
 
 }  // namespace
 

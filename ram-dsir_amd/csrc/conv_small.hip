@@ -479,8 +479,19 @@ int launch_conv_small(const rd_conv_t& p, hipStream_t st) {
     const int ntiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
     static int tpw_env = -1;
     if (tpw_env < 0) { const char* e = getenv("RD_TPW"); tpw_env = e ? atoi(e) : 0; }
-    int tpw = tpw_env > 0 ? tpw_env : 4;
-    while (tpw_env <= 0 && tpw > 1 && (long)((ntiles + tpw - 1) / tpw) * p.N < 1536) tpw >>= 1;     // keep >= ~3 workgroups per CU-slot
+    // tiles per workgroup: the launch runs in rounds of `slots` resident workgroups (2 per CU); pick the
+    // count whose last round is (nearly) full -- e.g. 16 images x 650 tiles: 4 tiles/workgroup is 6 rounds
+    // x 4 tile-times, 21 tiles/workgroup is 1 round x 21 -- charging half a tile-time per workgroup prologue
+    int tpw = tpw_env;
+    if (tpw <= 0) {
+        const long slots = 2L * rd_num_cus();
+        double best = 1e30;
+        for (int t = 1; t <= 32 && t <= ntiles; ++t) {
+            const long wgs = (long)((ntiles + t - 1) / t) * p.N;
+            const double cost = (double)((wgs + slots - 1) / slots) * (t + 0.5);
+            if (cost < best - 1e-9) { best = cost; tpw = t; }
+        }
+    }
     dim3 grid((ntiles + tpw - 1) / tpw, 1, p.N);
     static bool attr_set = false;
     if constexpr (REG_EPI) {

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int Cout
 // 38 ds_read_u16 + packing per k-step.  Channel rows are padded to 16*odd bytes mod 256 so the 16-lane
 // groups of a b128 read hit 64 distinct banks.  Each wave fills whole channel slots (lanes run over
 // pixels), so the transposing ds_write_b16 of a wave land on consecutive pixels of one row.
-template <int TAPS, int MB, int NB>
+template <int TAPS, int MB, int NB, bool PF>
 __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
     typedef bf16_t T;
     constexpr int S = 8;
@@ -220,21 +220,101 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    SlotCtx<T> ctx_a[SPA], ctx_z[SPZ];
-    int g_ctx = -1;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int n = tile / (tiles_x * tiles_y);
+    auto coords = [&](int tile, int& n, int& y0, int& x0) {
+        n = tile / (tiles_x * tiles_y);
         const int trem = tile - n * tiles_x * tiles_y;
-        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        y0 = (trem / tiles_x) * TH;
+        x0 = (trem % tiles_x) * TW;
+    };
+    SlotCtx<T> ctx_a[SPA], ctx_z[SPZ];
+    auto make_ctx = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < SPA; ++q) slot_ctx<T>(ctx_a[q], p.a, p.na, p.Cin, g, cbase + (wave + 4 * q) * S);
+#pragma unroll
+        for (int q = 0; q < SPZ; ++q) slot_ctx<T>(ctx_z[q], &p.dz, 1, p.Cout, g, nbase + (wave + 4 * q) * S);
+    };
+    int g_ctx = 0;
+    make_ctx(0);
+    // PF (every source is a plain per-pixel read with whole 16-byte channel slots -- the host checks): the
+    // raw 16-byte vectors of the NEXT tile are fetched into registers right after this tile's LDS fill, so
+    // their HBM latency is hidden behind the MFMA phase; channel slots beyond Cin / Cout are zeroed once.
+    constexpr int NITA = (PH * PW + 63) / 64, NITZ = (TH * TW) / 64;
+    ItemGeom<NITA> iga;
+    ItemGeom<NITZ> igz;
+    rd_src_t sa[SPA];
+    bool live_a[SPA], live_z[SPZ];
+    uint4 raw_a[SPA][NITA][1], raw_z[SPZ][NITZ][2];
+    auto issue = [&](int tile) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+#pragma unroll
+        for (int q = 0; q < SPA; ++q)
+            if (live_a[q]) pf_issue<T, NITA>(raw_a[q], sa[q], ctx_a[q], iga, n, H, W, y0 - HALO, x0 - HALO);
+#pragma unroll
+        for (int q = 0; q < SPZ; ++q)
+            if (live_z[q]) pf_issue<T, NITZ>(raw_z[q], p.dz, ctx_z[q], igz, n, H, W, y0, x0);
+    };
+    if constexpr (PF) {
+#pragma unroll
+        for (int b = 0; b < NITA; ++b) {
+            const int pix = lane + 64 * b, py = pix / PW, px = pix - py * PW;
+            iga.py[b] = (short)py;
+            iga.px[b] = (short)px;
+            iga.lds[b] = pix < PH * PW ? py * PWL + px : -1;
+        }
+#pragma unroll
+        for (int b = 0; b < NITZ; ++b) {
+            const int pix = lane + 64 * b;
+            igz.py[b] = (short)(pix / TW);
+            igz.px[b] = (short)(pix % TW);
+            igz.lds[b] = pix;
+        }
+#pragma unroll
+        for (int q = 0; q < SPA; ++q) {
+            sa[q] = select_src(p.a, ctx_a[q].si > 0 ? 1 : 0);
+            live_a[q] = wave + 4 * q < NSA && ctx_a[q].si >= 0;
+        }
+#pragma unroll
+        for (int q = 0; q < SPZ; ++q) live_z[q] = wave + 4 * q < NSZ && ctx_z[q].si >= 0;
+        unsigned* z32 = reinterpret_cast<unsigned*>(smem);
+        for (int i = tid; i < (CA * AP + CZ * ZP) / 2; i += 256) z32[i] = 0u;
+        if ((int)blockIdx.x < total_tiles) issue(blockIdx.x);
+    }
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
         const int g = group_of(gm, n);
         if (g != g_ctx) {
-#pragma unroll
-            for (int q = 0; q < SPA; ++q) slot_ctx<T>(ctx_a[q], p.a, p.na, p.Cin, g, cbase + (wave + 4 * q) * S);
-#pragma unroll
-            for (int q = 0; q < SPZ; ++q) slot_ctx<T>(ctx_z[q], &p.dz, 1, p.Cout, g, nbase + (wave + 4 * q) * S);
+            make_ctx(g);
             g_ctx = g;
         }
         __syncthreads();
+        if constexpr (PF) {
+#pragma unroll
+            for (int q = 0; q < SPA; ++q) {
+                const int sl = wave + 4 * q;
+                if (live_a[q])
+                    pf_consume_fn<T, NITA, 1>(raw_a[q], sa[q], ctx_a[q], iga, H, W, y0 - HALO, x0 - HALO, [&](int l, const uint4& u) {
+                        unsigned short* d = s_a + (sl * S) * AP + l;
+                        d[0 * AP] = (unsigned short)(u.x & 0xffff); d[1 * AP] = (unsigned short)(u.x >> 16);
+                        d[2 * AP] = (unsigned short)(u.y & 0xffff); d[3 * AP] = (unsigned short)(u.y >> 16);
+                        d[4 * AP] = (unsigned short)(u.z & 0xffff); d[5 * AP] = (unsigned short)(u.z >> 16);
+                        d[6 * AP] = (unsigned short)(u.w & 0xffff); d[7 * AP] = (unsigned short)(u.w >> 16);
+                    });
+            }
+#pragma unroll
+            for (int q = 0; q < SPZ; ++q) {
+                const int sl = wave + 4 * q;
+                if (live_z[q])
+                    pf_consume_fn<T, NITZ, 2>(raw_z[q], p.dz, ctx_z[q], igz, H, W, y0, x0, [&](int l, const uint4& u) {
+                        unsigned short* d = s_z + (sl * S) * ZP + l;
+                        d[0 * ZP] = (unsigned short)(u.x & 0xffff); d[1 * ZP] = (unsigned short)(u.x >> 16);
+                        d[2 * ZP] = (unsigned short)(u.y & 0xffff); d[3 * ZP] = (unsigned short)(u.y >> 16);
+                        d[4 * ZP] = (unsigned short)(u.z & 0xffff); d[5 * ZP] = (unsigned short)(u.z >> 16);
+                        d[6 * ZP] = (unsigned short)(u.w & 0xffff); d[7 * ZP] = (unsigned short)(u.w >> 16);
+                    });
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < SPA; ++q) {
             const int sl = wave + 4 * q;
@@ -276,7 +356,11 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
                 tile_fill<T, 64>(&p.dz, ctx_z[q], n, H, W, lane, TH * TW, map, store);
             }
         }
+        }
         __syncthreads();
+        if constexpr (PF) {
+            if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
+        }
         const unsigned short* zr = s_z + (mb * 32 + li) * ZP;
         const unsigned short* ar = s_a + (nb * 32 + li) * AP;
         for (int rr = 0; rr < ROWS; ++rr) {
@@ -340,8 +424,8 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
 // of one tile row, 16x16 channel blocks (no padding of 16-channel layers to 32), 4 accumulator VGPRs per tap
 // (36 for a 3x3) instead of 144 -> 4 workgroups per CU keep enough loads in flight.  MB x NB 16-channel
 // blocks per workgroup; the 4 waves are MB*NB blocks x KS = 4/(MB*NB) row splits.
-template <int TAPS, int MB, int NB>
-__global__ __launch_bounds__(256, 3) void wgrad_c16_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+template <int TAPS, int MB, int NB, bool PF>
+__global__ __launch_bounds__(256, PF ? 2 : 3) void wgrad_c16_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
     typedef bf16_t T;
     typedef __attribute__((ext_vector_type(4))) float f32x4v;
     constexpr int S = 8;
@@ -371,23 +455,99 @@ __global__ __launch_bounds__(256, 3) void wgrad_c16_kernel(const rd_wgrad_t p, i
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
-    SlotCtx<T> ctx[JPW];
-    int g_ctx = -1;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int n = tile / (tiles_x * tiles_y);
+    auto coords = [&](int tile, int& n, int& y0, int& x0) {
+        n = tile / (tiles_x * tiles_y);
         const int trem = tile - n * tiles_x * tiles_y;
-        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        y0 = (trem / tiles_x) * TH;
+        x0 = (trem % tiles_x) * TW;
+    };
+    SlotCtx<T> ctx[JPW];
+    auto make_ctx = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < JPW; ++q) {
+            const int job = wave + 4 * q;
+            if (job < NSA) slot_ctx<T>(ctx[q], p.a, p.na, p.Cin, g, cbase + job * S);
+            else if (job < NJOB) slot_ctx<T>(ctx[q], &p.dz, 1, p.Cout, g, nbase + (job - NSA) * S);
+            else ctx[q].si = -1;
+        }
+    };
+    int g_ctx = 0;
+    make_ctx(0);
+    // PF: see wgrad_t_kernel -- next tile's raw vectors are in flight during this tile's MFMA phase
+    constexpr int NITA = (PH * PW + 63) / 64, NITZ = (TH * TW) / 64;
+    ItemGeom<NITA> iga;
+    ItemGeom<NITZ> igz;
+    rd_src_t sj[JPW];
+    bool live[JPW];
+    uint4 raw_a[JPW][NITA][1], raw_z[JPW][NITZ][2];
+    auto issue = [&](int tile) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+#pragma unroll
+        for (int q = 0; q < JPW; ++q) {
+            if (!live[q]) continue;
+            if (wave + 4 * q < NSA) pf_issue<T, NITA>(raw_a[q], sj[q], ctx[q], iga, n, H, W, y0 - HALO, x0 - HALO);
+            else pf_issue<T, NITZ>(raw_z[q], sj[q], ctx[q], igz, n, H, W, y0, x0);
+        }
+    };
+    if constexpr (PF) {
+#pragma unroll
+        for (int b = 0; b < NITA; ++b) {
+            const int pix = lane + 64 * b, py = pix / PW, px = pix - py * PW;
+            iga.py[b] = (short)py;
+            iga.px[b] = (short)px;
+            iga.lds[b] = pix < PH * PW ? py * PWL + px : -1;
+        }
+#pragma unroll
+        for (int b = 0; b < NITZ; ++b) {
+            const int pix = lane + 64 * b;
+            igz.py[b] = (short)(pix / TW);
+            igz.px[b] = (short)(pix % TW);
+            igz.lds[b] = pix;
+        }
+#pragma unroll
+        for (int q = 0; q < JPW; ++q) {
+            const int job = wave + 4 * q;
+            sj[q] = job < NSA ? select_src(p.a, ctx[q].si > 0 ? 1 : 0) : p.dz;
+            live[q] = job < NJOB && ctx[q].si >= 0;
+        }
+        unsigned* z32 = reinterpret_cast<unsigned*>(smem);
+        for (int i = tid; i < (CA * AP + CZ * ZP) / 2; i += 256) z32[i] = 0u;
+        if ((int)blockIdx.x < total_tiles) issue(blockIdx.x);
+    }
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
         const int g = group_of(gm, n);
         if (g != g_ctx) {
-#pragma unroll
-            for (int q = 0; q < JPW; ++q) {
-                const int job = wave + 4 * q;
-                if (job < NSA) slot_ctx<T>(ctx[q], p.a, p.na, p.Cin, g, cbase + job * S);
-                else if (job < NJOB) slot_ctx<T>(ctx[q], &p.dz, 1, p.Cout, g, nbase + (job - NSA) * S);
-            }
+            make_ctx(g);
             g_ctx = g;
         }
         __syncthreads();
+        if constexpr (PF) {
+#pragma unroll
+            for (int q = 0; q < JPW; ++q) {
+                const int job = wave + 4 * q;
+                if (!live[q]) continue;
+                if (job < NSA) {
+                    pf_consume_fn<T, NITA, 1>(raw_a[q], sj[q], ctx[q], iga, H, W, y0 - HALO, x0 - HALO, [&](int l, const uint4& u) {
+                        unsigned short* d = s_a + (job * S) * AP + l;
+                        d[0 * AP] = (unsigned short)(u.x & 0xffff); d[1 * AP] = (unsigned short)(u.x >> 16);
+                        d[2 * AP] = (unsigned short)(u.y & 0xffff); d[3 * AP] = (unsigned short)(u.y >> 16);
+                        d[4 * AP] = (unsigned short)(u.z & 0xffff); d[5 * AP] = (unsigned short)(u.z >> 16);
+                        d[6 * AP] = (unsigned short)(u.w & 0xffff); d[7 * AP] = (unsigned short)(u.w >> 16);
+                    });
+                } else {
+                    pf_consume_fn<T, NITZ, 2>(raw_z[q], sj[q], ctx[q], igz, H, W, y0, x0, [&](int l, const uint4& u) {
+                        unsigned short* d = s_z + ((job - NSA) * S) * ZP + l;
+                        d[0 * ZP] = (unsigned short)(u.x & 0xffff); d[1 * ZP] = (unsigned short)(u.x >> 16);
+                        d[2 * ZP] = (unsigned short)(u.y & 0xffff); d[3 * ZP] = (unsigned short)(u.y >> 16);
+                        d[4 * ZP] = (unsigned short)(u.z & 0xffff); d[5 * ZP] = (unsigned short)(u.z >> 16);
+                        d[6 * ZP] = (unsigned short)(u.w & 0xffff); d[7 * ZP] = (unsigned short)(u.w >> 16);
+                    });
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < JPW; ++q) {
             const int job = wave + 4 * q;
@@ -425,10 +585,14 @@ __global__ __launch_bounds__(256, 3) void wgrad_c16_kernel(const rd_wgrad_t p, i
                 tile_fill<T, 64>(&p.dz, ctx[q], n, H, W, lane, TH * TW, map, store);
             }
         }
+        }
         __syncthreads();
+        if constexpr (PF) {
+            if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
+        }
         const unsigned short* zr = s_z + (mb * 16 + li) * ZP + kg * 8;
         const unsigned short* ar = s_a + (nb * 16 + li) * AP + kg * 8;
-#pragma unroll
+#pragma unroll 1
         for (int rr = 0; rr < ROWS; ++rr) {
             const int row = kq + rr * KS;
             const bf16x8 afrag = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(zr + row * TW));
@@ -528,7 +692,8 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
         g.CoutPadW = g.MB * 16;
         g.CinPadW = g.NB * 16;
         g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
-        int gx = 1024;                                      // 4 workgroups per CU
+        int gx = 3 * rd_num_cus();                                    // exactly the resident set (3 workgroups per CU): no second,
+                                                            // partially filled round of workgroups
         if (gx > g.total_tiles) gx = g.total_tiles;
         g.gx = gx < 1 ? 1 : gx;
         g.nsplit = g.gx;
@@ -571,6 +736,15 @@ int launch_wgrad(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// every source a plain per-pixel read (no pooling / on-the-fly upsampling) of whole 16-byte channel slots
+bool wgrad_pf_ok(const rd_wgrad_t& p) {
+    for (int i = 0; i < p.na; ++i) {
+        const int m = p.a[i].mode;
+        if (!(m == RD_SRC_RAW || m == RD_SRC_AFF || m == RD_SRC_AFFACT) || p.a[i].C % 8) return false;
+    }
+    return (p.dz.mode == RD_SRC_RAW || p.dz.mode == RD_SRC_BNBWD) && p.dz.C % 8 == 0;
+}
+
 template <int TAPS, int MB, int NB>
 int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -580,7 +754,11 @@ int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * TAPS * 4 * 64 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
     dim3 grid(g.gx, g.CoutPadW / (MB * 16), g.CinPadW / (NB * 16));
-    hipLaunchKernelGGL((wgrad_c16_kernel<TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    static const bool pf = getenv("RD_C16_PF") != nullptr;
+    if (pf && wgrad_pf_ok(p))
+        hipLaunchKernelGGL((wgrad_c16_kernel<TAPS, MB, NB, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    else
+        hipLaunchKernelGGL((wgrad_c16_kernel<TAPS, MB, NB, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     return (int)hipGetLastError();
 }
 
@@ -595,11 +773,16 @@ int launch_wgrad_t(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    if (wgrad_pf_ok(p))
+        hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    else
+        hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     return (int)hipGetLastError();
 }
 
@@ -608,13 +791,7 @@ int dispatch_wgrad(const rd_wgrad_t& p, hipStream_t st) {
     const WgradGeom g = wgrad_geom<T>(p);
     int e;
     if (g.c16) {
-#define RD_WGC(TAPS_)                                                                \
-    if (g.MB == 2 && g.NB == 2) e = launch_wgrad_c16<TAPS_, 2, 2>(p, g, st);         \
-    else if (g.MB == 2) e = launch_wgrad_c16<TAPS_, 2, 1>(p, g, st);                 \
-    else if (g.NB == 2) e = launch_wgrad_c16<TAPS_, 1, 2>(p, g, st);                 \
-    else e = launch_wgrad_c16<TAPS_, 1, 1>(p, g, st);
-        if (p.taps == 9) { RD_WGC(9) } else { RD_WGC(1) }
-#undef RD_WGC
+        e = p.taps == 9 ? launch_wgrad_c16<9, 1, 1>(p, g, st) : launch_wgrad_c16<1, 1, 1>(p, g, st);
     } else if constexpr (sizeof(T) == 2) {
 #define RD_WGT(TAPS_)                                                                \
     if (g.MB == 2 && g.NB == 2) e = launch_wgrad_t<TAPS_, 2, 2>(p, g, st);           \
