@@ -195,6 +195,16 @@ int rd_up_stats(const void* t, float* stats, void* y_out, int N, int h, int w, i
 int rd_up_bwd(const void* g, const void* t, void* dt, const float* P, const float* Q, const float* R, int N, int h,
               int w, int C, int G, const int32_t* gstart_host, int dtype, void* stream);
 
+/* Elementwise materialisation  out = act( a*x + b*x2 + c ; slope )  over NHWC [N][H][W][C] with per-(group, channel)
+ * coefficients a, b, c [G][C] (b, x2 may be NULL; slope 1 = no activation):
+ *   forward  : a = BN scale, c = BN shift          -> the activated tensor relu(bn(z)) (unet.py:59-70), stored once
+ *   backward : a = P, x2 = z, b = Q, c = R         -> dz, the gradient w.r.t. the conv output behind the BN
+ * Used for the >= 64-channel layers, whose conv kernels are instruction-bound in the loader: their many readers
+ * (one workgroup per 64 output channels, forward + dgrad + wgrad) then fetch the stored tensor with RD_SRC_RAW
+ * instead of each redoing the BN/ReLU arithmetic; the tensors are small (<= 20 MB) at those depths. */
+int rd_bn_apply(const void* x, const void* x2, void* out, const float* a, const float* b, const float* c, float slope,
+                int N, int H, int W, int C, int G, const int32_t* gstart_host, int dtype, void* stream);
+
 /* layout / materialisation at the module boundary (torch NCHW fp32 <-> NHWC dtype) */
 /* cstride: elements between pixels of y (0 or C: dense; larger: zero-initialised pad channels are left untouched) */
 int rd_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int N, int C, int H, int W, int cstride, int dtype, void* stream);

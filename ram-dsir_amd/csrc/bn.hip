@@ -299,6 +299,39 @@ __global__ __launch_bounds__(64) void colsum_final_kernel(const float* partial, 
     if (threadIdx.x == 0) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
 }
 
+// out = act(a*x + b*x2 + c; slope) over NHWC, one 16-byte channel slot per thread-item
+template <typename T, bool TWO>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, const T* x2, T* out, const float* a, const float* b, const float* c,
+                                                       float slope, int HW, int C, GroupMap gm) {
+    constexpr int S = Slot<T>::N;
+    const int n = blockIdx.y, g = group_of(gm, n);
+    const int SL = C / S;
+    const size_t base = (size_t)n * HW * C;
+    const int items = HW * SL;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < items; idx += gridDim.x * blockDim.x) {
+        const int sl = idx % SL;
+        float ca[S], cb[S], cc[S];
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            ca[e] = a[g * C + sl * S + e];
+            cc[e] = c[g * C + sl * S + e];
+            cb[e] = TWO ? b[g * C + sl * S + e] : 0.f;
+        }
+        float v[S], w[S];
+        const size_t off = base + (size_t)idx * S;
+        Slot<T>::unpack(*reinterpret_cast<const uint4*>(x + off), v);
+        if constexpr (TWO) {
+            Slot<T>::unpack(*reinterpret_cast<const uint4*>(x2 + off), w);
+#pragma unroll
+            for (int e = 0; e < S; ++e) v[e] = act_fn(ca[e] * v[e] + cb[e] * w[e] + cc[e], slope);
+        } else {
+#pragma unroll
+            for (int e = 0; e < S; ++e) v[e] = act_fn(ca[e] * v[e] + cc[e], slope);
+        }
+        *reinterpret_cast<uint4*>(out + off) = Slot<T>::pack(v);
+    }
+}
+
 GroupMap host_gm(int G, const int32_t* gs) {
     GroupMap gm;
     gm.G = G;
@@ -343,6 +376,23 @@ int rd_up_stats(const void* t, float* stats, void* y_out, int N, int h, int w, i
     else
         hipLaunchKernelGGL(up_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
                            (const float*)t, stats, (float*)y_out, h, w, C, gm);
+    return (int)hipGetLastError();
+}
+
+int rd_bn_apply(const void* x, const void* x2, void* out, const float* a, const float* b, const float* c, float slope, int N, int H,
+                int W, int C, int G, const int32_t* gstart_host, int dtype, void* stream) {
+    const int S = dtype == RD_BF16 ? 8 : 4;
+    if (C % S || !x || !out || !a || !c || ((x2 != nullptr) != (b != nullptr))) return -2;
+    if (G < 1 || G > RD_MAX_GROUPS) return -1;
+    const GroupMap gm = host_gm(G, gstart_host);
+    const int items = H * W * (C / S);
+    dim3 grid(grid_for(items, 256 * 4, 1024), N);
+    hipStream_t st = (hipStream_t)stream;
+#define RD_APPLY(T_, TWO_) hipLaunchKernelGGL((bn_apply_kernel<T_, TWO_>), grid, dim3(256), 0, st, (const T_*)x, (const T_*)x2, (T_*)out, \
+                                              a, b, c, slope, H * W, C, gm)
+    if (dtype == RD_BF16) { if (x2) RD_APPLY(bf16_t, true); else RD_APPLY(bf16_t, false); }
+    else { if (x2) RD_APPLY(float, true); else RD_APPLY(float, false); }
+#undef RD_APPLY
     return (int)hipGetLastError();
 }
 

@@ -642,5 +642,85 @@ __device__ __forceinline__ void pf_consume(const uint4 (&raw)[NIT][2], const rd_
     pf_consume_fn<T, NIT, 2>(raw, s, k, ig, H, W, yh, xh, [&](int l, const uint4& u) { s_in[l] = u; }, nit);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Plain per-pixel sources in ONE branch-free form (the prefetching loaders):
+//     v = act( sc*x + q*x2 + sh ; slope )        act(v; 1) = v
+//   RAW: sc=1 q=0 sh=0 slope=1 | AFF: slope=1 | AFFACT: slope | BNBWD: x2 = z (ptr2), slope=1
+// Loaders instantiated with NQ=2 always fetch x2; a single-operand source then aliases x2 to x with q=0.
+// Only whole 16-byte channel slots (C % S == 0).
+template <typename T>
+struct PlainSrc {
+    static constexpr int S = Slot<T>::N;
+    const T* p0;
+    const T* p1;
+    int C, n_off;
+    float slope;
+    float sc[S], sh[S], q[S];
+};
+
+template <typename T>
+__device__ __forceinline__ void plain_src_init(PlainSrc<T>& k, const rd_src_t& s, int c) {
+    k.p0 = reinterpret_cast<const T*>(s.ptr) + c;
+    k.p1 = s.mode == RD_SRC_BNBWD ? reinterpret_cast<const T*>(s.ptr2) + c : k.p0;
+    k.C = s.C;
+    k.n_off = s.n_off;
+    k.slope = s.mode == RD_SRC_AFFACT ? s.slope : 1.f;
+}
+
+template <typename T>
+__device__ __forceinline__ void plain_src_coef(PlainSrc<T>& k, const rd_src_t& s, int g_img, int c) {
+    constexpr int S = Slot<T>::N;
+    const int g = s.g_fixed >= 0 ? s.g_fixed : g_img;
+    const bool raw = s.mode == RD_SRC_RAW, bwd = s.mode == RD_SRC_BNBWD;
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        k.sc[e] = raw ? 1.f : s.scale[g * s.C + c + e];
+        k.sh[e] = raw ? 0.f : s.shift[g * s.C + c + e];
+        k.q[e] = bwd ? s.q[g * s.C + c + e] : 0.f;
+    }
+}
+
+template <typename T, int NIT, int NQ>
+__device__ __forceinline__ void pfu_issue(uint4 (&raw)[NIT][NQ], const PlainSrc<T>& k, const ItemGeom<NIT>& ig, int n,
+                                          int H, int W, int yh, int xh, int nit = NIT) {
+    const size_t img = (size_t)(n + k.n_off) * H * W * k.C;
+    const T* b0 = k.p0 + img;
+    const T* b1 = k.p1 + img;
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) {
+        if (b >= nit) break;
+        const int y = min(max(yh + ig.py[b], 0), H - 1), x = min(max(xh + ig.px[b], 0), W - 1);
+        const unsigned off = (unsigned)((y * W + x) * k.C);
+        raw[b][0] = ld16(b0 + off);
+        if constexpr (NQ == 2) raw[b][1] = ld16(b1 + off);
+    }
+}
+
+template <typename T, int NIT, int NQ, typename StoreFn>
+__device__ __forceinline__ void pfu_consume(const uint4 (&raw)[NIT][NQ], const PlainSrc<T>& k, const ItemGeom<NIT>& ig,
+                                            int H, int W, int yh, int xh, StoreFn store, int nit = NIT) {
+    constexpr int S = Slot<T>::N;
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) {
+        if (b >= nit) break;
+        if (ig.lds[b] < 0) continue;
+        const int y = yh + ig.py[b], x = xh + ig.px[b];
+        const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        float v[S];
+        Slot<T>::unpack(raw[b][0], v);
+        if constexpr (NQ == 2) {
+            float zz[S];
+            Slot<T>::unpack(raw[b][1], zz);
+#pragma unroll
+            for (int e = 0; e < S; ++e) v[e] = act_fn(k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e], k.slope);
+        } else {
+#pragma unroll
+            for (int e = 0; e < S; ++e) v[e] = act_fn(k.sc[e] * v[e] + k.sh[e], k.slope);
+        }
+        store(ig.lds[b], in ? Slot<T>::pack(v) : make_uint4(0, 0, 0, 0));
+    }
+}
+
 }  // namespace
 

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int Cout
 // 38 ds_read_u16 + packing per k-step.  Channel rows are padded to 16*odd bytes mod 256 so the 16-lane
 // groups of a b128 read hit 64 distinct banks.  Each wave fills whole channel slots (lanes run over
 // pixels), so the transposing ds_write_b16 of a wave land on consecutive pixels of one row.
-template <int TAPS, int MB, int NB, bool PF>
-__global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+template <int TAPS, int MB, int NB, bool PF, int TS>
+__global__ __launch_bounds__(256 * TS) void wgrad_t_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
     typedef bf16_t T;
     constexpr int S = 8;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -200,23 +200,29 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
     constexpr int KS = 4 / (MB * NB);
     constexpr int ROWS = TH / KS;
     constexpr int NSA = CA / S, NSZ = CZ / S;               // channel slots per tile
-    constexpr int SPA = (NSA + 3) / 4, SPZ = (NSZ + 3) / 4; // slots per wave
+    // TS = 3: the three kernel rows of a 3x3 go to three groups of 4 waves (12 waves share one LDS tile):
+    // 48 accumulator registers per wave instead of 144, so 3 waves per SIMD overlap their LDS->MFMA chains
+    constexpr int NW = 4 * TS, NTH = 256 * TS;
+    constexpr int KHN = (TAPS == 9 ? 3 : 1) / TS, NTAP = TAPS / TS;   // kernel rows / taps per wave
+    constexpr int SPA = (NSA + NW - 1) / NW, SPZ = (NSZ + NW - 1) / NW; // slots per wave (a: low waves, dz: high waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned short* s_a = reinterpret_cast<unsigned short*>(smem);     // [CA][AP]
     unsigned short* s_z = s_a + CA * AP;                                // [CZ][ZP]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index in an SGPR: everything derived from it (slot, BN coefficients, source pointers) is scalar
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, h = lane >> 5;
-    const int kq = wave / (MB * NB), blk = wave % (MB * NB);
+    const int khs = wave >> 2, w4 = wave & 3;
+    const int kq = w4 / (MB * NB), blk = w4 % (MB * NB);
     const int mb = blk / NB, nb = blk % NB;
     const int nbase = blockIdx.y * CZ, cbase = blockIdx.z * CA;
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int H = p.H, W = p.W;
     const GroupMap gm = make_gm(p.gstart, p.G);
 
-    f32x16 acc[TAPS];
+    f32x16 acc[NTAP];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -227,12 +233,42 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
         x0 = (trem % tiles_x) * TW;
     };
     SlotCtx<T> ctx_a[SPA], ctx_z[SPZ];
+    PlainSrc<T> psa[SPA], psz[SPZ];
+    rd_src_t sa[SPA];
+    bool live_a[SPA], live_z[SPZ];
+    int ca[SPA], cz[SPZ];                                   // channel of the slot inside its source
     auto make_ctx = [&](int g) {
+        if constexpr (PF) {
 #pragma unroll
-        for (int q = 0; q < SPA; ++q) slot_ctx<T>(ctx_a[q], p.a, p.na, p.Cin, g, cbase + (wave + 4 * q) * S);
+            for (int q = 0; q < SPA; ++q)
+                if (live_a[q]) plain_src_coef<T>(psa[q], sa[q], g, ca[q]);
 #pragma unroll
-        for (int q = 0; q < SPZ; ++q) slot_ctx<T>(ctx_z[q], &p.dz, 1, p.Cout, g, nbase + (wave + 4 * q) * S);
+            for (int q = 0; q < SPZ; ++q)
+                if (live_z[q]) plain_src_coef<T>(psz[q], p.dz, g, cz[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < SPA; ++q) slot_ctx<T>(ctx_a[q], p.a, p.na, p.Cin, g, cbase + (wave + NW * q) * S);
+#pragma unroll
+            for (int q = 0; q < SPZ; ++q) slot_ctx<T>(ctx_z[q], &p.dz, 1, p.Cout, g, nbase + (NW - 1 - wave + NW * q) * S);
+        }
     };
+    if constexpr (PF) {
+#pragma unroll
+        for (int q = 0; q < SPA; ++q) {
+            const int c = cbase + (wave + NW * q) * S;
+            const int si = (p.na == 1 || c < p.a[0].C) ? 0 : 1;
+            sa[q] = select_src(p.a, si);
+            ca[q] = c - (si ? p.a[0].C : 0);
+            live_a[q] = wave + NW * q < NSA && c < p.Cin;
+            plain_src_init<T>(psa[q], sa[q], ca[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < SPZ; ++q) {
+            cz[q] = nbase + (NW - 1 - wave + NW * q) * S;
+            live_z[q] = NW - 1 - wave + NW * q < NSZ && cz[q] < p.Cout;
+            plain_src_init<T>(psz[q], p.dz, cz[q]);
+        }
+    }
     int g_ctx = 0;
     make_ctx(0);
     // PF (every source is a plain per-pixel read with whole 16-byte channel slots -- the host checks): the
@@ -241,18 +277,16 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
     constexpr int NITA = (PH * PW + 63) / 64, NITZ = (TH * TW) / 64;
     ItemGeom<NITA> iga;
     ItemGeom<NITZ> igz;
-    rd_src_t sa[SPA];
-    bool live_a[SPA], live_z[SPZ];
     uint4 raw_a[SPA][NITA][1], raw_z[SPZ][NITZ][2];
     auto issue = [&](int tile) {
         int n, y0, x0;
         coords(tile, n, y0, x0);
 #pragma unroll
         for (int q = 0; q < SPA; ++q)
-            if (live_a[q]) pf_issue<T, NITA>(raw_a[q], sa[q], ctx_a[q], iga, n, H, W, y0 - HALO, x0 - HALO);
+            if (live_a[q]) pfu_issue<T, NITA>(raw_a[q], psa[q], iga, n, H, W, y0 - HALO, x0 - HALO);
 #pragma unroll
         for (int q = 0; q < SPZ; ++q)
-            if (live_z[q]) pf_issue<T, NITZ>(raw_z[q], p.dz, ctx_z[q], igz, n, H, W, y0, x0);
+            if (live_z[q]) pfu_issue<T, NITZ>(raw_z[q], psz[q], igz, n, H, W, y0, x0);
     };
     if constexpr (PF) {
 #pragma unroll
@@ -269,15 +303,8 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
             igz.px[b] = (short)(pix % TW);
             igz.lds[b] = pix;
         }
-#pragma unroll
-        for (int q = 0; q < SPA; ++q) {
-            sa[q] = select_src(p.a, ctx_a[q].si > 0 ? 1 : 0);
-            live_a[q] = wave + 4 * q < NSA && ctx_a[q].si >= 0;
-        }
-#pragma unroll
-        for (int q = 0; q < SPZ; ++q) live_z[q] = wave + 4 * q < NSZ && ctx_z[q].si >= 0;
         unsigned* z32 = reinterpret_cast<unsigned*>(smem);
-        for (int i = tid; i < (CA * AP + CZ * ZP) / 2; i += 256) z32[i] = 0u;
+        for (int i = tid; i < (CA * AP + CZ * ZP) / 2; i += NTH) z32[i] = 0u;
         if ((int)blockIdx.x < total_tiles) issue(blockIdx.x);
     }
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
@@ -292,9 +319,9 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
         if constexpr (PF) {
 #pragma unroll
             for (int q = 0; q < SPA; ++q) {
-                const int sl = wave + 4 * q;
+                const int sl = wave + NW * q;
                 if (live_a[q])
-                    pf_consume_fn<T, NITA, 1>(raw_a[q], sa[q], ctx_a[q], iga, H, W, y0 - HALO, x0 - HALO, [&](int l, const uint4& u) {
+                    pfu_consume<T, NITA, 1>(raw_a[q], psa[q], iga, H, W, y0 - HALO, x0 - HALO, [&](int l, const uint4& u) {
                         unsigned short* d = s_a + (sl * S) * AP + l;
                         d[0 * AP] = (unsigned short)(u.x & 0xffff); d[1 * AP] = (unsigned short)(u.x >> 16);
                         d[2 * AP] = (unsigned short)(u.y & 0xffff); d[3 * AP] = (unsigned short)(u.y >> 16);
@@ -304,9 +331,9 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
             }
 #pragma unroll
             for (int q = 0; q < SPZ; ++q) {
-                const int sl = wave + 4 * q;
+                const int sl = NW - 1 - wave + NW * q;
                 if (live_z[q])
-                    pf_consume_fn<T, NITZ, 2>(raw_z[q], p.dz, ctx_z[q], igz, H, W, y0, x0, [&](int l, const uint4& u) {
+                    pfu_consume<T, NITZ, 2>(raw_z[q], psz[q], igz, H, W, y0, x0, [&](int l, const uint4& u) {
                         unsigned short* d = s_z + (sl * S) * ZP + l;
                         d[0 * ZP] = (unsigned short)(u.x & 0xffff); d[1 * ZP] = (unsigned short)(u.x >> 16);
                         d[2 * ZP] = (unsigned short)(u.y & 0xffff); d[3 * ZP] = (unsigned short)(u.y >> 16);
@@ -317,7 +344,7 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
         } else {
 #pragma unroll
         for (int q = 0; q < SPA; ++q) {
-            const int sl = wave + 4 * q;
+            const int sl = wave + NW * q;
             if (sl < NSA) {
                 auto map = [&](int pix, int& y, int& x) -> bool {
                     const int py = pix / PW, px = pix - py * PW;
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
         }
 #pragma unroll
         for (int q = 0; q < SPZ; ++q) {
-            const int sl = wave + 4 * q;
+            const int sl = NW - 1 - wave + NW * q;
             if (sl < NSZ) {
                 auto map = [&](int pix, int& y, int& x) -> bool {
                     const int py = pix / TW, px = pix - py * TW;
@@ -363,6 +390,7 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
         }
         const unsigned short* zr = s_z + (mb * 32 + li) * ZP;
         const unsigned short* ar = s_a + (nb * 32 + li) * AP;
+#pragma unroll 1
         for (int rr = 0; rr < ROWS; ++rr) {
             const int row = kq + rr * KS;
 #pragma unroll
@@ -370,7 +398,8 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
                 const int px0 = ks * 16 + 8 * h;                  // this lane-half's 8 pixels (k = 8h+e)
                 const bf16x8 afrag = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(zr + row * TW + px0));
 #pragma unroll
-                for (int kh = 0; kh < (TAPS == 9 ? 3 : 1); ++kh) {
+                for (int kj = 0; kj < KHN; ++kj) {
+                    const int kh = khs * KHN + kj;
                     const unsigned short* wp = ar + (row + kh) * PWL + px0;     // halo coords: input = output + tap
                     const uint4 dq = *reinterpret_cast<const uint4*>(wp);
                     if constexpr (TAPS == 9) {
@@ -378,9 +407,9 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
                         const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(dq.y, dq.x, 16), __builtin_amdgcn_alignbit(dq.z, dq.y, 16),
                                                     __builtin_amdgcn_alignbit(dq.w, dq.z, 16), __builtin_amdgcn_alignbit(d4, dq.w, 16));
                         const uint4 m2 = make_uint4(dq.y, dq.z, dq.w, d4);
-                        acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kh * 3 + 0], 0, 0, 0);
-                        acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kh * 3 + 1], 0, 0, 0);
-                        acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kh * 3 + 2], 0, 0, 0);
+                        acc[kj * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kj * 3 + 0], 0, 0, 0);
+                        acc[kj * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kj * 3 + 1], 0, 0, 0);
+                        acc[kj * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kj * 3 + 2], 0, 0, 0);
                     } else {
                         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[0], 0, 0, 0);
                     }
@@ -389,9 +418,9 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
         }
     }
     if constexpr (KS > 1) {
-        float* s_acc = reinterpret_cast<float*>(smem);     // [(KS-1)][MB*NB][16][64]
+        float* s_acc = reinterpret_cast<float*>(smem) + khs * ((KS - 1) * (MB * NB) * 16 * 64);     // [TS][(KS-1)][MB*NB][16][64]
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
+        for (int tap = 0; tap < NTAP; ++tap) {
             __syncthreads();
             if (kq > 0) {
 #pragma unroll
@@ -409,12 +438,12 @@ __global__ __launch_bounds__(256) void wgrad_t_kernel(const rd_wgrad_t p, int Co
     if (kq == 0) {
         float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap)
+        for (int tap = 0; tap < NTAP; ++tap)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int ccol = cbase + nb * 32 + li;
-                out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
+                out[((size_t)(khs * NTAP + tap) * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
             }
     }
 }
@@ -762,28 +791,37 @@ int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int TAPS, int MB, int NB>
-int launch_wgrad_t(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
+template <int TAPS, int MB, int NB, int TS>
+int launch_wgrad_t_ts(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO;
     constexpr int PWL = (TAPS == 9) ? 40 : 32;
     size_t lds = (size_t)(NB * 32 * (PH * PWL + 8) + MB * 32 * (TH * TW + 8)) * 2;
-    const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * 16 * 64 * sizeof(float);
+    const size_t lds_red = (size_t)TS * (4 / (MB * NB) - 1) * (MB * NB) * 16 * 64 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
     dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB, true, TS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB, false, TS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (wgrad_pf_ok(p))
-        hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, true, TS>), grid, dim3(256 * TS), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     else
-        hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, false, TS>), grid, dim3(256 * TS), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     return (int)hipGetLastError();
+}
+
+template <int TAPS, int MB, int NB>
+int launch_wgrad_t(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
+    static const int ts_env = getenv("RD_WG_TS") ? atoi(getenv("RD_WG_TS")) : 1;
+    if constexpr (TAPS == 9) {
+        if (ts_env == 3) return launch_wgrad_t_ts<TAPS, MB, NB, 3>(p, g, st);
+    }
+    return launch_wgrad_t_ts<TAPS, MB, NB, 1>(p, g, st);
 }
 
 template <typename T>

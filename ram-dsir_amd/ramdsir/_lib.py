@@ -84,6 +84,7 @@ _SIGS = {
     'rd_packed_elems': (i64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'rd_bn_finalize_fwd': (C.c_int, [C.POINTER(RdBnFwd), vp]),
     'rd_bn_finalize_bwd': (C.c_int, [C.POINTER(RdBnBwd), vp]),
+    'rd_bn_apply': (C.c_int, [vp, vp, vp, fp, fp, fp, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
     'rd_up_stats': (C.c_int, [vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
     'rd_up_bwd': (C.c_int, [vp, vp, vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32),
                             C.c_int, vp]),

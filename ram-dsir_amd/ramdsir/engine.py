@@ -182,6 +182,11 @@ class Act:
         # that their readers fetch whole 16-byte channel vectors; producers never write the pad
         self.Cs, self.gCs = cstride or Cc, grad_cstride or Cc
         self.y_buf = plan.alloc_act((N, 2 * H, 2 * W, Cc)) if (up and plan.materialize_up) else None
+        # wide layers: relu(bn(z)) and the BN-backward gradient are stored once (rd_bn_apply) for their many readers
+        mat = (norm is not None and act and plan.materialize_min_c is not None and Cc >= plan.materialize_min_c and
+               (not up or self.y_buf is not None))
+        self.a_buf = plan.alloc_act((N, 2 * H, 2 * W, Cc) if up else (N, H, W, Cc)) if mat else None
+        self.dz_buf = None
         self.buf = plan.alloc_act((N, H, W, self.Cs))
         self.g = None                 # gradient w.r.t. the BN output (hi-res when up)
         self.g_written = False
@@ -223,6 +228,9 @@ class Plan:
         # reads y as a plain BN+ReLU source instead of interpolating t four-taps-per-pixel in every loader:
         # +1 write / +3 reads of y against ~40% less time in those three kernels ('upsample')
         self.materialize_up = False
+        self.materialize_min_c = None   # channels from which BN+ReLU outputs are stored once (rd_bn_apply)
+        self.materialize_dz_min_c = None  # ... and from which the BN-backward gradients dz are
+        self._unit = {}
         self.nodes = []
         self.keep = []
         self._stat_chunks = []
@@ -272,19 +280,36 @@ class Plan:
         self.nodes.append(node)
         return out
 
+    def unit_coef(self, Cc):
+        """(ones, zeros) [G][C] coefficient rows: identity BN for readers of an already materialised tensor."""
+        if Cc not in self._unit:
+            self._unit[Cc] = (self.alloc_f32(self.G * Cc).fill_(1.0), self.alloc_f32(self.G * Cc))
+        return self._unit[Cc]
+
     def slot_channels(self):
         return 8 if self.dtype == torch.bfloat16 else 4
 
     # ---- descriptor helpers
     def _src(self, a, mode, n_off, g_fixed):
         s = L.RdSrc()
-        if mode == L.SRC_UP and a.y_buf is not None:
-            s.ptr, mode = a.y_buf.data_ptr(), L.SRC_AFFACT
+        slope = self.slope
+        if a.a_buf is not None and mode in (L.SRC_AFFACT, L.SRC_UP, L.SRC_POOL):
+            # stored relu(bn(.)): read as is; the pooled read keeps its 2x2 max with identity coefficients
+            s.ptr = a.a_buf.data_ptr()
+            if mode == L.SRC_POOL:
+                one, zero = self.unit_coef(a.C)
+                s.scale, s.shift, slope = one.data_ptr(), zero.data_ptr(), 1.0
+                g_fixed = 0
+            else:
+                mode = L.SRC_RAW
         else:
-            s.ptr = a.buf.data_ptr()
-        if mode != L.SRC_RAW:
-            s.scale, s.shift = a.scale.data_ptr(), a.shift.data_ptr()
-        s.mode, s.C, s.slope, s.n_off, s.g_fixed = mode, a.Cs, self.slope, n_off, g_fixed
+            if mode == L.SRC_UP and a.y_buf is not None:
+                s.ptr, mode = a.y_buf.data_ptr(), L.SRC_AFFACT
+            else:
+                s.ptr = a.buf.data_ptr()
+            if mode != L.SRC_RAW:
+                s.scale, s.shift = a.scale.data_ptr(), a.shift.data_ptr()
+        s.mode, s.C, s.slope, s.n_off, s.g_fixed = mode, a.Cs, slope, n_off, g_fixed
         return s
 
     def _dz_src(self, node):
@@ -292,7 +317,9 @@ class Plan:
         o = node.out
         s = L.RdSrc()
         s.C, s.slope, s.n_off, s.g_fixed = (o.gCs if o.norm is None else o.C), 0.0, 0, -1
-        if o.norm is None or o.up:
+        if o.dz_buf is not None:
+            s.ptr, s.mode = o.dz_buf.data_ptr(), L.SRC_RAW
+        elif o.norm is None or o.up:
             s.ptr, s.mode = (o.dt_buf if o.up else o.grad_buf()).data_ptr(), L.SRC_RAW
         else:
             s.ptr, s.ptr2, s.mode = o.grad_buf().data_ptr(), o.buf.data_ptr(), L.SRC_BNBWD
@@ -341,6 +368,11 @@ class Plan:
                 self.keep.append(b)
                 o.bn_desc = b
                 self.fwd.append((lib.rd_bn_finalize_fwd, (C.byref(b),)))
+                if o.a_buf is not None:
+                    src = o.y_buf if o.up else o.buf
+                    Hh, Ww = (2 * H, 2 * W) if o.up else (H, W)
+                    self.fwd.append((lib.rd_bn_apply, (src.data_ptr(), None, o.a_buf.data_ptr(), o.scale.data_ptr(), None, o.shift.data_ptr(),
+                                                       self.slope, N, Hh, Ww, o.C, self.G, self.gs_arr, dt)))
         if not self.training:
             return
         # ---------------- backward, reverse order; bwd_split[m] = index where module m's backward starts
@@ -364,6 +396,10 @@ class Plan:
                 q.C, q.G = o.C, self.G
                 self.keep.append(q)
                 self.bwd.append((lib.rd_bn_finalize_bwd, (C.byref(q),)))
+                if (not o.up and self.materialize_dz_min_c is not None and o.C >= self.materialize_dz_min_c):
+                    o.dz_buf = self.alloc_act((N, H, W, o.C))
+                    self.bwd.append((lib.rd_bn_apply, (o.grad_buf().data_ptr(), o.buf.data_ptr(), o.dz_buf.data_ptr(), o.P.data_ptr(),
+                                                       o.Q.data_ptr(), o.R.data_ptr(), 1.0, N, H, W, o.C, self.G, self.gs_arr, dt)))
                 if o.up:
                     o.dt_buf = self.alloc_act((N, H, W, o.C))
                     self.bwd.append((lib.rd_up_bwd, (o.grad_buf().data_ptr(), o.buf.data_ptr(), o.dt_buf.data_ptr(), o.P.data_ptr(),

@@ -10,6 +10,7 @@ launch list on one HIP stream, optionally captured into a hipGraph:
 Only the flag combination that runs in the reference (--ram --rec [--consistency]) exists here.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -33,6 +34,10 @@ class TrainStep:
         # ---- graphs
         self.seg = E.Plan(bank, dtype, 2 * B, [0, B, 2 * B], slope=slope)
         self.seg.pad_narrow = self.seg.materialize_up = True
+        min_c = int(os.environ.get('RD_MAT_MINC', '0'))
+        self.seg.materialize_min_c = min_c if min_c > 0 else None
+        min_dz = int(os.environ.get('RD_MAT_DZ_MINC', '64'))
+        self.seg.materialize_dz_min_c = min_dz if min_dz > 0 else None
         slot = self.seg.slot_channels()
         self.x = E.Act(self.seg, 2 * B, H, W, in_channels, name='input', cstride=slot if in_channels < slot else None)
         self.feats = E.build_encoder(self.seg, self.x, n=n)
@@ -42,6 +47,8 @@ class TrainStep:
             gs.append(gs[-1] + b)
         self.rec = E.Plan(bank, dtype, B, gs, slope=slope)
         self.rec.pad_narrow = self.rec.materialize_up = True
+        self.rec.materialize_min_c = self.seg.materialize_min_c
+        self.rec.materialize_dz_min_c = self.seg.materialize_dz_min_c
         self.rec_logits = E.build_rec_decoder(self.rec, self.feats[4], n_off=B, g_fixed=1, domains=list(range(len(batch_sizes))),
                                               n=n, num_classes=in_channels)
         self.seg.build(self.wpack)

@@ -3,7 +3,8 @@ import csv, glob, collections, os, sys
 for d in sorted(glob.glob(sys.argv[1])):
     if not os.path.isdir(d): continue
     tr = list(csv.DictReader(open(d + '/pmc_1/p_kernel_trace.csv')))
-    last = tr[-1]
+    want = sys.argv[2] if len(sys.argv) > 2 else ''
+    last = [r for r in tr if want in r['Kernel_Name']][-1]
     kname = last['Kernel_Name']; grid = (last['Grid_Size_X'], last['Grid_Size_Y'], last['Grid_Size_Z'])
     durs = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in tr if r['Kernel_Name'] == kname and (r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z']) == grid]
     m = collections.defaultdict(list)
