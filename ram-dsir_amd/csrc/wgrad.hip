@@ -677,25 +677,38 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void wgrad_c16_kernel(const rd_wgr
 }
 
 // block = 32 outputs x 8 split lanes: each thread sums every 8th split, LDS folds the 8 lanes in a fixed order
+template <int OB>                                         // outputs per block; 256/OB threads share one output's splits
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dW, int nsplit, int taps, int Cout,
                                                            int Cin, int CoutPadW, int CinPadW, float beta) {
-    __shared__ float s[8][32];
+    constexpr int QL = 256 / OB;
+    __shared__ float s[QL][OB];
     const int total = taps * Cout * Cin;
-    const int o = threadIdx.x & 31, ql = threadIdx.x >> 5;
+    const int o = threadIdx.x % OB, ql = threadIdx.x / OB;
     const size_t stride = (size_t)taps * CoutPadW * CinPadW;
-    for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
+    for (int base = blockIdx.x * OB; base < total; base += gridDim.x * OB) {
         const int i = base + o;
         float acc = 0.f;
         int c = 0, n = 0, tap = 0;
         if (i < total) {
             c = i % Cin; n = (i / Cin) % Cout; tap = i / (Cin * Cout);
             const float* src = partial + ((size_t)tap * CoutPadW + n) * CinPadW + c;
-            for (int k = ql; k < nsplit; k += 8) acc += src[k * stride];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four loads in flight per thread
+            int k = ql;
+            for (; k + 3 * QL < nsplit; k += 4 * QL) {
+                a0 += src[(size_t)k * stride];
+                a1 += src[(size_t)(k + QL) * stride];
+                a2 += src[(size_t)(k + 2 * QL) * stride];
+                a3 += src[(size_t)(k + 3 * QL) * stride];
+            }
+            for (; k < nsplit; k += QL) a0 += src[(size_t)k * stride];
+            acc = (a0 + a1) + (a2 + a3);
         }
         s[ql][o] = acc;
         __syncthreads();
         if (ql == 0 && i < total) {
-            const float v = ((s[0][o] + s[1][o]) + (s[2][o] + s[3][o])) + ((s[4][o] + s[5][o]) + (s[6][o] + s[7][o]));
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < QL; ++q) v += s[q][o];
             float* d = dW + ((size_t)n * Cin + c) * taps + tap;
             *d = (beta != 0.f ? beta * *d : 0.f) + v;
         }
@@ -815,12 +828,10 @@ int launch_wgrad_t_ts(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// TS = 3 (12 waves, one kernel row per group of 4) measured slower than TS = 1 on every layer of the U-Net at
+// 400x400 (the 170-register cap spills, and the fill is still one lock-step phase): kept in the kernel, not instantiated
 template <int TAPS, int MB, int NB>
 int launch_wgrad_t(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
-    static const int ts_env = getenv("RD_WG_TS") ? atoi(getenv("RD_WG_TS")) : 1;
-    if constexpr (TAPS == 9) {
-        if (ts_env == 3) return launch_wgrad_t_ts<TAPS, MB, NB, 3>(p, g, st);
-    }
     return launch_wgrad_t_ts<TAPS, MB, NB, 1>(p, g, st);
 }
 
@@ -849,10 +860,17 @@ int dispatch_wgrad(const rd_wgrad_t& p, hipStream_t st) {
     }
     if (e) return e;
     const int total = p.taps * p.Cout * p.Cin;
-    int blocks = (total + 31) / 32;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
-                       g.CoutPadW, g.CinPadW, p.beta);
+    // many splits of a small filter (the 16/32-channel layers): 8 outputs x 32 split lanes per block
+    if (g.nsplit >= 128 && total <= 16384) {
+        const int blocks = (total + 7) / 8;
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(blocks), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
+                           g.CoutPadW, g.CinPadW, p.beta);
+    } else {
+        int blocks = (total + 31) / 32;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
+                           g.CoutPadW, g.CinPadW, p.beta);
+    }
     return (int)hipGetLastError();
 }
 
