@@ -26,8 +26,12 @@ for p in (ROOT, os.path.join(ROOT, 'ram-dsir_amd')):
 import numpy as np
 import torch
 
-DOMINANT = 'conv_small_kernel<bf16,9,*>'   # largest share of step time in profiles/ (3x3 layers with <=32 channels)
+# Largest share of step time in profiles/ (rocprofv3 --stats): the 3x3 convolutions with 64-wide output-channel tiles
+# (>= 64-channel layers, forward and dgrad) = conv_pf_kernel<bf16,9,2,*> (chunk-pipelined) + conv_kernel<bf16,9,2>.
+DOMINANT = 'conv_kernel<bf16,9,2>'
+DOMINANT_SYMBOLS = ('conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E')   # mangled-name fragments (profiles/)
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF (no sparsity)
 
 
 def synth_inputs(B, S, rank, device):
@@ -69,31 +73,45 @@ def init_weights(bank):
 
 
 def dominant_kernel_roofline(ts):
-    """One eager step with HIP events (recorded on the launch stream) around every launch of the dominant
-    kernel template; algorithmic bytes of each launch come from its descriptor (engine.Plan._conv_meta)."""
-    from ramdsir import engine as E
-    stream = torch.cuda.current_stream()
+    """One eager step, launched exactly like the captured one (weight-gradient kernels forked to the side stream, so
+    the timed launches see the same contention as inside the hipGraph), with HIP events recorded on the launch
+    stream around every launch of the dominant kernel family; the algorithmic bytes / flops of each launch come
+    from its descriptor (engine.Plan._conv_meta)."""
+    main, side = torch.cuda.current_stream(), ts.side
     ts.zero()
     evs, nbytes, flops = [], 0, 0
-    for op in ts._ops:
-        meta = op[2] if len(op) > 2 else None
-        hit = meta is not None and meta.get('kernel') == DOMINANT
-        if hit:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-        err = op[0](*op[1], stream.cuda_stream)
-        assert err == 0
-        if hit:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record(stream)
-            evs.append((e0, e1))
-            nbytes += meta['bytes']
-            flops += meta['flops']
+    for seg in (ts.seg_a, ts.seg_b, ts.seg_c):
+        forked = False
+        for op in seg:
+            meta = op[2] if len(op) > 2 else None
+            if meta is not None and meta.get('side') and ts.fork:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                assert op[0](*op[1], side.cuda_stream) == 0
+                forked = True
+                continue
+            hit = meta is not None and meta.get('kernel') == DOMINANT
+            if hit:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+            assert op[0](*op[1], main.cuda_stream) == 0
+            if hit:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(main)
+                evs.append((e0, e1))
+                nbytes += meta['bytes']
+                flops += meta['flops']
+        if forked:
+            main.wait_stream(side)
     torch.cuda.synchronize()
     total_ms = sum(a.elapsed_time(b) for a, b in evs)
     n = len(evs)
-    achieved = nbytes / (total_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC counters of the same kernel template: collected OFFLINE with
+    gbs = nbytes / (total_ms * 1e-3) / 1e9
+    tfs = flops / (total_ms * 1e-3) / 1e12
+    # which roof binds: arithmetic intensity of the launches against the ridge point of the chip
+    intensity, ridge = flops / nbytes, MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    # HBM bytes per launch from the PMC counters of the same kernels: collected OFFLINE with
     # `rocprofv3 -i scripts/pmc_hbm.txt` (separate FETCH_SIZE / WRITE_SIZE passes) on this command and corrected as
     # MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for 16-B/lane streaming reads, KB -> B); see profiles/README.md
     traffic = None
@@ -101,9 +119,14 @@ def dominant_kernel_roofline(ts):
     if os.path.exists(tpath):
         with open(tpath) as f:
             traffic = int(json.load(f)['traffic_bytes_per_launch'])
-    return dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=traffic, kernel=DOMINANT, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
-                avg_algorithmic_bytes=int(nbytes / n), achieved_tflops=round(flops / (total_ms * 1e-3) / 1e12, 1))
+    if intensity >= ridge:
+        out = dict(bound='mfma', achieved=round(tfs, 1), peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tfs / MFMA_PEAK_TFLOPS, 4))
+    else:
+        out = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
+    out.update(traffic=traffic, kernel=DOMINANT, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
+               avg_algorithmic_bytes=int(nbytes / n), avg_flops=int(flops / n), flop_per_byte=round(intensity, 1),
+               achieved_gbs=round(gbs, 1), achieved_tflops=round(tfs, 1))
+    return out
 
 
 def cpu_baseline(host_inputs, bs):
