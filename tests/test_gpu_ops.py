@@ -57,6 +57,10 @@ FWD_CASES = [
     ('up32_32', 9, [(L.SRC_UP, 32)], 32, 2, 16, 24, [0, 2], 0.0),
     ('cat16_up16_32', 9, [(L.SRC_AFFACT, 16), (L.SRC_UP, 16)], 32, 2, 16, 40, [0, 1, 2], 0.0),
     ('cat64_up64_128', 9, [(L.SRC_AFFACT, 64), (L.SRC_UP, 64)], 128, 2, 10, 12, [0, 1, 2], 0.0),
+    # concat of two plain sources (the stored-upsample form of ConvU.conv3): prefetching / chunk-pipelined loaders
+    ('cat16_aff16_16', 9, [(L.SRC_AFFACT, 16), (L.SRC_AFFACT, 16)], 16, 2, 16, 40, [0, 1, 2], 0.0),
+    ('cat64_aff64_128', 9, [(L.SRC_AFFACT, 64), (L.SRC_AFFACT, 64)], 128, 3, 10, 12, [0, 1, 3], 0.0),
+    ('raw128_64', 9, [(L.SRC_RAW, 128)], 64, 2, 9, 33, [0, 1, 2], 0.0),
     ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, [0, 1, 2], 0.0),
     ('out16_3', 9, [(L.SRC_AFFACT, 16)], 3, 3, 8, 32, [0, 1, 2, 3], 0.0),
     ('c256_256', 9, [(L.SRC_AFFACT, 256)], 256, 2, 6, 7, [0, 1, 2], 0.0),
@@ -109,6 +113,8 @@ GRAD_CASES = [
     ('upy32', 9, [(L.DST_UPY, 32, 1)], 32, 2, 12, 16, [0, 1, 2], 0.0, 0),
     ('cat16_upy16', 9, [(L.DST_PLAIN, 16, 1), (L.DST_UPY, 16, 1)], 32, 2, 16, 40, [0, 1, 2], 0.0, 0),
     ('cat64_upy64', 9, [(L.DST_PLAIN, 64, 1), (L.DST_UPY, 64, 1)], 128, 2, 10, 12, [0, 1, 2], 0.0, 0),
+    ('cat16_plain16', 9, [(L.DST_PLAIN, 16, 1), (L.DST_PLAIN, 16, 1)], 16, 2, 16, 40, [0, 1, 2], 0.0, 0),
+    ('cat64_plain64_acc', 9, [(L.DST_PLAIN, 64, 1), (L.DST_PLAIN, 64, 1)], 128, 2, 10, 12, [0, 1, 2], 0.0, 1),
     ('k1_plain128', 1, [(L.DST_PLAIN, 128, 1)], 64, 2, 10, 34, [0, 1, 2], 0.0, 0),
     ('from_out2', 9, [(L.DST_PLAIN, 32, 1)], 2, 2, 16, 33, [0, 1, 2], 0.0, 0),
 ]
@@ -218,6 +224,9 @@ WG_CASES = [
     ('pool16_32', 9, [(L.SRC_POOL, 16)], 32, 2, 12, 20, 1),
     ('cat16_up16_32', 9, [(L.SRC_AFFACT, 16), (L.SRC_UP, 16)], 32, 2, 16, 40, 1),
     ('c128_128', 9, [(L.SRC_AFFACT, 128)], 128, 2, 10, 12, 1),
+    ('cat16_aff16_16', 9, [(L.SRC_AFFACT, 16), (L.SRC_AFFACT, 16)], 16, 2, 16, 40, 1),
+    ('cat64_aff64_64_rawdz', 9, [(L.SRC_AFFACT, 64), (L.SRC_AFFACT, 64)], 64, 3, 10, 12, 0),
+    ('c64_64_many_tiles', 9, [(L.SRC_AFFACT, 64)], 64, 4, 40, 70, 1),
     ('c256_128', 9, [(L.SRC_AFFACT, 256)], 128, 2, 6, 7, 1),
     ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, 0),
     ('k1_128_64', 1, [(L.SRC_AFFACT, 128)], 64, 2, 10, 34, 0),
@@ -270,6 +279,101 @@ def test_wgrad(case, dtype):
     L.check(L.lib().rd_wgrad(C.byref(p), U.DT[dtype][0], None), name)
     torch.cuda.synchronize()
     U.assert_close(dW.cpu() - old, w.grad, dtype, name)
+
+
+# ------------------------------------------------------------------------------------ padded narrow tensors, rd_bn_apply
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_padded_narrow_sources(dtype):
+    """The 3-channel image and the 2-channel dlogits stored with the channel vector padded to one 16-byte slot
+    (descriptor C = slot width, conv Cin = real width): forward, dgrad and wgrad must ignore the pad."""
+    S = 8 if dtype == 'bf16' else 4
+    gen = torch.Generator().manual_seed(77)
+    keep = U.Keep()
+    N, H, W, gstart = 2, 20, 36, [0, 1, 2]
+    # forward: image 3 -> 16
+    x = U.rnd(torch.randn(N, 3, H, W, generator=gen), dtype)
+    xpad = torch.cat([x, torch.zeros(N, S - 3, H, W)], 1)
+    w = U.rnd(torch.randn(16, 3, 3, 3, generator=gen) / 5, dtype)
+    bias = 0.1 * torch.randn(16, generator=gen)
+    ref = F.conv2d(x, w, bias, padding=1)
+    src = U.make_src(keep, xpad, L.SRC_RAW, dtype)
+    p = _conv_desc(keep, [src], w, bias, N, H, W, gstart, dtype, 9)
+    out = torch.full((N, H, W, 16), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
+    p.emode, p.out, p.stats = 0, out.data_ptr(), None
+    L.check(L.lib().rd_conv(C.byref(p), U.DT[dtype][0], None), 'padded fwd')
+    torch.cuda.synchronize()
+    U.assert_close(U.from_nhwc(out), ref, dtype, 'padded fwd')
+    # wgrad of the same conv (a padded) and of out1 (dz padded): 16 -> 2
+    dz = U.rnd(torch.randn(N, 16, H, W, generator=gen), dtype)
+    wz = torch.zeros(16, 3, 3, 3, requires_grad=True)
+    (F.conv2d(x, wz, None, padding=1) * dz).sum().backward()
+    g = L.RdWgrad()
+    g.a[0], g.dz = src, U.make_src(keep, dz, L.SRC_RAW, dtype)
+    g.na, g.taps, g.N, g.H, g.W, g.Cin, g.Cout, g.G = 1, 9, N, H, W, 3, 16, 2
+    g.gstart = L.gstart_array(gstart)
+    part = torch.empty(L.lib().rd_wgrad_workspace(C.byref(g), U.DT[dtype][0]) // 4, device=U.dev())
+    dW = torch.zeros(16, 3, 3, 3, device=U.dev())
+    g.partial, g.dW, g.beta = part.data_ptr(), dW.data_ptr(), 0.0
+    L.check(L.lib().rd_wgrad(C.byref(g), U.DT[dtype][0], None), 'padded wgrad a')
+    torch.cuda.synchronize()
+    U.assert_close(dW.cpu(), wz.grad, dtype, 'padded wgrad a')
+    a16 = U.rnd(torch.randn(N, 16, H, W, generator=gen), dtype)
+    dl = U.rnd(torch.randn(N, 2, H, W, generator=gen), dtype)
+    dlpad = torch.cat([dl, torch.zeros(N, S - 2, H, W)], 1)
+    w2 = torch.zeros(2, 16, 3, 3, requires_grad=True)
+    (F.conv2d(a16, w2, None, padding=1) * dl).sum().backward()
+    g2 = L.RdWgrad()
+    g2.a[0], g2.dz = U.make_src(keep, a16, L.SRC_RAW, dtype), U.make_src(keep, dlpad, L.SRC_RAW, dtype)
+    g2.na, g2.taps, g2.N, g2.H, g2.W, g2.Cin, g2.Cout, g2.G = 1, 9, N, H, W, 16, 2, 2
+    g2.gstart = L.gstart_array(gstart)
+    part2 = torch.empty(L.lib().rd_wgrad_workspace(C.byref(g2), U.DT[dtype][0]) // 4, device=U.dev())
+    dW2 = torch.zeros(2, 16, 3, 3, device=U.dev())
+    g2.partial, g2.dW, g2.beta = part2.data_ptr(), dW2.data_ptr(), 0.0
+    L.check(L.lib().rd_wgrad(C.byref(g2), U.DT[dtype][0], None), 'padded wgrad dz')
+    torch.cuda.synchronize()
+    U.assert_close(dW2.cpu(), w2.grad, dtype, 'padded wgrad dz')
+    # dgrad from the padded dlogits into a 16-channel producer (no BN: plain gradient)
+    wt = U.rnd(torch.randn(2, 16, 3, 3, generator=gen) / 12, dtype)
+    yv = a16.clone().requires_grad_(True)
+    (F.conv2d(yv, wt, None, padding=1) * dl).sum().backward()
+    pd = _conv_desc(keep, [U.make_src(keep, dlpad, L.SRC_RAW, dtype)], wt, None, N, H, W, gstart, dtype, 9, transpose=True)
+    pd.emode, pd.c_split = 1, 16
+    gbuf = torch.full((N, H, W, 16), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
+    d = L.RdDst()
+    d.g, d.kind, d.act, d.accumulate, d.Cd, d.slope, d.n_off, d.g_fixed = gbuf.data_ptr(), L.DST_PLAIN, 0, 0, 16, 0.0, 0, -1
+    pd.dst[0] = d
+    pd.dst[1].kind = L.DST_NONE
+    L.check(L.lib().rd_conv(C.byref(pd), U.DT[dtype][0], None), 'padded dgrad')
+    torch.cuda.synchronize()
+    U.assert_close(U.from_nhwc(gbuf), yv.grad, dtype, 'padded dgrad', scale=2.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_bn_apply(dtype):
+    """out = act(a*x + b*x2 + c): the stored relu(bn(z)) and the stored BN-backward gradient P*g + Q*z + R."""
+    gen = torch.Generator().manual_seed(78)
+    N, Cc, H, W, gstart = 3, 64, 7, 9, [0, 1, 3]
+    x = U.rnd(torch.randn(N, Cc, H, W, generator=gen), dtype)
+    z = U.rnd(torch.randn(N, Cc, H, W, generator=gen), dtype)
+    a, c = _params(2, Cc, gen)
+    b = 0.1 * torch.randn(2, Cc, generator=gen)
+    gs = L.gstart_array(gstart)
+    xd, zd = U.nhwc(x, dtype), U.nhwc(z, dtype)
+    ad, bd, cd = U.fdev(a), U.fdev(b), U.fdev(c)
+    out = torch.full((N, H, W, Cc), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
+    for slope in (0.0, 0.01):
+        L.check(L.lib().rd_bn_apply(L.ptr(xd), None, L.ptr(out), L.ptr(ad), None, L.ptr(cd), slope, N, H, W, Cc, 2, gs,
+                                    U.DT[dtype][0], None), 'apply fwd')
+        torch.cuda.synchronize()
+        ref = U.act(x * U.group_rows(a, gstart, N) + U.group_rows(c, gstart, N), slope)
+        U.assert_close(U.from_nhwc(out), ref, dtype, 'bn_apply fwd')
+    L.check(L.lib().rd_bn_apply(L.ptr(xd), L.ptr(zd), L.ptr(out), L.ptr(ad), L.ptr(bd), L.ptr(cd), 1.0, N, H, W, Cc, 2, gs,
+                                U.DT[dtype][0], None), 'apply bwd')
+    torch.cuda.synchronize()
+    ref = x * U.group_rows(a, gstart, N) + z * U.group_rows(b, gstart, N) + U.group_rows(c, gstart, N)
+    U.assert_close(U.from_nhwc(out), ref, dtype, 'bn_apply bwd')
+    assert L.lib().rd_bn_apply(L.ptr(xd), L.ptr(zd), L.ptr(out), L.ptr(ad), None, L.ptr(cd), 1.0, N, H, W, Cc, 2, gs,
+                               U.DT[dtype][0], None) != 0           # x2 without its coefficient row: rejected
 
 
 # ------------------------------------------------------------------------------------ BN finalize
