@@ -448,6 +448,183 @@ __global__ __launch_bounds__(256 * TS) void wgrad_t_kernel(const rd_wgrad_t p, i
     }
 }
 
+// ------------------------------------------------------------------------------------ bf16 wgrad, hardware transpose read
+// Same blocks / waves / MFMAs / split-K as wgrad_t_kernel, but the LDS tiles keep the memory layout [pixel][channel]:
+// the fill is ONE ds_write_b128 per 16-byte channel slot (lanes run slot-fastest: 64-128 contiguous bytes per pixel
+// from HBM and into LDS) instead of eight ds_write_b16 + eight extractions, and the K = pixels fragments of both
+// MFMA operands come from gfx950's transposing LDS read: in a 16-lane group lane i points ds_read_b64_tr_b16 at
+// pixel (i/4), channels 4*(i%4)..+3 of a 4-pixel x 16-channel block and receives channel i of the four pixels
+// (probe: scripts/probe/tr_probe.hip).  The three horizontal taps of a kernel row share three such reads of 4
+// pixels each (12 >= 8+2), the odd tap is 4 v_alignbit as before.  Row pitches are 144 B (64 channels) / 96 B (32):
+// the four pixel rows of a group then fall into disjoint 8-bank spans.  Plain sources only (PlainSrc), tile-ahead prefetch.
+typedef __attribute__((ext_vector_type(4))) short tr_s4;
+typedef __attribute__((address_space(3))) tr_s4 tr_lds_s4;
+__device__ __forceinline__ uint2 lds_tr(const char* p) {
+    const tr_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_s4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <int TAPS, int MB, int NB, int NQZ>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+    typedef bf16_t T;
+    constexpr int S = 8;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int NPIX = PH * PW;
+    constexpr int CA = NB * 32, CZ = MB * 32;
+    constexpr int PA = CA * 2 + (CA == 32 ? 32 : 16), PZ = CZ * 2 + (CZ == 32 ? 32 : 16);   // bytes per pixel row
+    constexpr int KS = 4 / (MB * NB);
+    constexpr int ROWS = TH / KS;
+    constexpr int NSA = CA / S, NSZ = CZ / S;               // channel slots per pixel
+    constexpr int NITA = (NPIX * NSA + 255) / 256, NITZ = (TH * TW * NSZ) / 256;
+    constexpr int KW = (TAPS == 9) ? 3 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_a = smem;                                       // [NPIX + 4][PA]
+    char* s_z = smem + (NPIX + 4) * PA;                     // [TH*TW][PZ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int kq = wave / (MB * NB), blk = wave % (MB * NB);
+    const int mb = blk / NB, nb = blk % NB;
+    const int nbase = blockIdx.y * CZ, cbase = blockIdx.z * CA;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int H = p.H, W = p.W;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto coords = [&](int tile, int& n, int& y0, int& x0) {
+        n = tile / (tiles_x * tiles_y);
+        const int trem = tile - n * tiles_x * tiles_y;
+        y0 = (trem / tiles_x) * TH;
+        x0 = (trem % tiles_x) * TW;
+    };
+    // ---- fill mapping: thread -> one channel slot of `a` and one of `dz` (slot fastest), pixels strided
+    const int sla = tid % NSA, slz = tid % NSZ;
+    const int ca_abs = cbase + sla * S, cz_abs = nbase + slz * S;
+    const int sia = (p.na == 1 || ca_abs < p.a[0].C) ? 0 : 1;
+    const rd_src_t sda = select_src(p.a, sia);
+    const int ca = ca_abs - (sia ? p.a[0].C : 0);
+    const bool live_a = ca_abs < p.Cin, live_z = cz_abs < p.Cout;
+    PlainSrc<T> psa, psz;
+    plain_src_init<T>(psa, sda, live_a ? ca : 0);
+    plain_src_init<T>(psz, p.dz, live_z ? cz_abs : 0);
+    ItemGeom<NITA> iga;
+    ItemGeom<NITZ> igz;
+#pragma unroll
+    for (int b = 0; b < NITA; ++b) {
+        const int pix = tid / NSA + (256 / NSA) * b, py = pix / PW, px = pix - py * PW;
+        iga.py[b] = (short)py;
+        iga.px[b] = (short)px;
+        iga.lds[b] = pix < NPIX ? pix * PA + sla * 16 : -1;
+    }
+#pragma unroll
+    for (int b = 0; b < NITZ; ++b) {
+        const int pix = tid / NSZ + (256 / NSZ) * b;
+        igz.py[b] = (short)(pix / TW);
+        igz.px[b] = (short)(pix % TW);
+        igz.lds[b] = pix * PZ + slz * 16;
+    }
+    uint4 raw_a[NITA][1], raw_z[NITZ][NQZ];
+    auto issue = [&](int tile) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+        if (live_a) pfu_issue<T, NITA>(raw_a, psa, iga, n, H, W, y0 - HALO, x0 - HALO);
+        if (live_z) pfu_issue<T, NITZ>(raw_z, psz, igz, n, H, W, y0, x0);
+    };
+    {
+        uint4* z4 = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < ((NPIX + 4) * PA + TH * TW * PZ) / 16; i += 256) z4[i] = make_uint4(0, 0, 0, 0);
+    }
+    int g_ctx = -1;
+    if ((int)blockIdx.x < total_tiles) issue(blockIdx.x);
+
+    // ---- fragment addressing: 16-lane group gq = lane >> 4 -> 16-channel sub-block (gq & 1), K half (gq >> 1)
+    const int i16 = lane & 15, gq = lane >> 4;
+    const int zoff = ((gq >> 1) * 8 + (i16 >> 2)) * PZ + (mb * 32 + (gq & 1) * 16 + (i16 & 3) * 4) * 2;
+    const int aoff = ((gq >> 1) * 8 + (i16 >> 2)) * PA + (nb * 32 + (gq & 1) * 16 + (i16 & 3) * 4) * 2;
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+        const int g = group_of(gm, n);
+        if (g != g_ctx) {
+            if (live_a) plain_src_coef<T>(psa, sda, g, ca);
+            if (live_z) plain_src_coef<T>(psz, p.dz, g, cz_abs);
+            g_ctx = g;
+        }
+        __syncthreads();
+        if (live_a)
+            pfu_consume<T, NITA, 1>(raw_a, psa, iga, H, W, y0 - HALO, x0 - HALO,
+                                    [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
+        if (live_z)
+            pfu_consume<T, NITZ, NQZ>(raw_z, psz, igz, H, W, y0, x0,
+                                      [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_z + l) = u; });
+        __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int row = kq + rr * KS;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* zp = s_z + zoff + (row * TW + ks * 16) * PZ;
+                const uint2 z0 = lds_tr(zp), z1 = lds_tr(zp + 4 * PZ);
+                const bf16x8 afrag = __builtin_bit_cast(bf16x8, make_uint4(z0.x, z0.y, z1.x, z1.y));
+#pragma unroll
+                for (int kh = 0; kh < KW; ++kh) {
+                    const char* ap = s_a + aoff + ((row + kh) * PW + ks * 16) * PA;     // halo coords: input = output + tap
+                    const uint2 a0 = lds_tr(ap), a1 = lds_tr(ap + 4 * PA);
+                    if constexpr (TAPS == 9) {
+                        const uint2 a2 = lds_tr(ap + 8 * PA);
+                        const uint4 dq = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                        const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(a0.y, a0.x, 16), __builtin_amdgcn_alignbit(a1.x, a0.y, 16),
+                                                    __builtin_amdgcn_alignbit(a1.y, a1.x, 16), __builtin_amdgcn_alignbit(a2.x, a1.y, 16));
+                        const uint4 m2 = make_uint4(a0.y, a1.x, a1.y, a2.x);
+                        acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kh * 3 + 0], 0, 0, 0);
+                        acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kh * 3 + 1], 0, 0, 0);
+                        acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kh * 3 + 2], 0, 0, 0);
+                    } else {
+                        const uint4 dq = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[0], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (KS > 1) {
+        float* s_acc = reinterpret_cast<float*>(smem);     // [(KS-1)][MB*NB][16][64]
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            __syncthreads();
+            if (kq > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_acc[(((kq - 1) * (MB * NB) + blk) * 16 + r) * 64 + lane] = acc[tap][r];
+            }
+            __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int k2 = 0; k2 < KS - 1; ++k2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tap][r] += s_acc[((k2 * (MB * NB) + blk) * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (kq == 0) {
+        float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int ccol = cbase + nb * 32 + li;
+                out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------ bf16 wgrad, <= 32 channels
 // The HBM-bound layers (16/32 channels at 400x400 / 200x200): v_mfma_f32_16x16x32_bf16 with K = the 32 pixels
 // of one tile row, 16x16 channel blocks (no padding of 16-channel layers to 32), 4 accumulator VGPRs per tap
@@ -804,6 +981,29 @@ int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+template <int TAPS, int MB, int NB>
+int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    size_t lds = (size_t)(PH * PW + 4) * (NB * 64 + (NB == 1 ? 32 : 16)) + (size_t)TH * TW * (MB * 64 + (MB == 1 ? 32 : 16));
+    const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * 16 * 64 * sizeof(float);
+    if (lds < lds_red) lds = lds_red;
+    dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<TAPS, MB, NB, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<TAPS, MB, NB, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (p.dz.mode == RD_SRC_BNBWD)
+        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 2>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    else
+        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    return (int)hipGetLastError();
+}
+
 template <int TAPS, int MB, int NB, int TS>
 int launch_wgrad_t_ts(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -821,6 +1021,8 @@ int launch_wgrad_t_ts(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    static const bool tr_off = getenv("RD_WG_TR_OFF") != nullptr;
+    if (wgrad_pf_ok(p) && !tr_off) return launch_wgrad_tr<TAPS, MB, NB>(p, g, st);
     if (wgrad_pf_ok(p))
         hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, true, TS>), grid, dim3(256 * TS), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     else
