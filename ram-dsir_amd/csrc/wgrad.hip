@@ -625,6 +625,154 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
     }
 }
 
+// 16-channel twin of wgrad_tr_kernel (v_mfma_f32_16x16x32_bf16, K = the 32 pixels of a tile row, one 16x16 block,
+// the 4 waves split the 8 rows): 32 bytes of channels per pixel, pitch 48 B (disjoint 8-bank spans for 4 pixel rows).
+template <int TAPS, int NQZ>
+__global__ __launch_bounds__(256, 3) void wgrad_c16_tr_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+    typedef bf16_t T;
+    typedef __attribute__((ext_vector_type(4))) float f32x4v;
+    constexpr int S = 8;
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int NPIX = PH * PW;
+    constexpr int PA = 48, PZ = 48;                         // bytes per pixel row (16 channels + pad)
+    constexpr int KS = 4, ROWS = TH / KS;
+    constexpr int NITA = (NPIX * 2 + 255) / 256, NITZ = (TH * TW * 2) / 256;
+    constexpr int KW = (TAPS == 9) ? 3 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_a = smem;                                       // [NPIX + 4][PA]
+    char* s_z = smem + (NPIX + 4) * PA;                     // [TH*TW][PZ]
+
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int H = p.H, W = p.W;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+
+    f32x4v acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    auto coords = [&](int tile, int& n, int& y0, int& x0) {
+        n = tile / (tiles_x * tiles_y);
+        const int trem = tile - n * tiles_x * tiles_y;
+        y0 = (trem / tiles_x) * TH;
+        x0 = (trem % tiles_x) * TW;
+    };
+    const int sl = tid & 1;                                 // this thread's channel slot (of 2) in both tiles
+    const int ca_abs = sl * S, cz_abs = sl * S;
+    const int sia = (p.na == 1 || ca_abs < p.a[0].C) ? 0 : 1;
+    const rd_src_t sda = select_src(p.a, sia);
+    const int ca = ca_abs - (sia ? p.a[0].C : 0);
+    const bool live_a = ca_abs < p.Cin, live_z = cz_abs < p.Cout;
+    PlainSrc<T> psa, psz;
+    plain_src_init<T>(psa, sda, live_a ? ca : 0);
+    plain_src_init<T>(psz, p.dz, live_z ? cz_abs : 0);
+    ItemGeom<NITA> iga;
+    ItemGeom<NITZ> igz;
+#pragma unroll
+    for (int b = 0; b < NITA; ++b) {
+        const int pix = (tid >> 1) + 128 * b, py = pix / PW, px = pix - py * PW;
+        iga.py[b] = (short)py;
+        iga.px[b] = (short)px;
+        iga.lds[b] = pix < NPIX ? pix * PA + sl * 16 : -1;
+    }
+#pragma unroll
+    for (int b = 0; b < NITZ; ++b) {
+        const int pix = (tid >> 1) + 128 * b;
+        igz.py[b] = (short)(pix / TW);
+        igz.px[b] = (short)(pix % TW);
+        igz.lds[b] = pix * PZ + sl * 16;
+    }
+    uint4 raw_a[NITA][1], raw_z[NITZ][NQZ];
+    auto issue = [&](int tile) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+        if (live_a) pfu_issue<T, NITA>(raw_a, psa, iga, n, H, W, y0 - HALO, x0 - HALO);
+        if (live_z) pfu_issue<T, NITZ>(raw_z, psz, igz, n, H, W, y0, x0);
+    };
+    {
+        uint4* z4 = reinterpret_cast<uint4*>(smem);
+        for (int i = tid; i < ((NPIX + 4) * PA + TH * TW * PZ) / 16; i += 256) z4[i] = make_uint4(0, 0, 0, 0);
+    }
+    int g_ctx = -1;
+    if ((int)blockIdx.x < total_tiles) issue(blockIdx.x);
+    // fragment addressing: 16-lane group kg = K block (8 pixels), lane li = channel
+    const int zoff = (kg * 8 + (li >> 2)) * PZ + (li & 3) * 8;
+    const int aoff = (kg * 8 + (li >> 2)) * PA + (li & 3) * 8;
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+        const int g = group_of(gm, n);
+        if (g != g_ctx) {
+            if (live_a) plain_src_coef<T>(psa, sda, g, ca);
+            if (live_z) plain_src_coef<T>(psz, p.dz, g, cz_abs);
+            g_ctx = g;
+        }
+        __syncthreads();
+        if (live_a)
+            pfu_consume<T, NITA, 1>(raw_a, psa, iga, H, W, y0 - HALO, x0 - HALO,
+                                    [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
+        if (live_z)
+            pfu_consume<T, NITZ, NQZ>(raw_z, psz, igz, H, W, y0, x0,
+                                      [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_z + l) = u; });
+        __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int row = kq + rr * KS;
+            const char* zp = s_z + zoff + (row * TW) * PZ;
+            const uint2 z0 = lds_tr(zp), z1 = lds_tr(zp + 4 * PZ);
+            const bf16x8 afrag = __builtin_bit_cast(bf16x8, make_uint4(z0.x, z0.y, z1.x, z1.y));
+#pragma unroll
+            for (int kh = 0; kh < KW; ++kh) {
+                const char* ap = s_a + aoff + ((row + kh) * PW) * PA;
+                const uint2 a0 = lds_tr(ap), a1 = lds_tr(ap + 4 * PA);
+                const uint4 dq = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                if constexpr (TAPS == 9) {
+                    const uint2 a2 = lds_tr(ap + 8 * PA);
+                    const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(a0.y, a0.x, 16), __builtin_amdgcn_alignbit(a1.x, a0.y, 16),
+                                                __builtin_amdgcn_alignbit(a1.y, a1.x, 16), __builtin_amdgcn_alignbit(a2.x, a1.y, 16));
+                    const uint4 m2 = make_uint4(a0.y, a1.x, a1.y, a2.x);
+                    acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kh * 3 + 0], 0, 0, 0);
+                    acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kh * 3 + 1], 0, 0, 0);
+                    acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kh * 3 + 2], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[0], 0, 0, 0);
+                }
+            }
+        }
+    }
+    {
+        float* s_acc = reinterpret_cast<float*>(smem);     // [(KS-1)][TAPS][4][64]
+        __syncthreads();
+        if (kq > 0) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_acc[(((kq - 1) * TAPS + tap) * 4 + r) * 64 + lane] = acc[tap][r];
+        }
+        __syncthreads();
+        if (kq == 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < KS - 1; ++k2)
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tap][r] += s_acc[((k2 * TAPS + tap) * 4 + r) * 64 + lane];
+        }
+    }
+    if (kq == 0) {
+        // D layout of the 16x16 MFMA: column (N, cin) = lane&15, row (M, cout) = 4*(lane>>4) + r
+        float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[((size_t)tap * CoutPadW + 4 * kg + r) * CinPadW + li] = acc[tap][r];
+    }
+}
+
 // ------------------------------------------------------------------------------------ bf16 wgrad, <= 32 channels
 // The HBM-bound layers (16/32 channels at 400x400 / 200x200): v_mfma_f32_16x16x32_bf16 with K = the 32 pixels
 // of one tile row, 16x16 channel blocks (no padding of 16-channel layers to 32), 4 accumulator VGPRs per tap
@@ -893,6 +1041,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
     }
 }
 
+// every source a plain per-pixel read (no pooling / on-the-fly upsampling) of whole 16-byte channel slots
+bool wgrad_pf_ok(const rd_wgrad_t& p) {
+    for (int i = 0; i < p.na; ++i) {
+        const int m = p.a[i].mode;
+        if (!(m == RD_SRC_RAW || m == RD_SRC_AFF || m == RD_SRC_AFFACT) || p.a[i].C % 8) return false;
+    }
+    return (p.dz.mode == RD_SRC_RAW || p.dz.mode == RD_SRC_BNBWD) && p.dz.C % 8 == 0;
+}
+
 struct WgradGeom {
     int MB, NB, KS, CoutPadW, CinPadW, gx, total_tiles, nsplit;
     bool c16;
@@ -911,8 +1068,10 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
         g.CoutPadW = g.MB * 16;
         g.CinPadW = g.NB * 16;
         g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
-        int gx = 3 * rd_num_cus();                                    // exactly the resident set (3 workgroups per CU): no second,
-                                                            // partially filled round of workgroups
+        // exactly the resident set (no second, partially filled round): 4 workgroups/CU for the transpose-read kernel
+        // (plain sources), 3/CU for the generic one
+        static const bool tr_off = getenv("RD_WG_TR_OFF") != nullptr;
+        int gx = ((wgrad_pf_ok(p) && !tr_off) ? 3 : 3) * rd_num_cus();
         if (gx > g.total_tiles) gx = g.total_tiles;
         g.gx = gx < 1 ? 1 : gx;
         g.nsplit = g.gx;
@@ -955,15 +1114,6 @@ int launch_wgrad(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// every source a plain per-pixel read (no pooling / on-the-fly upsampling) of whole 16-byte channel slots
-bool wgrad_pf_ok(const rd_wgrad_t& p) {
-    for (int i = 0; i < p.na; ++i) {
-        const int m = p.a[i].mode;
-        if (!(m == RD_SRC_RAW || m == RD_SRC_AFF || m == RD_SRC_AFFACT) || p.a[i].C % 8) return false;
-    }
-    return (p.dz.mode == RD_SRC_RAW || p.dz.mode == RD_SRC_BNBWD) && p.dz.C % 8 == 0;
-}
-
 template <int TAPS, int MB, int NB>
 int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -973,11 +1123,19 @@ int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * TAPS * 4 * 64 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
     dim3 grid(g.gx, g.CoutPadW / (MB * 16), g.CinPadW / (NB * 16));
-    static const bool pf = getenv("RD_C16_PF") != nullptr;
-    if (pf && wgrad_pf_ok(p))
-        hipLaunchKernelGGL((wgrad_c16_kernel<TAPS, MB, NB, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
-    else
-        hipLaunchKernelGGL((wgrad_c16_kernel<TAPS, MB, NB, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    static const bool tr_off = getenv("RD_WG_TR_OFF") != nullptr;
+    if (wgrad_pf_ok(p) && !tr_off) {
+        size_t l2 = (size_t)((TH + 2 * HALO) * (TW + 2 * HALO) + 4) * 48 + (size_t)TH * TW * 48;
+        const size_t l2red = (size_t)3 * TAPS * 4 * 64 * sizeof(float);
+        if (l2 < l2red) l2 = l2red;
+        if (p.dz.mode == RD_SRC_BNBWD)
+            hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 2>), grid, dim3(256), l2, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        else
+            hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 1>), grid, dim3(256), l2, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        return (int)hipGetLastError();
+    }
+    // (a tile-ahead prefetch variant of this kernel, PF = true, measured slower: 2 workgroups/CU worth of registers)
+    hipLaunchKernelGGL((wgrad_c16_kernel<TAPS, MB, NB, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     return (int)hipGetLastError();
 }
 
