@@ -464,7 +464,7 @@ __device__ __forceinline__ uint2 lds_tr(const char* p) {
     return __builtin_bit_cast(uint2, v);
 }
 
-template <int TAPS, int MB, int NB, int NQZ>
+template <int TAPS, int MB, int NB, int NQZ, bool PF>
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
     typedef bf16_t T;
     constexpr int S = 8;
@@ -531,11 +531,14 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
     }
     uint4 raw_a[NITA][1], raw_z[NITZ][NQZ];
     auto issue = [&](int tile) {
-        int n, y0, x0;
-        coords(tile, n, y0, x0);
-        if (live_a) pfu_issue<T, NITA>(raw_a, psa, iga, n, H, W, y0 - HALO, x0 - HALO);
-        if (live_z) pfu_issue<T, NITZ>(raw_z, psz, igz, n, H, W, y0, x0);
+        if constexpr (PF) {
+            int n, y0, x0;
+            coords(tile, n, y0, x0);
+            if (live_a) pfu_issue<T, NITA>(raw_a, psa, iga, n, H, W, y0 - HALO, x0 - HALO);
+            if (live_z) pfu_issue<T, NITZ>(raw_z, psz, igz, n, H, W, y0, x0);
+        }
     };
+    SlotCtx<T> ctx_a, ctx_z;                                // PF == false: generic (pooled / interpolated) sources, synchronous fill
     {
         uint4* z4 = reinterpret_cast<uint4*>(smem);
         for (int i = tid; i < ((NPIX + 4) * PA + TH * TW * PZ) / 16; i += 256) z4[i] = make_uint4(0, 0, 0, 0);
@@ -553,17 +556,42 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
         coords(tile, n, y0, x0);
         const int g = group_of(gm, n);
         if (g != g_ctx) {
-            if (live_a) plain_src_coef<T>(psa, sda, g, ca);
-            if (live_z) plain_src_coef<T>(psz, p.dz, g, cz_abs);
+            if constexpr (PF) {
+                if (live_a) plain_src_coef<T>(psa, sda, g, ca);
+                if (live_z) plain_src_coef<T>(psz, p.dz, g, cz_abs);
+            } else {
+                slot_ctx<T>(ctx_a, p.a, p.na, p.Cin, g, ca_abs);
+                slot_ctx<T>(ctx_z, &p.dz, 1, p.Cout, g, cz_abs);
+            }
             g_ctx = g;
         }
         __syncthreads();
-        if (live_a)
-            pfu_consume<T, NITA, 1>(raw_a, psa, iga, H, W, y0 - HALO, x0 - HALO,
-                                    [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
-        if (live_z)
-            pfu_consume<T, NITZ, NQZ>(raw_z, psz, igz, H, W, y0, x0,
-                                      [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_z + l) = u; });
+        if constexpr (PF) {
+            if (live_a)
+                pfu_consume<T, NITA, 1>(raw_a, psa, iga, H, W, y0 - HALO, x0 - HALO,
+                                        [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
+            if (live_z)
+                pfu_consume<T, NITZ, NQZ>(raw_z, psz, igz, H, W, y0, x0,
+                                          [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_z + l) = u; });
+        } else {
+            // idx = pixel * slots + slot; idx % slots is this thread's slot for every idx it visits (256 % slots == 0)
+            tile_fill<T, 256, false>(p.a, ctx_a, n, H, W, tid, NPIX * NSA,
+                [&](int idx, int& y, int& x) -> bool {
+                    const int pix = idx / NSA, py = pix / PW, px = pix - py * PW;
+                    y = y0 - HALO + py;
+                    x = x0 - HALO + px;
+                    return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                },
+                [&](int idx, const uint4& u) { *reinterpret_cast<uint4*>(s_a + (idx / NSA) * PA + sla * 16) = u; });
+            tile_fill<T, 256, false>(&p.dz, ctx_z, n, H, W, tid, TH * TW * NSZ,
+                [&](int idx, int& y, int& x) -> bool {
+                    const int pix = idx / NSZ;
+                    y = y0 + pix / TW;
+                    x = x0 + pix % TW;
+                    return y < H && x < W;
+                },
+                [&](int idx, const uint4& u) { *reinterpret_cast<uint4*>(s_z + (idx / NSZ) * PZ + slz * 16) = u; });
+        }
         __syncthreads();
         if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
         for (int rr = 0; rr < ROWS; ++rr) {
@@ -1050,6 +1078,13 @@ bool wgrad_pf_ok(const rd_wgrad_t& p) {
     return (p.dz.mode == RD_SRC_RAW || p.dz.mode == RD_SRC_BNBWD) && p.dz.C % 8 == 0;
 }
 
+// every source made of whole 16-byte channel slots (any read mode)
+bool wgrad_slots_ok(const rd_wgrad_t& p) {
+    for (int i = 0; i < p.na; ++i)
+        if (p.a[i].C % 8) return false;
+    return p.dz.C % 8 == 0;
+}
+
 struct WgradGeom {
     int MB, NB, KS, CoutPadW, CinPadW, gx, total_tiles, nsplit;
     bool c16;
@@ -1149,16 +1184,20 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<TAPS, MB, NB, 1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<TAPS, MB, NB, 1, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<TAPS, MB, NB, 2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<TAPS, MB, NB, 2, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<TAPS, MB, NB, 1, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    if (p.dz.mode == RD_SRC_BNBWD)
-        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 2>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    if (!wgrad_pf_ok(p))
+        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    else if (p.dz.mode == RD_SRC_BNBWD)
+        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 2, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     else
-        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     return (int)hipGetLastError();
 }
 
@@ -1180,7 +1219,9 @@ int launch_wgrad_t_ts(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
         attr_set = true;
     }
     static const bool tr_off = getenv("RD_WG_TR_OFF") != nullptr;
-    if (wgrad_pf_ok(p) && !tr_off) return launch_wgrad_tr<TAPS, MB, NB>(p, g, st);
+    // the transpose-read kernel needs whole 16-byte channel slots in every source (its generic fill covers pooled
+    // / interpolated ones); ragged channel counts stay on the transposing-store kernel below
+    if (!tr_off && wgrad_slots_ok(p)) return launch_wgrad_tr<TAPS, MB, NB>(p, g, st);
     if (wgrad_pf_ok(p))
         hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, true, TS>), grid, dim3(256 * TS), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     else
