@@ -1212,8 +1212,6 @@ int launch_wgrad_t_ts(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB, true, TS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB, false, TS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
@@ -1222,10 +1220,8 @@ int launch_wgrad_t_ts(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     // the transpose-read kernel needs whole 16-byte channel slots in every source (its generic fill covers pooled
     // / interpolated ones); ragged channel counts stay on the transposing-store kernel below
     if (!tr_off && wgrad_slots_ok(p)) return launch_wgrad_tr<TAPS, MB, NB>(p, g, st);
-    if (wgrad_pf_ok(p))
-        hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, true, TS>), grid, dim3(256 * TS), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
-    else
-        hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, false, TS>), grid, dim3(256 * TS), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    // (its tile-ahead prefetch form, PF = true, and the 12-wave form, TS = 3, are superseded by wgrad_tr_kernel: not instantiated)
+    hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, false, TS>), grid, dim3(256 * TS), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     return (int)hipGetLastError();
 }
 
