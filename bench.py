@@ -72,38 +72,31 @@ def init_weights(bank):
             v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * bound).to(v.device))
 
 
-def dominant_kernel_roofline(ts):
-    """One eager step, launched exactly like the captured one (weight-gradient kernels forked to the side stream, so
-    the timed launches see the same contention as inside the hipGraph), with HIP events recorded on the launch
-    stream around every launch of the dominant kernel family; the algorithmic bytes / flops of each launch come
-    from its descriptor (engine.Plan._conv_meta)."""
-    main, side = torch.cuda.current_stream(), ts.side
+def dominant_kernel_roofline(ts, eager=True):
+    """One more step, launched exactly like the timed ones (eager: weight-gradient kernels on the side stream and the
+    restoration-decoder branch on its own stream, so the timed launches see the same contention), with HIP events
+    recorded on the stream each launch goes to around every launch of the dominant kernel family; the algorithmic
+    bytes / flops of each launch come from its descriptor (engine.Plan._conv_meta)."""
+    main = torch.cuda.current_stream()
     ts.zero()
-    evs, nbytes, flops = [], 0, 0
-    for seg in (ts.seg_a, ts.seg_b, ts.seg_c):
-        forked = False
-        for op in seg:
-            meta = op[2] if len(op) > 2 else None
-            if meta is not None and meta.get('side') and ts.fork:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                assert op[0](*op[1], side.cuda_stream) == 0
-                forked = True
-                continue
-            hit = meta is not None and meta.get('kernel') == DOMINANT
-            if hit:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e0.record(main)
-            assert op[0](*op[1], main.cuda_stream) == 0
-            if hit:
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record(main)
-                evs.append((e0, e1))
-                nbytes += meta['bytes']
-                flops += meta['flops']
-        if forked:
-            main.wait_stream(side)
+    evs, acc = [], dict(nbytes=0, flops=0)
+
+    def wrap(op, stream, launch):
+        meta = op[2] if len(op) > 2 else None
+        if meta is None or meta.get('kernel') != DOMINANT:
+            return launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        launch()
+        e1.record(stream)
+        evs.append((e0, e1))
+        acc['nbytes'] += meta['bytes']
+        acc['flops'] += meta['flops']
+
+    lanes = ts.lanes() if eager else {}
+    ts.run_segment(ts.seg_a + ts.seg_b, main, lanes, wrap)
+    ts.run_segment(ts.seg_c, main, lanes, wrap)
+    nbytes, flops = acc['nbytes'], acc['flops']
     torch.cuda.synchronize()
     total_ms = sum(a.elapsed_time(b) for a, b in evs)
     n = len(evs)
@@ -163,7 +156,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=400)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay one captured hipGraph per step instead of the 3-stream eager launch (slower on ROCm 7: DESIGN.md section 3)')
+    ap.add_argument('--no-graph', action='store_true', help='(default; kept for older command lines)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -198,11 +192,11 @@ def main():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     if world > 1 or force_ddp:
         runner = D.DataParallelStep(ts)
-        if not args.no_graph:
+        if args.graph:
             runner.capture()
         step = runner.step
     else:
-        if not args.no_graph:
+        if args.graph:
             ts.capture()
         step = ts.step
 
@@ -232,11 +226,11 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'Fundus target0 --ram --rec --consistency kd, batch 8=[2,3,3] per GPU, %dx%dx3' % (Sz, Sz),
-                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph,
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hipgraph': bool(args.graph), 'streams': 1 if (args.graph or not ts.fork) else 1 + len(ts.lanes()),
                        'final_loss': round(losses['loss'], 4)},
         }
         if args.dtype == 'bf16':
-            out['roofline'] = dominant_kernel_roofline(ts)
+            out['roofline'] = dominant_kernel_roofline(ts, eager=not args.graph)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(host_inputs, bs)
         print(json.dumps(out), flush=True)

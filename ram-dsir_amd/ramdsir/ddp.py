@@ -1,11 +1,15 @@
 """Data-parallel training: one process per GPU, rank-local BatchNorm statistics (the reference's
 nn.DataParallel keeps per-replica BN too, code/train.py:205-208), ONE exchange per step: the flat fp32
-gradient arena (3.8 M floats = 15.2 MB) is averaged with RCCL all-reduce in two buckets --
-  bucket 0 = seg-decoder + rec-decoder gradients, ready when segment A ends, reduced on a side stream
-             while the encoder backward (segment B) runs;
-  bucket 1 = encoder gradients, reduced after segment B;
-both are waited for before Adam (segment C).  On a fully connected xGMI node the payload is latency-bound
-(SURVEY.md section 5), hence two large buckets rather than per-tensor all-reduces.
+gradient arena (3.8 M floats = 15.2 MB) is averaged with RCCL all-reduce in three buckets that follow the order
+in which the backward produces them --
+  bucket 0 = seg-decoder + rec-decoder gradients, ready when segment A ends: reduced on the communication stream
+             while the encoder backward runs;
+  bucket 1 = encoder levels 3-5 (98 % of the encoder's parameters), ready after the first part of the encoder
+             backward (segment B1, the 100x100 and smaller levels): reduced while the 200x200 / 400x400 levels
+             (segment B2, most of the encoder's backward TIME) are still running;
+  bucket 2 = encoder levels 1-2 (28 K floats): the only exchange that is not hidden, and it is latency-sized;
+all are waited for before Adam (segment C).  On a fully connected xGMI node the payload is latency-bound
+(SURVEY.md section 5), hence a few large buckets rather than per-tensor all-reduces.
 """
 import torch
 import torch.distributed as dist
@@ -14,20 +18,25 @@ from . import engine as E
 
 
 class GradBuckets:
-    """Bucketing + averaging of a flat gradient tensor; pure torch.distributed (runs on gloo/CPU in tests)."""
+    """Bucketing + averaging of a flat gradient tensor; pure torch.distributed (runs on gloo/CPU in tests).
+    boundaries: ascending offsets [0, b1, ..., n]; bucket i = flat[boundaries[i]:boundaries[i+1]]."""
 
     def __init__(self, flat_grads, boundaries, group=None):
-        # boundaries: [0, n_enc, n_total] -> bucket 1 = [0, n_enc) (encoder), bucket 0 = [n_enc, n_total)
         self.flat = flat_grads
-        self.n_enc, self.n = boundaries[1], boundaries[2]
+        self.bounds = list(boundaries)
+        assert self.bounds[0] == 0 and all(a <= b for a, b in zip(self.bounds, self.bounds[1:])) and self.bounds[-1] <= flat_grads.numel()
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.late = self.flat[self.n_enc:self.n]      # decoder + rec decoder
-        self.early = self.flat[0:self.n_enc]          # encoder
+        self.views = [self.flat[a:b] for a, b in zip(self.bounds, self.bounds[1:])]
         self._avg = dist.ReduceOp.AVG if (dist.is_initialized() and dist.get_backend(group) == 'nccl') else dist.ReduceOp.SUM
 
-    def _reduce(self, t, async_op):
-        if self.world == 1 and not dist.is_initialized():
+    def __len__(self):
+        return len(self.views)
+
+    def reduce(self, i, async_op=True):
+        """Average bucket i over the ranks; returns the work handle (None when there is nothing to wait for)."""
+        t = self.views[i]
+        if t.numel() == 0 or (self.world == 1 and not dist.is_initialized()):
             return None
         w = dist.all_reduce(t, op=self._avg, group=self.group, async_op=async_op)
         if self._avg == dist.ReduceOp.SUM:
@@ -37,22 +46,22 @@ class GradBuckets:
             t.div_(self.world)
         return w
 
-    def reduce_decoder_side(self, async_op=True):
-        return self._reduce(self.late, async_op)
-
-    def reduce_encoder(self, async_op=True):
-        return self._reduce(self.early, async_op)
-
 
 class DataParallelStep:
-    """Wraps a TrainStep: three hipGraphs (segments A, B, C) with the two all-reduces between them."""
+    """Wraps a TrainStep: four hipGraphs (segments A, B1, B2, C) with the three all-reduces between them."""
 
     def __init__(self, ts, group=None):
         self.ts = ts
         b = ts.bank
-        self.buckets = GradBuckets(b.grads, [0, b.module_range['enc'][1], b.n], group)
+        n_enc = b.module_range['enc'][1]
+        # arena order = parameters() order: encoder levels 1..5, then the decoders
+        self.buckets = GradBuckets(b.grads, [0, ts.enc_deep_offset, n_enc, b.n], group)
         self.comm = torch.cuda.Stream()
         self.graphs = None
+
+    def _segments(self):
+        ts = self.ts
+        return (ts.seg_a, ts.seg_b1, ts.seg_b2, ts.seg_c)
 
     def capture(self):
         ts = self.ts
@@ -66,38 +75,36 @@ class DataParallelStep:
         st = torch.cuda.Stream()
         self.graphs = []
         with torch.cuda.stream(st):
-            for i, seg in enumerate((ts.seg_a, ts.seg_b, ts.seg_c)):
+            for i, seg in enumerate(self._segments()):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=st):
                     if i == 0:
                         ts.zero()
-                    ts.run_segment(seg, st)
+                    ts.run_segment(seg, st, lanes={})      # one chain per graph: forked branches replay slower
                 self.graphs.append(g)
         torch.cuda.synchronize()
         ts._restore(saved)
         torch.cuda.synchronize()
 
+    def _run(self, i, main):
+        if self.graphs is not None:
+            self.graphs[i].replay()
+        else:
+            if i == 0:
+                self.ts.zero()
+            self.ts.run_segment(self._segments()[i], main)
+
     def step(self):
-        ts = self.ts
         main = torch.cuda.current_stream()
-        if self.graphs is not None:
-            self.graphs[0].replay()
-        else:
-            ts.zero()
-            ts.run_segment(ts.seg_a, main)
-        self.comm.wait_stream(main)
-        with torch.cuda.stream(self.comm):
-            w0 = self.buckets.reduce_decoder_side(async_op=True)
-        if self.graphs is not None:
-            self.graphs[1].replay()
-        else:
-            ts.run_segment(ts.seg_b, main)
-        w1 = self.buckets.reduce_encoder(async_op=True)
-        for w in (w0, w1):
+        works = []
+        # segment -> bucket that is complete when it ends: A -> decoders (2), B1 -> deep encoder (1), B2 -> shallow (0)
+        for seg_i, bucket in ((0, 2), (1, 1), (2, 0)):
+            self._run(seg_i, main)
+            self.comm.wait_stream(main)
+            with torch.cuda.stream(self.comm):
+                works.append(self.buckets.reduce(bucket, async_op=True))
+        for w in works:
             if w is not None:
                 w.wait()
         main.wait_stream(self.comm)
-        if self.graphs is not None:
-            self.graphs[2].replay()
-        else:
-            ts.run_segment(ts.seg_c, main)
+        self._run(3, main)

@@ -332,9 +332,12 @@ class Plan:
         self.finalize_stats()
         dt = self.dt
         ws_need = 0
+        self.fwd_split = {}
         for node in self.nodes:
             o = node.out
             H, W, N = o.H, o.W, o.N
+            if node.mname not in self.fwd_split:
+                self.fwd_split[node.mname] = len(self.fwd)
             # ---------------- forward conv
             p = L.RdConv()
             for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
@@ -376,10 +379,11 @@ class Plan:
         if not self.training:
             return
         # ---------------- backward, reverse order; bwd_split[m] = index where module m's backward starts
-        self.bwd_split = {}
+        self.bwd_split, self.bwd_node_start = {}, {}
         for node in reversed(self.nodes):
             if node.mname not in self.bwd_split:
                 self.bwd_split[node.mname] = len(self.bwd)
+            self.bwd_node_start[(node.mname, node.name)] = len(self.bwd)
             o = node.out
             H, W, N = o.H, o.W, o.N
             if o.norm is not None:
@@ -494,26 +498,79 @@ class Plan:
                 raise RuntimeError('ramdsir HIP launch failed: %s -> %d' % (fn.__name__, err))
 
     @staticmethod
-    def run_forked(ops, main, side):
-        """Launch `ops` on the torch stream `main`, except those tagged side=True (weight gradients: nothing in
-        the backward chain depends on them), which go to `side` behind an event recorded at their position in
-        the main stream.  The caller joins `side` before anything reads the parameter gradients.  Works eagerly
-        and under hipGraph capture (fork/join through events)."""
-        used = False
+    def run_lanes(ops, main, lanes, wrap=None):
+        """Launch `ops` in list order over up to three HIP streams.  `lanes` maps lane names to torch streams:
+          'side' -- ops tagged side=True (weight gradients, bias column sums: nothing in the backward chain depends
+                    on them) go there, each behind an event recorded at its position in the main stream;
+          'rec'  -- ops tagged lane='rec' (the restoration decoder's forward, loss and backward: independent of
+                    the seg decoder between the bottleneck and the encoder backward) run there in their own
+                    order, their weight gradients inline;
+        and sync_op('fork'|'join', lane) entries order a lane against the main stream.  A lane missing from
+        `lanes` falls back to the main stream (the list order is a valid sequential schedule).  Works eagerly and
+        under hipGraph capture (fork/join through events).  Returns the set of lanes that still have to be joined.
+        wrap(op, stream, launch) may time a launch: it must call launch() exactly once."""
+        open_lanes = set()
         for op in ops:
             fn, args = op[0], op[1]
             meta = op[2] if len(op) > 2 else None
-            if meta is not None and meta.get('side'):
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                err = fn(*args, side.cuda_stream)
-                used = True
+            if fn is None:
+                kind, lane = args
+                st = lanes.get(lane)
+                if st is None:
+                    continue
+                if kind == 'fork':
+                    st.wait_stream(main)
+                    open_lanes.add(lane)
+                elif lane in open_lanes:
+                    main.wait_stream(st)
+                    open_lanes.discard(lane)
+                continue
+            st = main
+            if meta is not None:
+                if meta.get('lane') == 'rec' and 'rec' in lanes:
+                    st = lanes['rec']
+                elif meta.get('side') and 'side' in lanes:
+                    st = lanes['side']
+                    st.wait_stream(main)
+                    open_lanes.add('side')
+
+            def launch(fn=fn, args=args, st=st):
+                err = fn(*args, st.cuda_stream)
+                if err:
+                    raise RuntimeError('ramdsir HIP launch failed: %s -> %d' % (fn.__name__, err))
+            if wrap is None:
+                launch()
             else:
-                err = fn(*args, main.cuda_stream)
-            if err:
-                raise RuntimeError('ramdsir HIP launch failed: %s -> %d' % (fn.__name__, err))
-        return used
+                wrap(op, st, launch)
+        return open_lanes
+
+
+def sync_op(kind, lane):
+    """Pseudo-op for Plan.run_lanes: 'fork' = the lane's stream waits for the main stream here, 'join' = the
+    main stream waits for everything the lane has been given so far."""
+    assert kind in ('fork', 'join')
+    return (None, (kind, lane), {})
+
+
+def tag_lane(ops, lane):
+    """Copy of `ops` with meta['lane'] = lane."""
+    out = []
+    for op in ops:
+        meta = dict(op[2]) if len(op) > 2 else {}
+        meta['lane'] = lane
+        out.append((op[0], op[1], meta))
+    return out
+
+
+def interleave(a, b):
+    """Merge two independent op lists, alternating, each keeping its own order (CPU enqueue order only)."""
+    out, i, j = [], 0, 0
+    while i < len(a) or j < len(b):
+        if i < len(a):
+            out.append(a[i]); i += 1
+        if j < len(b):
+            out.append(b[j]); j += 1
+    return out
 
 
 class WeightPack:

@@ -53,10 +53,12 @@ class TrainStep:
                                               n=n, num_classes=in_channels)
         self.seg.build(self.wpack)
         self.rec.build(self.wpack)
-        ws_bytes = max(self.seg.ws_bytes, self.rec.ws_bytes, 4)
-        self.ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device=dev)
+        # weight-gradient split workspaces: one per plan, because the restoration decoder's backward runs beside
+        # the seg decoder's on its own stream
+        self.ws = torch.empty(max(self.seg.ws_bytes, 4) // 4 + 1, dtype=torch.float32, device=dev)
+        self.rec_wsp = torch.empty(max(self.rec.ws_bytes, 4) // 4 + 1, dtype=torch.float32, device=dev)
         self.seg.bind_workspace(self.ws)
-        self.rec.bind_workspace(self.ws)
+        self.rec.bind_workspace(self.rec_wsp)
         # ---- losses
         if dataset == 'fundus':
             self.target = torch.zeros(B, num_classes, H, W, dtype=torch.float32, device=dev)
@@ -97,33 +99,61 @@ class TrainStep:
             self.ram = R.RamMixer(B, H, W, dtype, dev, dataset)
             self.ram.bind(self.src, self.trg, self.lam, self.x.buf[:B], self.x.buf[B:])
         self.graph = None
-        self.side = torch.cuda.Stream(device=dev)          # weight-gradient kernels run beside the dgrad chain
-        self.fork = True
+        # eager execution uses three HIP streams (Plan.run_lanes): main = the forward / dgrad chain, 'side' = the
+        # weight-gradient kernels beside it, 'rec' = the whole restoration-decoder branch beside the seg decoder.
+        # RD_FORK=0: everything on one stream.  Captured into a hipGraph the same forks become parallel branches,
+        # which ROCm 7's graph executor runs SLOWER than the single chain (measured), so
+        # capture() records the one-stream order.
+        self.side = torch.cuda.Stream(device=dev)
+        self.rec_stream = torch.cuda.Stream(device=dev)
+        self.fork = os.environ.get('RD_FORK', '1') != '0'
+        self.rec_lane = os.environ.get('RD_REC_LANE', '1') != '0'
         self._ops = self._build_ops()
 
     def _build_ops(self):
-        """Three segments: A = [RAM] forward, losses, seg-decoder + rec-decoder backward; B = encoder backward;
-        C = Adam + weight repack.  Single GPU runs A+B+C back to back; data parallel all-reduces the
-        decoder-side gradients while B runs and the encoder gradients before C (ddp.py)."""
+        """Segments: A = [RAM] forward, losses, seg-decoder + rec-decoder backward; B = encoder backward (B1 = levels
+        5..3, B2 = levels 2..1); C = Adam + weight repack.  Single GPU runs A+B+C back to back; data parallel
+        all-reduces each part of the flat gradient as soon as the segment that completes it ends (ddp.py).
+        Inside A the restoration decoder (forward, loss, backward up to its last dgrad) is tagged lane='rec': it only
+        meets the seg decoder again in the bottleneck gradient, which its last dgrad ACCUMULATES into after the
+        seg decoder's has written it -- that launch stays on the main stream behind the join."""
         lib = L.lib()
         B, H, W = self.B, self.H, self.W
         split = self.seg.bwd_split['enc']
+        fdec = self.seg.fwd_split['dec']
+        seg_loss = (lib.rd_seg_loss, (C.byref(self.sl), self.dt))
+        rec_loss = (lib.rd_rec_loss, (self.rec_logits.buf.data_ptr(), self.x.buf.data_ptr(), self.rec_logits.grad_buf().data_ptr(),
+                                      self.rec_mse.data_ptr(), self.rec_ws.data_ptr(), B, H, W, self.c, self.x.Cs, self.rec_logits.gCs,
+                                      self.rec.G, self.rec.gs_arr,
+                                      self.lambda_rec, self.dt))
         a = []
         if self.ram is not None:
             a.append(self.ram.op())
-        a += self.seg.fwd
-        a += self.rec.fwd
-        a.append((lib.rd_seg_loss, (C.byref(self.sl), self.dt)))
-        a.append((lib.rd_rec_loss, (self.rec_logits.buf.data_ptr(), self.x.buf.data_ptr(), self.rec_logits.grad_buf().data_ptr(),
-                                    self.rec_mse.data_ptr(), self.rec_ws.data_ptr(), B, H, W, self.c, self.x.Cs, self.rec_logits.gCs,
-                                    self.rec.G, self.rec.gs_arr,
-                                    self.lambda_rec, self.dt)))
-        a += self.seg.bwd[:split]
-        a += self.rec.bwd
+        a += self.seg.fwd[:fdec]                                     # encoder
+        a.append(E.sync_op('fork', 'rec'))
+        rec_branch = E.tag_lane(self.rec.fwd + [rec_loss] + self.rec.bwd[:-1], 'rec')
+        dec_branch = self.seg.fwd[fdec:] + [seg_loss] + self.seg.bwd[:split]
+        a += E.interleave(dec_branch, rec_branch)
+        a.append(E.sync_op('join', 'rec'))
+        a.append(self.rec.bwd[-1])                                   # rec.convu4.conv1 dgrad: += into the bottleneck gradient
+        assert self.rec.bwd[-1][2].get('what') == 'dgrad', self.rec.bwd[-1][2]
         b = list(self.seg.bwd[split:])
+        # encoder backward in two parts (data parallel: the deep levels hold 98 % of the encoder's parameters and finish
+        # first, so their gradients are all-reduced while the 200x200 / 400x400 levels are still running)
+        cut = self.seg.bwd_node_start.get(('enc', 'convd2.conv3'), split) - split
+        self.seg_b1, self.seg_b2 = b[:cut], b[cut:]
+        self.enc_deep_offset = min(off for (m, k), (off, _) in self.bank.index.items() if m == 'enc' and k.startswith('convd3.'))
         c = [(lib.rd_adam_step, (C.byref(self.ad),)), self.wpack.refresh_op()]
         self.seg_a, self.seg_b, self.seg_c = a, b, c
         return a + b + c
+
+    def lanes(self):
+        if not self.fork:
+            return {}
+        out = {'side': self.side}
+        if self.rec_lane:
+            out['rec'] = self.rec_stream
+        return out
 
     # ---- inputs
     def load_images(self, img_nchw, img_freq_nchw, stream=None):
@@ -154,20 +184,17 @@ class TrainStep:
         self.rec.stat_arena.zero_()
         self.bank.grads.zero_()
 
-    def run_segment(self, ops, main=None):
-        """One segment with the weight-gradient fork; the side stream is joined before returning."""
+    def run_segment(self, ops, main=None, lanes=None, wrap=None):
+        """One segment over the lanes; every lane it used is joined before returning."""
         main = torch.cuda.current_stream() if main is None else main
-        if not self.fork:
-            E.Plan.run(ops, main.cuda_stream)
-            return
-        if E.Plan.run_forked(ops, main, self.side):
-            main.wait_stream(self.side)
+        lanes = self.lanes() if lanes is None else lanes
+        for lane in E.Plan.run_lanes(ops, main, lanes, wrap):
+            main.wait_stream(lanes[lane])
 
-    def run_eager(self):
+    def run_eager(self, lanes=None):
         self.zero()
-        self.run_segment(self.seg_a)
-        self.run_segment(self.seg_b)
-        self.run_segment(self.seg_c)
+        self.run_segment(self.seg_a + self.seg_b, lanes=lanes)   # one join of the weight-gradient stream, right before Adam
+        self.run_segment(self.seg_c, lanes=lanes)
 
     def capture(self):
         """Capture one step (zeroing + every launch) into a hipGraph on a side stream."""
@@ -183,7 +210,7 @@ class TrainStep:
             st.synchronize()
             self._restore(saved)
             with torch.cuda.graph(g, stream=st):
-                self.run_eager()
+                self.run_eager(lanes=self.lanes() if os.environ.get('RD_GRAPH_FORK') == '1' else {})
         torch.cuda.current_stream().wait_stream(st)
         self.graph = g
         return g

@@ -1,6 +1,8 @@
 """Glue between the drop-in nn.Modules and the fused HIP training step: puts the three modules into ONE
 parameter arena (encoder first: Adam's lr/2 group, code/train.py:573), builds the TrainStep for the batch
-geometry, captures it into a hipGraph and (multi-GPU) wraps it with the bucketed RCCL gradient exchange."""
+geometry and (multi-GPU) wraps it with the bucketed RCCL gradient exchange.  The step is launched eagerly over three
+HIP streams (step.TrainStep.lanes; the host enqueues a step in ~1.4 ms against ~7 ms of GPU time); use_graph=True
+replays one captured hipGraph per step instead (no host work per step, but slower on ROCm 7: DESIGN.md section 3)."""
 import torch
 import torch.distributed as dist
 
@@ -11,7 +13,7 @@ from . import ddp as D
 
 class FusedTrainer:
     def __init__(self, encoder, seg_decoder, rec_decoder, batch_sizes, H, W, dataset='fundus', consistency='kd', lambda_rec=0.1,
-                 lr=2e-3, total_iters=1, dtype=torch.bfloat16, use_graph=True, device=None):
+                 lr=2e-3, total_iters=1, dtype=torch.bfloat16, use_graph=False, device=None):
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
         self.modules = dict(enc=encoder, dec=seg_decoder, rec=rec_decoder)
         mods = [('enc', encoder._specs), ('dec', seg_decoder._specs), ('rec', rec_decoder._specs)]

@@ -7,7 +7,7 @@ training semantics (code/train.py:195-361, 363-528, 530-601) -- on the fused HIP
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...      # data parallel (RCCL)
 
 Differences, all deliberate: (i) RAM runs on the GPU per batch (the DataLoader workers only pick the partner
-image and lambda); (ii) the step is one captured hipGraph, so the five loss scalars are read every
+image and lambda); (ii) the step is a static launch list enqueued ahead of the GPU, so the five loss scalars are read every
 --log_every iterations instead of forcing a device sync every iteration (train.py:298-304); (iii) multi-GPU is
 one process per GPU with an RCCL gradient all-reduce instead of nn.DataParallel; (iv) tensorboard image
 grids and the source-tree snapshot (train.py:306-329,534-536) are not reproduced.

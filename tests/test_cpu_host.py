@@ -80,10 +80,11 @@ rank = int(sys.argv[1])
 os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2], RANK=str(rank), WORLD_SIZE='2')
 dist.init_process_group('gloo', rank=rank, world_size=2)
 g = torch.arange(10, dtype=torch.float32) * (rank + 1)
-b = GradBuckets(g, [0, 4, 10])
-w0 = b.reduce_decoder_side(async_op=True)
-w1 = b.reduce_encoder(async_op=False)
-if w0 is not None: w0.wait()
+b = GradBuckets(g, [0, 1, 4, 10])
+assert len(b) == 3
+ws = [b.reduce(2, async_op=True), b.reduce(1, async_op=True), b.reduce(0, async_op=False)]
+for w in ws:
+    if w is not None: w.wait()
 exp = torch.arange(10, dtype=torch.float32) * 1.5
 assert torch.allclose(g, exp), (g, exp)
 dist.destroy_process_group()
