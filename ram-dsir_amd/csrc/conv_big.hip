@@ -14,117 +14,10 @@
 //   MFMA       = v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, bit-exact fmaf chain)
 
 #include "conv_device.h"
+#include "conv_epilogue.h"
 #include "conv_dispatch.h"
 
 namespace {
-
-// ------------------------------------------------------------------------------------ epilogue (shared)
-template <typename T, int NB>
-__device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[2][NB], char* smem, int tid, int n, int g, int y0, int x0,
-                                              int n0, int slot) {
-    constexpr int S = Slot<T>::N;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, h = lane >> 5;
-    const int H = p.H, W = p.W;
-    // ---------------------------------------------------------------- epilogue
-    // C/D layout of the 32x32 MFMA: column (N, channel) = lane&31, row (M, pixel) = (r&3)+8*(r>>2)+4*(lane>>5).
-    // Each 32-channel block is staged through LDS as fp32 [256 pixels][32 ch] so that the global side runs
-    // on 16-byte slots (coalesced stores; vector reads of z / old gradients in the backward epilogues).
-    constexpr int SL = 32 / S;                             // slots per 32 channels
-    float* s_out = reinterpret_cast<float*>(smem);         // [TH*TW][32]
-    float* s_red = s_out + TH * TW * 32;                   // [32][2]
-    T* out = reinterpret_cast<T*>(p.out);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        __syncthreads();
-        const int cb = n0 + nb * 32;
-        if (tid < 64) s_red[tid] = 0.f;
-        {
-            const int cch = cb + li;
-            const bool cok = cch < p.Cout;
-            const float bsv = (p.emode == 0 && cok && p.bias) ? p.bias[cch] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const int y = y0 + wave * 2 + mb;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float v = acc[mb][nb][r] + bsv;
-                    s_out[((wave * 2 + mb) * TW + col) * 32 + li] = v;
-                    if (cok && y < H && x0 + col < W) { s1 += v; s2 += v * v; }
-                }
-            }
-            __syncthreads();
-            if (p.emode == 0 && p.stats) {
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (h == 0 && cok) {
-                    atomicAdd(&s_red[li * 2 + 0], s1);
-                    atomicAdd(&s_red[li * 2 + 1], s2);
-                }
-            }
-        }
-        const int sl = tid % SL;                           // constant per thread: 256 % SL == 0
-        const int c = cb + sl * S;
-        float b1[S], b2[S];
-#pragma unroll
-        for (int e = 0; e < S; ++e) b1[e] = b2[e] = 0.f;
-        const int di = (p.emode == 1 && c >= p.c_split) ? 1 : 0;
-        const rd_dst_t d = select_dst(p, di);
-        const int cd = c - (di ? p.c_split : 0);
-        float dsc[S], dsh[S];
-        {
-            const int gd = d.g_fixed >= 0 ? d.g_fixed : g;
-#pragma unroll
-            for (int e = 0; e < S; ++e) {
-                const bool ok = p.emode == 1 && c < p.Cout && d.kind != RD_DST_NONE && d.scale && (cd + e < d.Cd);
-                dsc[e] = ok ? d.scale[gd * d.Cd + cd + e] : 1.f;
-                dsh[e] = ok ? d.shift[gd * d.Cd + cd + e] : 0.f;
-            }
-        }
-        if (c < p.Cout) {
-            for (int idx = tid; idx < TH * TW * SL; idx += 256) {
-                const int pix = idx / SL;
-                const int y = y0 + pix / TW, x = x0 + pix % TW;
-                if (y >= H || x >= W) continue;
-                float v[S];
-#pragma unroll
-                for (int e = 0; e < S; e += 4) {
-                    const float4 f = *reinterpret_cast<const float4*>(s_out + pix * 32 + sl * S + e);
-                    v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
-                }
-                if (p.emode == 0)
-                    store_vec<T>(out + ((size_t)(n * H + y) * W + x) * p.Cout + c, v, p.Cout - c, (p.Cout % S) == 0);
-                else if (d.kind != RD_DST_NONE)
-                    grad_item<T>(d, g, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
-            }
-        }
-        // (wave-uniform condition: emode is a launch constant; lanes without a live destination add zeros)
-        if (p.emode == 1) flush_bstats<S, SL>(s_red, lane, sl, b1, b2);
-        __syncthreads();
-        if (tid < 32 && cb + tid < p.Cout) {
-            if (p.emode == 0) {
-                if (p.stats) {
-                    const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + cb + tid) * 2;
-                    atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
-                    atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
-                }
-            } else {
-                const int cch = cb + tid;
-                const int dj = cch >= p.c_split ? 1 : 0;
-                const rd_dst_t dd = select_dst(p, dj);
-                if (dd.kind != RD_DST_NONE && dd.bstats) {
-                    const int cdd = cch - (dj ? p.c_split : 0);
-                    const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
-                    const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
-                    atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
-                    atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
-                }
-            }
-        }
-    }
-}
 
 // MFMA phase of one input-channel chunk: s_in [halo pixel][4 slots], s_w [tap][n][4 slots], both XOR-swizzled
 template <typename T, int TAPS, int NB>
@@ -320,6 +213,19 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
         }
     };
     issue(0);
+    // BN coefficient rows of this image's group, all input channels, staged once: the per-chunk fill then reads them
+    // from LDS (~100 cycles) instead of from L2 right in front of the transform (an exposed ~1 us per chunk)
+    float* s_coef = reinterpret_cast<float*>(s_w + TAPS * NT * 4);        // [3][CinPad]: sc, sh, q
+    for (int c = tid; c < p.CinPad; c += 256) {
+        const int si = (p.nsrc == 1 || c < p.src[0].C) ? 0 : 1;
+        const rd_src_t sd = select_src(p.src, si);
+        const int cc = c - (si ? p.src[0].C : 0);
+        const bool live = c < p.Cin, raw = sd.mode == RD_SRC_RAW, bwd = sd.mode == RD_SRC_BNBWD;
+        const int gg = sd.g_fixed >= 0 ? sd.g_fixed : g;
+        s_coef[c] = (live && !raw) ? sd.scale[gg * sd.C + cc] : 1.f;
+        s_coef[p.CinPad + c] = (live && !raw) ? sd.shift[gg * sd.C + cc] : 0.f;
+        s_coef[2 * p.CinPad + c] = (live && bwd) ? sd.q[gg * sd.C + cc] : 0.f;
+    }
     for (int c0 = 0; c0 < p.CinPad; c0 += CK) {
         __syncthreads();
         {
@@ -330,7 +236,22 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
             if (slot_src(c0, sd, cc)) {
                 PlainSrc<T> ps;
                 plain_src_init<T>(ps, sd, cc);
-                plain_src_coef<T>(ps, sd, g, cc);
+                {
+                    const float* cp = s_coef + c0 + s * S;
+#pragma unroll
+                    for (int e = 0; e < S; e += 4) {
+                        const float4 a = *reinterpret_cast<const float4*>(cp + e);
+                        const float4 b = *reinterpret_cast<const float4*>(cp + p.CinPad + e);
+                        ps.sc[e] = a.x; ps.sc[e + 1] = a.y; ps.sc[e + 2] = a.z; ps.sc[e + 3] = a.w;
+                        ps.sh[e] = b.x; ps.sh[e + 1] = b.y; ps.sh[e + 2] = b.z; ps.sh[e + 3] = b.w;
+                        if constexpr (NQ == 2) {
+                            const float4 d = *reinterpret_cast<const float4*>(cp + 2 * p.CinPad + e);
+                            ps.q[e] = d.x; ps.q[e + 1] = d.y; ps.q[e + 2] = d.z; ps.q[e + 3] = d.w;
+                        } else {
+                            ps.q[e] = ps.q[e + 1] = ps.q[e + 2] = ps.q[e + 3] = 0.f;
+                        }
+                    }
+                }
                 pfu_consume<T, NIT>(raw, ps, ig, H, W, y0 - HALO, x0 - HALO, [&](int l, const uint4& u) { s_in[l] = u; });
             } else {
 #pragma unroll
@@ -357,26 +278,34 @@ template <typename T, int TAPS, int NB>
 int launch_conv(const rd_conv_t& p, hipStream_t st) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
-    size_t lds = (size_t)(PH * PW * 4 + TAPS * NB * 32 * 4) * sizeof(uint4);
+    size_t lds = (size_t)(PH * PW * 4 + TAPS * NB * 32 * 4) * sizeof(uint4) + (size_t)3 * p.CinPad * sizeof(float);   // + coefficient rows (conv_pf_kernel)
     const size_t lds_epi = (size_t)(TH * TW * 32 + 64) * sizeof(float);
     if (lds < lds_epi) lds = lds_epi;
     dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), p.CoutPad / (NB * 32), p.N);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, TAPS, NB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
         attr_set = true;
+    }
+    if constexpr (sizeof(T) == 2 && TAPS == 9 && NB == 2) {
+        static const bool pp_off = getenv("RD_CONV_PP_OFF") != nullptr;
+        if (!pp_off) {
+            const int rc = rd_conv_pp_dispatch(p, st);
+            if (rc != RD_CONV_PP_NA) return rc;
+        }
     }
     if constexpr (sizeof(T) == 2) {
         static const bool pf_off = getenv("RD_CONV_PF_OFF") != nullptr;
         const int nq = conv_pf_kind(p);
-        if (!pf_off && nq) {
+        if (!pf_off && nq && lds <= (size_t)72 * 1024) {
             static bool attr_pf = false;
             if (!attr_pf) {
+                const int lds_max = 72 * 1024;                  // two workgroups per CU; covers CinPad <= 1024
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pf_kernel<T, TAPS, NB, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pf_kernel<T, TAPS, NB, 2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
                 attr_pf = true;
             }
             if (nq == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1>), grid, dim3(256), lds, st, p);

@@ -1,0 +1,117 @@
+// conv_epilogue.h -- the output side shared by the multi-chunk conv kernels (conv_big.hip, conv_pp.hip): accumulators ->
+// LDS staging -> 16-byte NHWC stores (forward: + bias, BatchNorm batch statistics) or the gradient destinations
+// (backward: activation mask, pool scatter, skip accumulation, BN-backward sums).
+#pragma once
+#include "conv_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ epilogue (shared)
+template <typename T, int NB>
+__device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[2][NB], char* smem, int tid, int n, int g, int y0, int x0,
+                                              int n0, int slot) {
+    constexpr int S = Slot<T>::N;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W;
+    // ---------------------------------------------------------------- epilogue
+    // C/D layout of the 32x32 MFMA: column (N, channel) = lane&31, row (M, pixel) = (r&3)+8*(r>>2)+4*(lane>>5).
+    // Each 32-channel block is staged through LDS as fp32 [256 pixels][32 ch] so that the global side runs
+    // on 16-byte slots (coalesced stores; vector reads of z / old gradients in the backward epilogues).
+    constexpr int SL = 32 / S;                             // slots per 32 channels
+    float* s_out = reinterpret_cast<float*>(smem);         // [TH*TW][32]
+    float* s_red = s_out + TH * TW * 32;                   // [32][2]
+    T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        __syncthreads();
+        const int cb = n0 + nb * 32;
+        if (tid < 64) s_red[tid] = 0.f;
+        {
+            const int cch = cb + li;
+            const bool cok = cch < p.Cout;
+            const float bsv = (p.emode == 0 && cok && p.bias) ? p.bias[cch] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int y = y0 + wave * 2 + mb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = acc[mb][nb][r] + bsv;
+                    s_out[((wave * 2 + mb) * TW + col) * 32 + li] = v;
+                    if (cok && y < H && x0 + col < W) { s1 += v; s2 += v * v; }
+                }
+            }
+            __syncthreads();
+            if (p.emode == 0 && p.stats) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0 && cok) {
+                    atomicAdd(&s_red[li * 2 + 0], s1);
+                    atomicAdd(&s_red[li * 2 + 1], s2);
+                }
+            }
+        }
+        const int sl = tid % SL;                           // constant per thread: 256 % SL == 0
+        const int c = cb + sl * S;
+        float b1[S], b2[S];
+#pragma unroll
+        for (int e = 0; e < S; ++e) b1[e] = b2[e] = 0.f;
+        const int di = (p.emode == 1 && c >= p.c_split) ? 1 : 0;
+        const rd_dst_t d = select_dst(p, di);
+        const int cd = c - (di ? p.c_split : 0);
+        float dsc[S], dsh[S];
+        {
+            const int gd = d.g_fixed >= 0 ? d.g_fixed : g;
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                const bool ok = p.emode == 1 && c < p.Cout && d.kind != RD_DST_NONE && d.scale && (cd + e < d.Cd);
+                dsc[e] = ok ? d.scale[gd * d.Cd + cd + e] : 1.f;
+                dsh[e] = ok ? d.shift[gd * d.Cd + cd + e] : 0.f;
+            }
+        }
+        if (c < p.Cout) {
+            for (int idx = tid; idx < TH * TW * SL; idx += 256) {
+                const int pix = idx / SL;
+                const int y = y0 + pix / TW, x = x0 + pix % TW;
+                if (y >= H || x >= W) continue;
+                float v[S];
+#pragma unroll
+                for (int e = 0; e < S; e += 4) {
+                    const float4 f = *reinterpret_cast<const float4*>(s_out + pix * 32 + sl * S + e);
+                    v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
+                }
+                if (p.emode == 0)
+                    store_vec<T>(out + ((size_t)(n * H + y) * W + x) * p.Cout + c, v, p.Cout - c, (p.Cout % S) == 0);
+                else if (d.kind != RD_DST_NONE)
+                    grad_item<T>(d, g, n, y, x, H, W, cd, v, dsc, dsh, b1, b2);
+            }
+        }
+        // (wave-uniform condition: emode is a launch constant; lanes without a live destination add zeros)
+        if (p.emode == 1) flush_bstats<S, SL>(s_red, lane, sl, b1, b2);
+        __syncthreads();
+        if (tid < 32 && cb + tid < p.Cout) {
+            if (p.emode == 0) {
+                if (p.stats) {
+                    const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + cb + tid) * 2;
+                    atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
+                }
+            } else {
+                const int cch = cb + tid;
+                const int dj = cch >= p.c_split ? 1 : 0;
+                const rd_dst_t dd = select_dst(p, dj);
+                if (dd.kind != RD_DST_NONE && dd.bstats) {
+                    const int cdd = cch - (dj ? p.c_split : 0);
+                    const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
+                    const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
+                    atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace

@@ -1,0 +1,336 @@
+// conv_pp.hip -- persistent, software-pipelined 3x3 convolution for the >=64-channel layers (bf16, 64 output channels
+// per tile, plain per-pixel sources).  Same implicit GEMM, tile (8 x 32 pixels x 64 channels), LDS layout and MFMA
+// (v_mfma_f32_32x32x16_bf16) as conv_big.hip; what changes is WHEN things happen:
+//
+//   * ONE workgroup per CU (4 wave64, one per SIMD, up to 512 VGPRs), persistent over a contiguous range of tiles
+//     (output-channel block fastest, so the blocks of one pixel tile re-read it from this XCD's L2);
+//   * the (tile, 32-channel chunk) pairs of that range form one stream of STEPS.  While the MFMAs of step s run out
+//     of LDS buffer s&1, the same waves transform the raw vectors of step s+1 (BN affine + activation, bf16 pack)
+//     into buffer (s+1)&1 and request the vectors of step s+2 from HBM/L2 -- item by item, placed BETWEEN the MFMA
+//     groups of the nine taps, so the VALU / LDS-store / global-load issue slots ride in the shadow of the matrix
+//     pipe (a 32x32x16 MFMA occupies it for 32 cycles; an in-order wave can issue ~5 other instructions meanwhile);
+//   * MFMA operand fragments of tap t+1 are read from LDS before the MFMAs of tap t are issued (register double
+//     buffer), one barrier per step, and the pipeline runs ACROSS tiles: the first chunk of the next tile is
+//     already in LDS when the epilogue of this one starts.
+//
+// conv_pf_kernel (conv_big.hip) runs the same work as fill -> barrier -> MFMA -> barrier with two workgroups per CU
+// and leaves the matrix pipe idle ~75 % of the chunk loop (fill VALU and MFMA of one wave never overlap, LDS reads
+// are waited for right before their MFMA, and every tile starts with an exposed HBM round trip).
+#include "conv_device.h"
+#include "conv_epilogue.h"
+#include "conv_dispatch.h"
+
+namespace {
+
+constexpr int PP_PH = TH + 2, PP_PW = TW + 2, PP_NPIX = PP_PH * PP_PW;     // 10 x 34 halo tile
+constexpr int PP_NT = 64, PP_NIT = 6, PP_WIT = 9;
+// LDS operand tiles are kept as four PLANES, one per 16-byte channel slot of the 32-channel chunk:
+//   input  [slot][halo pixel]      weights [slot][tap * 64 + n]          (16 B per entry)
+// so that (i) consecutive lanes of a ds_read_b128 touch consecutive 16-byte entries (conflict free without an XOR
+// swizzle) and (ii) every fragment address is ONE per-lane base + a compile-time immediate (tap / row / k-step),
+// i.e. no address arithmetic inside the MFMA stream.  +32 B per plane staggers the planes by 8 banks for the
+// slot-fastest ds_write_b128 of the fill.
+constexpr int PP_PLANE_A = (PP_NPIX + 4) * 16 + 32;                        // + 4 dummy pixels (stores of non-items)
+constexpr int PP_PLANE_W = 9 * PP_NT * 16 + 32;
+constexpr int PP_IN_BYTES = 4 * PP_PLANE_A, PP_W_BYTES = 4 * PP_PLANE_W;
+constexpr int PP_W0 = 2 * PP_IN_BYTES;
+constexpr int PP_EPI = PP_W0 + 2 * PP_W_BYTES;
+constexpr int PP_EPI_BYTES = (TH * TW * 32 + 64) * 4;
+constexpr int PP_TAB = PP_EPI + PP_EPI_BYTES;
+constexpr int PP_MAX_CHUNKS = 16;                                          // CinPad <= 512
+constexpr int PP_LDS = PP_TAB + PP_MAX_CHUNKS * 4 * 48;                    // 154368 B of the CU's 160 KB
+
+// pointers that come out of the LDS slot table have lost their address space: say "global" so that the loads are
+// global_load (vmcnt only) and not flat_load (which also ties up lgkmcnt, the counter the LDS fragment reads wait on)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16g(const void* q) {
+    const u32x4_t v = *(const __attribute__((address_space(1))) u32x4_t*)(uintptr_t)q;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 ldf4g(const void* q) {
+    const f32x4_t v = *(const __attribute__((address_space(1))) f32x4_t*)(uintptr_t)q;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#else
+__device__ __forceinline__ uint4 ld16g(const void* q) { return *reinterpret_cast<const uint4*>(q); }
+__device__ __forceinline__ float4 ldf4g(const void* q) { return *reinterpret_cast<const float4*>(q); }
+#endif
+
+struct PpStage {            // wave-uniform position in the step stream
+    int tile, c;
+    int n, y0, x0, n0, g, txy;
+};
+
+struct PpGeo {
+    int ncb, tiles_x, tiles_xy, nch, tile_end;
+};
+
+// what a thread needs to know about its 16-byte channel slot of chunk c (one row per (chunk, slot), built once in LDS
+// from the kernel-argument descriptors so that the step loop never touches them)
+struct __attribute__((aligned(16))) PpSlot {
+    const bf16_t* ptr;      // source tensor + channel offset
+    const float* scale;     // coefficient rows + channel offset (a valid dummy for RAW sources)
+    const float* shift;
+    int C, n_off;
+    float slope;            // activation slope, 1 = none
+    int g_fixed;
+    int flags;              // 1: live (channel < Cin), 2: RAW (coefficients 1 / 0)
+    int pad_;
+};
+static_assert(sizeof(PpSlot) == 48, "PpSlot is read as three 16-byte LDS vectors");
+
+__device__ __forceinline__ void pp_decode(PpStage& s, const PpGeo& q, const GroupMap& gm) {
+    const int cb = s.tile % q.ncb, r = s.tile / q.ncb;
+    s.txy = r % q.tiles_xy;
+    s.n = r / q.tiles_xy;
+    s.y0 = (s.txy / q.tiles_x) * TH;
+    s.x0 = (s.txy % q.tiles_x) * TW;
+    s.n0 = cb * PP_NT;
+    s.g = group_of(gm, s.n);
+}
+
+// next step of the stream; the last step repeats (its loads stay valid, its results are never used)
+__device__ __forceinline__ void pp_advance(PpStage& s, const PpGeo& q, const GroupMap& gm) {
+    if (s.c + 1 < q.nch) {
+        s.c += 1;
+    } else if (s.tile + 1 < q.tile_end) {
+        s.c = 0;
+        s.tile += 1;
+        pp_decode(s, q, gm);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int tiles_total) {
+    typedef bf16_t T;
+    constexpr int S = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+    PpGeo q;
+    q.ncb = p.CoutPad / PP_NT;
+    q.tiles_x = (W + TW - 1) / TW;
+    q.tiles_xy = q.tiles_x * ((H + TH - 1) / TH);
+    q.nch = p.CinPad / 32;
+    const int tile_begin = (int)((long long)blockIdx.x * tiles_total / gridDim.x);
+    q.tile_end = (int)((long long)(blockIdx.x + 1) * tiles_total / gridDim.x);
+    const int nsteps = (q.tile_end - tile_begin) * q.nch;
+    if (nsteps <= 0) return;
+
+    // ---- slot table
+    if (tid < q.nch * 4) {
+        const int c = (tid >> 2) * 32 + (tid & 3) * S;
+        const int si = (p.nsrc == 1 || c < p.src[0].C) ? 0 : 1;
+        const rd_src_t sd = select_src(p.src, si);
+        const bool live = c < p.Cin, rawm = sd.mode == RD_SRC_RAW;
+        const int cc = live ? c - (si ? p.src[0].C : 0) : 0;
+        PpSlot e;
+        e.ptr = reinterpret_cast<const T*>(sd.ptr) + cc;
+        e.scale = rawm ? reinterpret_cast<const float*>(p.w) : sd.scale + cc;
+        e.shift = rawm ? reinterpret_cast<const float*>(p.w) : sd.shift + cc;
+        e.C = sd.C;
+        e.n_off = sd.n_off;
+        e.slope = sd.mode == RD_SRC_AFFACT ? sd.slope : 1.f;
+        e.g_fixed = rawm ? 0 : sd.g_fixed;
+        e.flags = (live ? 1 : 0) | (rawm ? 2 : 0);
+        e.pad_ = 0;
+        reinterpret_cast<PpSlot*>(smem + PP_TAB)[tid] = e;
+    }
+    __syncthreads();
+
+    // ---- per-thread constants of the fill: channel slot sw of a chunk, halo items, LDS byte addresses
+    const int sw = tid & 3, nn_w = tid >> 2;
+    int it_yx[PP_NIT], it_lds[PP_NIT];
+#pragma unroll
+    for (int b = 0; b < PP_NIT; ++b) {
+        const int pix = (tid >> 2) + 64 * b;
+        const int py = pix / PP_PW;
+        it_yx[b] = (py << 16) | (pix - py * PP_PW);
+        it_lds[b] = sw * PP_PLANE_A + (pix < PP_NPIX ? pix : PP_NPIX) * 16;
+    }
+    const int w_lds = PP_W0 + sw * PP_PLANE_W + nn_w * 16;                          // + tap * 1024 + parity * PP_W_BYTES
+    const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)nn_w * p.CinPad + sw * S;
+    const size_t w_tap_stride = (size_t)p.CoutPad * p.CinPad;
+    const int CinPad = p.CinPad;
+    // MFMA fragment bases: lane (li, h) reads entry li (+ immediate) of plane ks*2 + h
+    const int a_base = h * PP_PLANE_A + (wave * 2 * PP_PW + li) * 16;
+    const int b_base = PP_W0 + h * PP_PLANE_W + li * 16;
+
+    // ---- pipeline registers
+    uint4 raw[PP_NIT], wr[PP_WIT];
+    float scC[S], shC[S], scL[S], shL[S];
+    float slopeC = 1.f, slopeL = 1.f;
+    bool liveC = false, liveL = false;
+    const T* ldbase = nullptr;          // stage L: this thread's channel slot of image n, pixel (0,0)
+    int ldC = 0;
+
+    PpStage L, Cs, M;
+    L.tile = tile_begin;
+    L.c = 0;
+    pp_decode(L, q, gm);
+
+    // stage L set-up: source / channel of this thread's slot, BN coefficients (consumed one step later)
+    auto begin_issue = [&]() {
+        const PpSlot e = reinterpret_cast<const PpSlot*>(smem + PP_TAB)[L.c * 4 + sw];
+        liveL = (e.flags & 1) != 0;
+        const bool rawm = (e.flags & 2) != 0;
+        ldC = e.C;
+        ldbase = e.ptr + (size_t)(L.n + e.n_off) * H * W * e.C;
+        slopeL = e.slope;
+        const int g = e.g_fixed >= 0 ? e.g_fixed : L.g;
+        const float* sp = e.scale + (rawm ? 0 : g * e.C);
+        const float* hp = e.shift + (rawm ? 0 : g * e.C);
+        const float4 a0 = ldf4g(sp), a1 = ldf4g(sp + 4), b0 = ldf4g(hp), b1 = ldf4g(hp + 4);
+        scL[0] = a0.x; scL[1] = a0.y; scL[2] = a0.z; scL[3] = a0.w; scL[4] = a1.x; scL[5] = a1.y; scL[6] = a1.z; scL[7] = a1.w;
+        shL[0] = b0.x; shL[1] = b0.y; shL[2] = b0.z; shL[3] = b0.w; shL[4] = b1.x; shL[5] = b1.y; shL[6] = b1.z; shL[7] = b1.w;
+#pragma unroll
+        for (int e2 = 0; e2 < S; ++e2) {
+            scL[e2] = rawm ? 1.f : scL[e2];
+            shL[e2] = rawm ? 0.f : shL[e2];
+        }
+    };
+    auto issue_item = [&](int b) {
+        const int y = min(max(L.y0 - 1 + (it_yx[b] >> 16), 0), H - 1), x = min(max(L.x0 - 1 + (it_yx[b] & 0xffff), 0), W - 1);
+        raw[b] = ld16g(ldbase + (unsigned)((y * W + x) * ldC));
+    };
+    auto issue_w = [&](int t) {
+        wr[t] = ld16(wbase + (size_t)t * w_tap_stride + (size_t)L.n0 * CinPad + L.c * 32);
+    };
+    auto consume_item = [&](int b, int par) {
+        const int y = Cs.y0 - 1 + (it_yx[b] >> 16), x = Cs.x0 - 1 + (it_yx[b] & 0xffff);
+        const bool in = liveC & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
+        float v[S];
+        Slot<T>::unpack(raw[b], v);
+#pragma unroll
+        for (int e = 0; e < S; ++e) v[e] = act_fn(scC[e] * v[e] + shC[e], slopeC);
+        const uint4 u = Slot<T>::pack(v);
+        *reinterpret_cast<uint4*>(smem + par * PP_IN_BYTES + it_lds[b]) = in ? u : make_uint4(0, 0, 0, 0);
+    };
+    auto consume_w = [&](int t, int par) {
+        *reinterpret_cast<uint4*>(smem + par * PP_W_BYTES + w_lds + t * (PP_NT * 16)) = wr[t];
+    };
+    auto shift_stages = [&]() {          // C <- L, L <- next step
+        Cs = L;
+        liveC = liveL;
+        slopeC = slopeL;
+#pragma unroll
+        for (int e = 0; e < S; ++e) { scC[e] = scL[e]; shC[e] = shL[e]; }
+        pp_advance(L, q, gm);
+    };
+
+    // ---- MFMA operand fragments: A = 32 pixels x 16 channels, B = 32 output channels x 16 channels
+    struct Frag { uint4 a[2][2], b[2][2]; };
+    Frag fr[2];
+    auto load_frags = [&](int tap, int par, Frag& f) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const char* s_a = smem + par * PP_IN_BYTES + a_base;
+        const char* s_b = smem + par * PP_W_BYTES + b_base;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                f.a[mb][ks] = *reinterpret_cast<const uint4*>(s_a + ks * 2 * PP_PLANE_A + ((mb + kh) * PP_PW + kw) * 16);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                f.b[nb][ks] = *reinterpret_cast<const uint4*>(s_b + ks * 2 * PP_PLANE_W + (tap * PP_NT + nb * 32) * 16);
+    };
+
+    f32x16 acc[2][2];
+
+    // ---- prologue: step 0 into buffer 0, step 1 requested
+    begin_issue();
+#pragma unroll
+    for (int b = 0; b < PP_NIT; ++b) issue_item(b);
+#pragma unroll
+    for (int t = 0; t < PP_WIT; ++t) issue_w(t);
+    shift_stages();                      // C = step 0, L = step 1
+    begin_issue();
+#pragma unroll
+    for (int b = 0; b < PP_NIT; ++b) { consume_item(b, 0); issue_item(b); }
+#pragma unroll
+    for (int t = 0; t < PP_WIT; ++t) { consume_w(t, 0); issue_w(t); }
+    M = Cs;
+    shift_stages();                      // C = step 1, L = step 2
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int par = s & 1, nxt = par ^ 1;
+        if (M.c == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+        }
+        load_frags(0, par, fr[0]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) load_frags(t + 1, par, fr[(t + 1) & 1]);
+            const Frag& f = fr[t & 1];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[mb][ks]),
+                                                                              __builtin_bit_cast(bf16x8, f.b[nb][ks]), acc[mb][nb], 0, 0, 0);
+            // fill of step s+1 / requests of step s+2, one piece per tap
+            if (t == 0) begin_issue();
+            if (t >= 3) {
+                consume_item(t - 3, nxt);
+                issue_item(t - 3);
+            }
+            consume_w(t, nxt);
+            issue_w(t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (M.c == q.nch - 1) {
+            const int slot = (M.txy + 7 * M.n) % RD_STAT_SLOTS;
+            conv_epilogue<T, 2>(p, acc, smem + PP_EPI, tid, M.n, M.g, M.y0, M.x0, M.n0, slot);
+        }
+        M = Cs;
+        shift_stages();
+        __syncthreads();
+    }
+}
+
+// plain per-pixel single-operand sources made of whole 16-byte channel slots (the fill above is branch-free)
+bool pp_sources_ok(const rd_conv_t& p) {
+    for (int i = 0; i < p.nsrc; ++i) {
+        const int m = p.src[i].mode;
+        if (!(m == RD_SRC_RAW || m == RD_SRC_AFF || m == RD_SRC_AFFACT) || p.src[i].C % 8) return false;
+        if (m != RD_SRC_RAW && (((uintptr_t)p.src[i].scale | (uintptr_t)p.src[i].shift) & 15)) return false;   // float4 coefficient reads
+    }
+    return p.Cin % 8 == 0;
+}
+
+}  // namespace
+
+int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
+    if (p.taps != 9 || p.CoutPad % PP_NT || p.CinPad > 32 * PP_MAX_CHUNKS || !pp_sources_ok(p)) return RD_CONV_PP_NA;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RD_CONV_PP_NA;
+        n_cu = prop.multiProcessorCount;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+    }
+    const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / PP_NT);
+    // Measured (gpurun_out/lb_pp*.txt): with at most one tile per CU -- the 25x25 level -- the pipelined K loop wins
+    // 1.06-1.2x; on longer tile ranges the un-overlapped epilogue (2100 VALU per tile and wave, one workgroup per CU)
+    // costs more than the K loop gains (0.7-0.9x), so those launches stay with conv_pf_kernel.  RD_CONV_PP_ALL=1 lifts the limit.
+    static const bool pp_all = getenv("RD_CONV_PP_ALL") != nullptr;
+    if (tiles > n_cu && !pp_all) return RD_CONV_PP_NA;
+    const int grid = tiles < n_cu ? tiles : n_cu;
+    hipLaunchKernelGGL(conv_pp_kernel, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
+    return (int)hipGetLastError();
+}

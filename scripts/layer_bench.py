@@ -15,6 +15,7 @@ ts = S.TrainStep(bank, mods, dtype, bs, Sz, Sz, ram=True)
 ts.wpack.refresh()
 src, trg, lam, mask, _ = Bn.synth_inputs(8, Sz, 0, 'cuda:0')
 ts.load_raw(src, trg, lam); ts.load_target(mask)
+OPS = [op for op in (ts.seg_a + ts.seg_b + ts.seg_c) if op[0] is not None]      # fork/join markers dropped: one stream here
 for _ in range(2):
     ts.run_eager()
 torch.cuda.synchronize()
@@ -24,7 +25,7 @@ acc = {}
 for rep in range(reps):
     ts.zero()
     evs = []
-    for i, op in enumerate(ts._ops):
+    for i, op in enumerate(OPS):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(st)
         assert op[0](*op[1], st.cuda_stream) == 0
@@ -34,7 +35,7 @@ for rep in range(reps):
     for i, e0, e1 in evs:
         acc[i] = acc.get(i, 0.0) + e0.elapsed_time(e1) * 1e3 / reps
 rows = []
-for i, op in enumerate(ts._ops):
+for i, op in enumerate(OPS):
     meta = op[2] if len(op) > 2 else {}
     name = op[0].__name__
     rows.append((acc[i], i, name, meta.get('kernel', ''), meta.get('what', ''), meta.get('layer', ''), meta.get('bytes', 0), meta.get('flops', 0)))

@@ -16,8 +16,8 @@ ts.load_raw(src, trg, lam); ts.load_target(mask)
 ts.run_eager()
 torch.cuda.synchronize()
 st = torch.cuda.current_stream()
-sel = [op for op in ts._ops if len(op) > 2 and op[2].get('layer') == layer and (op[2].get('what', 'wgrad') == what or (what == 'wgrad' and op[2].get('kernel') == 'wgrad'))]
-assert len(sel) == 1, [o[2] for o in ts._ops if len(o) > 2][:5]
+sel = [op for op in ts._ops if op[0] is not None and len(op) > 2 and op[2].get('layer') == layer and (op[2].get('what', 'wgrad') == what or (what == 'wgrad' and op[2].get('kernel') == 'wgrad'))]
+assert len(sel) == 1, [o[2] for o in ts._ops if o[0] is not None and len(o) > 2][:5]
 op = sel[0]
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 e0.record(st)
