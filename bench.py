@@ -27,9 +27,10 @@ import numpy as np
 import torch
 
 # Largest share of step time in profiles/ (rocprofv3 --stats): the 3x3 convolutions with 64-wide output-channel tiles
-# (>= 64-channel layers, forward and dgrad) = conv_pf_kernel<bf16,9,2,*> (chunk-pipelined) + conv_kernel<bf16,9,2>.
+# (>= 64-channel layers, forward and dgrad) = conv_pf_kernel<bf16,9,2,*> (chunk-pipelined) + conv_kernel<bf16,9,2>
+# (pooled sources) + conv_pp_kernel (persistent variant, 25x25 level).
 DOMINANT = 'conv_kernel<bf16,9,2>'
-DOMINANT_SYMBOLS = ('conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E')   # mangled-name fragments (profiles/)
+DOMINANT_SYMBOLS = ('conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel')   # mangled-name fragments (profiles/)
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF (no sparsity)
 

@@ -8,67 +8,121 @@
 
 namespace {
 
-// one wave per channel: lane k sums slot k of the RD_STAT_SLOTS partial sums, lane 0 does the per-channel math
-__global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(const rd_bn_fwd_t p) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    for (int g = 0; g < p.G; ++g) {                       // in order: shared BNs see pass 0 then pass 1
-        float s1 = 0.f, s2 = 0.f;
-        if (p.training) {
-            for (int k = lane; k < RD_STAT_SLOTS; k += 64) {
-                s1 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
-                s2 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
-            }
-            s1 = wave_sum(s1);
-            s2 = wave_sum(s2);
+// One workgroup per channel, one wave per BN group: lane k sums slot k of the RD_STAT_SLOTS partial sums.  Every global
+// load a group needs (statistics, gamma/beta, running statistics) is issued before the first dependent instruction,
+// so a launch costs one memory round trip; the old form (one wave walking the groups, loads behind the reduction)
+// paid 2 x G of them, on the critical path of the step 76 times.  Groups that share one BatchNorm (the two passes of
+// the seg network) update its running statistics in group order, exactly as two consecutive module calls would:
+// thread 0 replays the momentum recursion from the per-group results in LDS.
+__global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_fwd_kernel(const rd_bn_fwd_t p) {
+    __shared__ float s_mean[RD_MAX_GROUPS], s_unb[RD_MAX_GROUPS], s_rm[RD_MAX_GROUPS], s_rv[RD_MAX_GROUPS];
+    const int c = blockIdx.x, lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float s1 = 0.f, s2 = 0.f;
+    if (p.training) {
+        for (int k = lane; k < RD_STAT_SLOTS; k += 64) {
+            s1 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
+            s2 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
         }
-        if (lane != 0) continue;
-        const float gam = p.gamma[g][c], bet = p.beta[g][c];
-        float mean, invstd;
-        if (p.training) {
-            const float cnt = p.count[g];
-            mean = s1 / cnt;
-            float var = s2 / cnt - mean * mean;
-            if (var < 0.f) var = 0.f;
-            invstd = 1.0f / sqrtf(var + p.eps);
-            if (p.running_mean[g]) {
-                const float unb = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
-                p.running_mean[g][c] = (1.f - p.momentum) * p.running_mean[g][c] + p.momentum * mean;
-                p.running_var[g][c] = (1.f - p.momentum) * p.running_var[g][c] + p.momentum * unb;
-            }
-            if (c == 0 && p.num_batches_tracked[g]) *p.num_batches_tracked[g] += 1;
-        } else {
-            mean = p.running_mean[g][c];
-            invstd = 1.0f / sqrtf(p.running_var[g][c] + p.eps);
-        }
+    }
+    const float gam = p.gamma[g][c], bet = p.beta[g][c];
+    const bool has_run = p.running_mean[g] != nullptr;
+    float rm = 0.f, rv = 1.f;
+    if (has_run) {
+        rm = p.running_mean[g][c];
+        rv = p.running_var[g][c];
+    }
+    float mean, invstd, unb = 0.f;
+    if (p.training) {
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const float cnt = p.count[g];
+        mean = s1 / cnt;
+        float var = s2 / cnt - mean * mean;
+        if (var < 0.f) var = 0.f;
+        invstd = 1.0f / sqrtf(var + p.eps);
+        unb = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
+    } else {
+        mean = rm;
+        invstd = 1.0f / sqrtf(rv + p.eps);
+    }
+    if (lane == 0) {
         const float sc = gam * invstd;
         p.scale[g * p.C + c] = sc;
         p.shift[g * p.C + c] = bet - mean * sc;
         p.mean[g * p.C + c] = mean;
         p.invstd[g * p.C + c] = invstd;
+        s_mean[g] = mean; s_unb[g] = unb; s_rm[g] = rm; s_rv[g] = rv;
+    }
+    if (!p.training) return;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < p.G; ++i) {
+        if (!p.running_mean[i]) continue;
+        const float nm = (1.f - p.momentum) * s_rm[i] + p.momentum * s_mean[i];
+        const float nv = (1.f - p.momentum) * s_rv[i] + p.momentum * s_unb[i];
+        p.running_mean[i][c] = nm;
+        p.running_var[i][c] = nv;
+        for (int j = i + 1; j < p.G; ++j)                  // a later group on the same BatchNorm continues from here
+            if (p.running_mean[j] == p.running_mean[i]) { s_rm[j] = nm; s_rv[j] = nv; }
+    }
+    if (c == 0) {
+        for (int i = 0; i < p.G; ++i) {
+            if (!p.num_batches_tracked[i]) continue;
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && p.num_batches_tracked[j] != p.num_batches_tracked[i];
+            if (!first) continue;
+            int n = 0;
+            for (int j = i; j < p.G; ++j) n += p.num_batches_tracked[j] == p.num_batches_tracked[i] ? 1 : 0;
+            *p.num_batches_tracked[i] += n;
+        }
     }
 }
 
-__global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(const rd_bn_bwd_t p) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    for (int g = 0; g < p.G; ++g) {
-        float s1 = 0.f, sgz = 0.f;
-        for (int k = lane; k < RD_STAT_SLOTS; k += 64) {
-            s1 += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
-            sgz += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
-        }
-        s1 = wave_sum(s1);
-        sgz = wave_sum(sgz);
-        if (lane != 0) continue;
+__global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_bwd_kernel(const rd_bn_bwd_t p) {
+    __shared__ float s_s1[RD_MAX_GROUPS], s_s2[RD_MAX_GROUPS];
+    const int c = blockIdx.x, lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float s1 = 0.f, sgz = 0.f;
+    for (int k = lane; k < RD_STAT_SLOTS; k += 64) {
+        s1 += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
+        sgz += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
+    }
+    const float mu = p.mean[g * p.C + c], is = p.invstd[g * p.C + c], gam = p.gamma[g][c];
+    s1 = wave_sum(s1);
+    sgz = wave_sum(sgz);
+    if (lane == 0) {
         const float cnt = p.count[g];
-        const float mu = p.mean[g * p.C + c], is = p.invstd[g * p.C + c], gam = p.gamma[g][c];
         const float s2 = is * (sgz - mu * s1);            // sum g * zhat
         const float P = gam * is;
         const float Q = -gam * is * is * s2 / cnt;
         p.P[g * p.C + c] = P;
         p.Q[g * p.C + c] = Q;
         p.R[g * p.C + c] = -P * s1 / cnt - Q * mu;
-        if (p.dgamma[g]) p.dgamma[g][c] += s2;
-        if (p.dbeta[g]) p.dbeta[g][c] += s1;
+        s_s1[g] = s1; s_s2[g] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    // dgamma / dbeta: groups on one BatchNorm add into the same element, in group order
+    for (int i = 0; i < p.G; ++i) {
+        if (p.dgamma[i]) {
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && p.dgamma[j] != p.dgamma[i];
+            if (first) {
+                float v = p.dgamma[i][c];
+                for (int j = i; j < p.G; ++j) if (p.dgamma[j] == p.dgamma[i]) v += s_s2[j];
+                p.dgamma[i][c] = v;
+            }
+        }
+        if (p.dbeta[i]) {
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && p.dbeta[j] != p.dbeta[i];
+            if (first) {
+                float v = p.dbeta[i][c];
+                for (int j = i; j < p.G; ++j) if (p.dbeta[j] == p.dbeta[i]) v += s_s1[j];
+                p.dbeta[i][c] = v;
+            }
+        }
     }
 }
 
@@ -352,13 +406,13 @@ extern "C" {
 
 int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream) {
     if (!p || p->G < 1 || p->G > RD_MAX_GROUPS) return -1;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(p->C), dim3(64), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(p->C), dim3(64 * p->G), 0, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 
 int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
     if (!p || p->G < 1 || p->G > RD_MAX_GROUPS) return -1;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(p->C), dim3(64), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(p->C), dim3(64 * p->G), 0, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 

@@ -228,13 +228,16 @@ __global__ __launch_bounds__(256) void rec_loss_kernel(const T* lg, const T* tgt
     if (threadIdx.x == 0) partial[n * gridDim.x + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-__global__ void rec_loss_final_kernel(const float* partial, float* mse_out, int bx, int per_img, GroupMap gm) {
-    const int g = threadIdx.x;
+// one wave per group: lanes stride over the per-block partial sums (fixed order -> deterministic), fp64 wave reduce
+__global__ __launch_bounds__(64 * RD_MAX_GROUPS) void rec_loss_final_kernel(const float* partial, float* mse_out, int bx, int per_img, GroupMap gm) {
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (g >= gm.G) return;
+    const int lo = gm.gs[g] * bx, hi = gm.gs[g + 1] * bx;
     double s = 0.0;
-    for (int n = gm.gs[g]; n < gm.gs[g + 1]; ++n)
-        for (int b = 0; b < bx; ++b) s += (double)partial[n * bx + b];
-    mse_out[g] = (float)(s / ((double)(gm.gs[g + 1] - gm.gs[g]) * per_img));
+    for (int i = lo + lane; i < hi; i += 64) s += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) mse_out[g] = (float)(s / ((double)(gm.gs[g + 1] - gm.gs[g]) * per_img));
 }
 
 // ----------------------------------------------------------------------------------- Adam
@@ -324,7 +327,7 @@ int rd_rec_loss(const void* lg, const void* tgt, void* dl, float* mse_out, float
     else
         hipLaunchKernelGGL(rec_loss_kernel<float>, dim3(bx, B), dim3(256), 0, st, (const float*)lg, (const float*)tgt, (float*)dl,
                            partial_ws, per_img, gm, lambda_rec, C, Ts, Ds);
-    hipLaunchKernelGGL(rec_loss_final_kernel, dim3(1), dim3(64), 0, st, partial_ws, mse_out, bx, per_img, gm);
+    hipLaunchKernelGGL(rec_loss_final_kernel, dim3(1), dim3(64 * G), 0, st, partial_ws, mse_out, bx, per_img, gm);
     return (int)hipGetLastError();
 }
 

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 run = os.path.join(ROOT, 'gpurun_out', 'profiles_run')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-frags = ('conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E')          # == bench.DOMINANT_SYMBOLS
+frags = ('conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel')          # == bench.DOMINANT_SYMBOLS
 
 line = [l for l in open(os.path.join(run, 'bench.json')) if l.startswith('{')][-1]
 open(os.path.join(ROOT, 'profiles', tag + '_bench.json'), 'w').write(line)
@@ -26,7 +26,7 @@ for f in glob.glob(os.path.join(run, 'pmc', 'pmc_*', '*counter_collection.csv'))
 fk = sum(vals['FETCH_SIZE']) / len(vals['FETCH_SIZE'])
 wk = sum(vals['WRITE_SIZE']) / len(vals['WRITE_SIZE'])
 out = {
-    'kernel': 'conv_kernel<bf16,9,2> (conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2>)',
+    'kernel': 'conv_kernel<bf16,9,2> (conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> + conv_pp_kernel)',
     'launches_profiled': len(vals['FETCH_SIZE']),
     'fetch_size_kb_per_launch': fk, 'write_size_kb_per_launch': wk,
     'traffic_bytes_per_launch': (2 * fk + wk) * 1024,
