@@ -111,6 +111,20 @@ def test_fundus(encoder, seg_decoder, epoch, data_dir, datasetTest, output_path,
     return (cup + disc) * 100.0 / 2
 
 
+def test_prostate(encoder, seg_decoder, epoch, data_dir, datasetTest, output_path, batch_size=8, dataset='prostate'):
+    """train.py:134-192: Dice over the NIfTI volumes of the held-out site (BN in eval mode), one line in
+    <target>_val_log.csv.  `data_dir` is the dataset directory (<data_root>/prostate)."""
+    from utils.prostate_eval import DOMAIN_LIST, evaluate_domain
+    encoder.eval()
+    seg_decoder.eval()
+    with torch.no_grad():
+        val_dice, _, _ = evaluate_domain(lambda v: seg_decoder(encoder(v.cuda())), data_dir, DOMAIN_LIST[datasetTest], batch_size)
+    print('val_dice : {}'.format(val_dice))
+    with open(osp.join(output_path, str(datasetTest) + '_val_log.csv'), 'a') as f:
+        f.write(','.join(map(str, [['batch-size: '] + [batch_size] + [epoch] + ['dice coefficence: '] + [val_dice]])) + '\n')
+    return val_dice * 100.0
+
+
 def save_checkpoint(path, encoder, seg_decoder, rec_decoder):
     """train.py:342-360: unwrapped state_dicts under the reference's three keys."""
     torch.save({'encoder_state_dict': encoder.state_dict(), 'seg_decoder_state_dict': seg_decoder.state_dict(),
@@ -184,16 +198,24 @@ def main(args):
             iter_num += 1
             if args.max_iters and iter_num >= args.max_iters:
                 break
-        if args.dataset == 'fundus' and rank == 0 and os.path.exists(os.path.join(data_root, 'Domain%d_test.list' % (args.test_domain_idx + 1))):
+        # validation on the held-out domain + keep-best checkpoint rotation (train.py:331-350); skipped when the
+        # evaluation data is not on disk (synthetic / smoke runs)
+        avg_dice = None
+        if rank == 0 and args.dataset == 'fundus' and os.path.exists(os.path.join(data_root, 'Domain%d_test.list' % (args.test_domain_idx + 1))):
             print('Test on target domain {}'.format(args.test_domain_idx))
             avg_dice = test_fundus(encoder, seg_decoder, epoch, data_root, args.test_domain_idx, args.save_path, args.test_batch_size)
-            if avg_dice >= previous_best:
-                if previous_best != 0:
-                    old = os.path.join(args.save_path, 'model_%.2f.pth' % previous_best)
-                    if os.path.exists(old):
-                        os.remove(old)
-                save_checkpoint(os.path.join(args.save_path, 'model_%.2f.pth' % avg_dice), encoder, seg_decoder, rec_decoder)
-                previous_best = avg_dice
+        elif rank == 0 and args.dataset == 'prostate':
+            from utils.prostate_eval import DOMAIN_LIST
+            if os.path.isdir(os.path.join(data_root, DOMAIN_LIST[args.test_domain_idx])):
+                print('Test on target domain {}'.format(args.test_domain_idx))
+                avg_dice = test_prostate(encoder, seg_decoder, epoch, data_root, args.test_domain_idx, args.save_path, args.test_batch_size)
+        if avg_dice is not None and avg_dice >= previous_best:
+            if previous_best != 0:
+                old = os.path.join(args.save_path, 'model_%.2f.pth' % previous_best)
+                if os.path.exists(old):
+                    os.remove(old)
+            save_checkpoint(os.path.join(args.save_path, 'model_%.2f.pth' % avg_dice), encoder, seg_decoder, rec_decoder)
+            previous_best = avg_dice
         if args.max_iters and iter_num >= args.max_iters:
             break
     if rank == 0:

@@ -37,3 +37,67 @@ def postprocessing(prediction, threshold=0.5, dataset='G'):
     out[1] = get_largest_fillhole(out[1]).astype(np.uint8)
     out[0] = get_largest_fillhole(out[0]).astype(np.uint8)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# medpy.metric.binary restated.  The reference imports `medpy` (test_fundus_slice.py:19,125-136,
+# test_prostate_volume.py:14,121-126, utils/metrics.py:2,20; no version pinned, the package is not vendored and not
+# installed here).  These follow medpy's published definitions (medpy/metric/binary.py, 0.4.x): `dc` = 2|A&B| /
+# (|A|+|B|), 0 when both are empty; surface distances = Euclidean distance transform of the complement of the
+# REFERENCE's border sampled on the RESULT's border, a border being `x XOR binary_erosion(x)` with the connectivity-1
+# (face) structuring element; `hd95` = 95th percentile of the two directed distance sets stacked; `asd` = mean of the
+# directed set result -> reference.  Empty operands raise RuntimeError as medpy does.
+def _as_bool(a):
+    return np.atleast_1d(np.asarray(a).astype(bool))
+
+
+def dc(result, reference):
+    result, reference = _as_bool(result), _as_bool(reference)
+    inter = np.count_nonzero(result & reference)
+    a, b = np.count_nonzero(result), np.count_nonzero(reference)
+    try:
+        return 2.0 * inter / float(a + b)
+    except ZeroDivisionError:
+        return 0.0
+
+
+def _surface_distances(result, reference, voxelspacing=None, connectivity=1):
+    result, reference = _as_bool(result), _as_bool(reference)
+    if voxelspacing is not None:
+        voxelspacing = np.asarray(voxelspacing, dtype=np.float64)
+        if voxelspacing.ndim == 0:
+            voxelspacing = np.repeat(voxelspacing, result.ndim)
+    footprint = ndi.generate_binary_structure(result.ndim, connectivity)
+    if np.count_nonzero(result) == 0:
+        raise RuntimeError('The first supplied array does not contain any binary object.')
+    if np.count_nonzero(reference) == 0:
+        raise RuntimeError('The second supplied array does not contain any binary object.')
+    result_border = result ^ ndi.binary_erosion(result, structure=footprint, iterations=1)
+    reference_border = reference ^ ndi.binary_erosion(reference, structure=footprint, iterations=1)
+    dt = ndi.distance_transform_edt(~reference_border, sampling=voxelspacing)
+    return dt[result_border]
+
+
+def hd95(result, reference, voxelspacing=None, connectivity=1):
+    hd1 = _surface_distances(result, reference, voxelspacing, connectivity)
+    hd2 = _surface_distances(reference, result, voxelspacing, connectivity)
+    return float(np.percentile(np.hstack((hd1, hd2)), 95))
+
+
+def asd(result, reference, voxelspacing=None, connectivity=1):
+    return float(_surface_distances(result, reference, voxelspacing, connectivity).mean())
+
+
+def connectivity_region_analysis(mask):
+    """code/utils/utils.py:30-42 `_connectivity_region_analysis`: keep the largest connected component of a volume
+    (scipy.ndimage.label with its default face connectivity; sizes[0] is the background's sum, i.e. 0 for a
+    binary mask).  Returns an integer array like the reference."""
+    mask = np.asarray(mask)
+    label_im, nb = ndi.label(mask)
+    sizes = ndi.sum(mask, label_im, range(nb + 1))
+    keep = int(np.argmax(sizes))
+    out = np.zeros_like(label_im)
+    out[label_im == keep] = 1
+    if keep == 0:                      # the reference's two in-place assignments: label 0 stays 0 first, then 0 == argmax -> all ones
+        out = np.ones_like(label_im)
+    return out

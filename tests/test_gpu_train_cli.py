@@ -71,3 +71,32 @@ def test_train_cli_rejects_flag_sets_the_reference_cannot_run(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, 'ram-dsir_amd', 'train.py'), '--save_path', str(tmp_path), '--epochs', '1', '--ram']
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode != 0 and b'--ram --rec' in r.stdout
+
+
+def test_prostate_volume_script_on_synthetic_nifti(tmp_path):
+    """test_prostate_volume.py end to end: NIfTI volumes of the held-out site, random-init checkpoint, BN in train
+    mode; the script must run, report the three metrics and append the reference's CSV line."""
+    sys.path.insert(0, os.path.join(ROOT, 'ram-dsir_amd'))
+    from networks.unet import Encoder, Decoder
+    from utils import nifti
+    dom = tmp_path / 'data' / 'prostate' / 'BIDMC'
+    os.makedirs(dom)
+    rng = np.random.RandomState(3)
+    for k in range(2):
+        img = rng.uniform(0, 60, (10, 64, 64)).astype(np.float32)
+        msk = np.zeros((10, 64, 64), np.uint8)
+        img[2:8, 20:44, 20:44] += 150
+        msk[2:8, 20:44, 20:44] = 1
+        nifti.write_volume(str(dom / ('Case%02d.nii.gz' % k)), img)
+        nifti.write_volume(str(dom / ('Case%02d_segmentation.nii.gz' % k)), msk)
+    torch.manual_seed(0)
+    ck = str(tmp_path / 'ck.pth')
+    torch.save({'encoder_state_dict': Encoder().state_dict(), 'seg_decoder_state_dict': Decoder(num_classes=2).state_dict()}, ck)
+    ev = [sys.executable, os.path.join(ROOT, 'ram-dsir_amd', 'test_prostate_volume.py'), '--model_file', ck, '--data_dir', str(tmp_path / 'data'),
+          '--datasetTest', '4', '--test_prediction_save_path', str(tmp_path / 'pred'), '--batch_size', '4']
+    r = subprocess.run(ev, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    log = r.stdout.decode()
+    assert r.returncode == 0, log[-3000:]
+    assert 'val_dice' in log and 'average_hd' in log and 'average_asd' in log
+    line = open(str(tmp_path / 'pred' / 'test4_log.csv')).read()
+    assert 'dice coefficence' in line and 'average_asd' in line
