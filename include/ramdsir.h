@@ -86,7 +86,7 @@ typedef struct {
     rd_src_t src[2];     /* 2 sources = torch.cat([prev, y], 1) (unet.py:110), never materialised */
     int32_t nsrc;
     int32_t taps;        /* 9 (3x3, pad 1) or 1 (1x1) */
-    const void* w;       /* packed weights [taps][CoutPad][CinPad], dtype, zero padded */
+    const void* w;       /* packed weights [CinPad/CK][taps][CoutPad][CK] (CK = 64 B of channels), dtype, zero padded */
     const float* bias;   /* [Cout] or NULL */
     int32_t CinPad, CoutPad;
     int32_t N, H, W, Cin, Cout;
@@ -123,8 +123,9 @@ int64_t rd_wgrad_workspace(const rd_wgrad_t* p, int dtype);
 int rd_wgrad(const rd_wgrad_t* p, int dtype, void* stream);
 
 /* rd_pack_weights: OIHW fp32 master weights -> the packed operand rd_conv reads.
- * transpose=0: forward  [tap][CoutPad][CinPad]  (tap = kh*3+kw)
- * transpose=1: dgrad    [tap'][CinPad'][CoutPad'] with tap' = 8-tap (180-degree flip), i.e. the conv
+ * K-chunk-major, CK = 32 (bf16) / 16 (fp32) input channels = the 64 bytes one K step of rd_conv consumes:
+ * transpose=0: forward  [CinPad/CK][tap][CoutPad][CK]  (tap = kh*3+kw)
+ * transpose=1: dgrad    [CoutPad'/CK][tap'][CinPad'][CK] with tap' = 8-tap (180-degree flip), i.e. the conv
  *              that maps dz (Cout channels) to da (Cin channels). */
 int rd_pack_weights(const float* w_oihw, void* packed, int Cout, int Cin, int taps, int transpose,
                     int dtype, void* stream);

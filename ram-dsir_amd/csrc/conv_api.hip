@@ -8,11 +8,15 @@ namespace {
 // ------------------------------------------------------------------------------------ weight packing
 template <typename T>
 __global__ void pack_weights_kernel(const float* w, T* out, int Cout, int Cin, int taps, int transpose, int RowPad, int ColPad) {
-    // forward:   out[tap][n<RowPad(Cout)][c<ColPad(Cin)]   = w[n][c][tap]
-    // transpose: out[tap'][c<RowPad(Cin)][n<ColPad(Cout)]  = w[n][c][taps-1-tap']
+    // K-chunk-major: the CK = 64 B / sizeof(T) columns one K step of the conv kernels consumes are contiguous for every
+    // (tap, row), and all taps x rows of a chunk follow each other -> a workgroup's weight fetch for one chunk is one
+    // contiguous block (it was 64-byte pieces 2*ColPad bytes apart, the dominant L2 traffic of the 25x25 / 50x50 levels)
+    // forward:   out[col/CK][tap][n<RowPad(Cout)][col%CK]   = w[n][col][tap]
+    // transpose: out[col/CK][tap'][c<RowPad(Cin)][col%CK]   = w[col][c][taps-1-tap']
+    constexpr int CK = 64 / (int)sizeof(T);
     const int total = taps * RowPad * ColPad;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int col = i % ColPad, row = (i / ColPad) % RowPad, tap = i / (ColPad * RowPad);
+        const int cc = i % CK, row = (i / CK) % RowPad, tap = (i / (CK * RowPad)) % taps, col = (i / (CK * RowPad * taps)) * CK + cc;
         float v = 0.f;
         if (!transpose) {
             if (row < Cout && col < Cin) v = w[((size_t)row * Cin + col) * taps + tap];
@@ -35,7 +39,8 @@ __global__ void pack_weights_batched_kernel(const float* params, T* packed, cons
         }
         const rd_pack_entry_t e = tab[lo];
         const int j = (int)(i - e.start);
-        const int col = j % e.ColPad, row = (j / e.ColPad) % e.RowPad, tap = j / (e.ColPad * e.RowPad);
+        constexpr int CK = 64 / (int)sizeof(T);
+        const int cc = j % CK, row = (j / CK) % e.RowPad, tap = (j / (CK * e.RowPad)) % e.taps, col = (j / (CK * e.RowPad * e.taps)) * CK + cc;
         const float* w = params + e.src_off;
         float v = 0.f;
         if (!e.transpose) {

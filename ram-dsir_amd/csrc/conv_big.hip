@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
                 const int idx = tid + b * 256;
                 const int s = idx & 3, rec = idx >> 2;
                 const int nn = rec % NT, tap = rec / NT;
-                wr[b] = ld16(wbase + ((size_t)(min(tap, TAPS - 1) * p.CoutPad + n0 + nn) * p.CinPad + c0 + s * S));
+                wr[b] = ld16(wbase + ((size_t)((c0 / CK) * TAPS + min(tap, TAPS - 1)) * p.CoutPad + n0 + nn) * CK + s * S);
             }
 #pragma unroll
             for (int b = 0; b < WIT; ++b) {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
             const int idx = tid + b * 256;
             const int sw = idx & 3, rec = idx >> 2;
             const int nn = rec % NT, tap = rec / NT;
-            wr[b] = ld16(wbase + ((size_t)(min(tap, TAPS - 1) * p.CoutPad + n0 + nn) * p.CinPad + c0 + sw * S));
+            wr[b] = ld16(wbase + ((size_t)((c0 / CK) * TAPS + min(tap, TAPS - 1)) * p.CoutPad + n0 + nn) * CK + sw * S);
         }
     };
     issue(0);
@@ -320,7 +320,13 @@ int launch_conv(const rd_conv_t& p, hipStream_t st) {
 }  // namespace
 
 int rd_conv_big_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
-    const bool nb2 = (p.CoutPad % 64) == 0;
+    bool nb2 = (p.CoutPad % 64) == 0;
+    {
+        // small grids (the 25x25 / 50x50 levels): 32-channel tiles double the number of workgroups
+        static const int nb1_below = getenv("RD_CONV_NB1_BELOW") ? atoi(getenv("RD_CONV_NB1_BELOW")) : 300;
+        const int wgs64 = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / 64);
+        if (nb2 && dtype == RD_BF16 && wgs64 < nb1_below) nb2 = false;
+    }
     if (dtype == RD_BF16) {
         if (p.taps == 9) return nb2 ? launch_conv<bf16_t, 9, 2>(p, st) : launch_conv<bf16_t, 9, 1>(p, st);
         return nb2 ? launch_conv<bf16_t, 1, 2>(p, st) : launch_conv<bf16_t, 1, 1>(p, st);

@@ -65,6 +65,7 @@ struct PpStage {            // wave-uniform position in the step stream
 
 struct PpGeo {
     int ncb, tiles_x, tiles_xy, nch, tile_end;
+    int cb_slow, n_img;     // cb_slow: channel block is the slowest tile coordinate (register-resident BN sums)
 };
 
 // what a thread needs to know about its 16-byte channel slot of chunk c (one row per (chunk, slot), built once in LDS
@@ -82,7 +83,9 @@ struct __attribute__((aligned(16))) PpSlot {
 static_assert(sizeof(PpSlot) == 48, "PpSlot is read as three 16-byte LDS vectors");
 
 __device__ __forceinline__ void pp_decode(PpStage& s, const PpGeo& q, const GroupMap& gm) {
-    const int cb = s.tile % q.ncb, r = s.tile / q.ncb;
+    const int per_cb = q.n_img * q.tiles_xy;
+    const int cb = q.cb_slow ? s.tile / per_cb : s.tile % q.ncb;
+    const int r = q.cb_slow ? s.tile % per_cb : s.tile / q.ncb;
     s.txy = r % q.tiles_xy;
     s.n = r / q.tiles_xy;
     s.y0 = (s.txy / q.tiles_x) * TH;
@@ -102,6 +105,18 @@ __device__ __forceinline__ void pp_advance(PpStage& s, const PpGeo& q, const Gro
     }
 }
 
+// LEAN = forward launches: the MFMA roles are swapped (A = weights, B = pixels), so a lane ends up with ONE pixel and
+// 16 output channels per 32-channel block, regroups them with v_permlane32_swap into 16-byte NHWC vectors and stores
+// them straight from registers; the BatchNorm sums stay in registers across the tiles of a (channel block, group) run.
+// Ablation on dec.convu2.conv3 forward (64->64 at 200x200, 16 images; RD_PP_DBG builds of this kernel): 157.7 us with
+// the LDS-staged epilogue of conv_epilogue.h, 42.3 us with the epilogue removed, 9.2 us MFMA + fragment reads only --
+// the staged epilogue (~3000 instructions per wave and tile: scalar LDS stores, a non-unrolled store loop with the
+// gradient switch, LDS + global atomics per tile) was 3/4 of the kernel, not the K loop.
+// MODE: 0 = LDS-staged epilogue of conv_epilogue.h (any destination), 1 = LEAN forward, 2 = LEAN gradient (every
+// destination plain, whole 16-byte slots, c_split % 16 == 0): same register regrouping; the producer's raw tensor (for the
+// activation mask and sum g*z) and, for accumulating destinations, the old gradient are requested at the start of the
+// tile's last K step and consumed after it.
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int tiles_total) {
     typedef bf16_t T;
     constexpr int S = 8;
@@ -116,6 +131,9 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
     q.tiles_x = (W + TW - 1) / TW;
     q.tiles_xy = q.tiles_x * ((H + TH - 1) / TH);
     q.nch = p.CinPad / 32;
+    constexpr bool LEAN = MODE != 0;
+    q.cb_slow = LEAN ? 1 : 0;
+    q.n_img = p.N;
     const int tile_begin = (int)((long long)blockIdx.x * tiles_total / gridDim.x);
     q.tile_end = (int)((long long)(blockIdx.x + 1) * tiles_total / gridDim.x);
     const int nsteps = (q.tile_end - tile_begin) * q.nch;
@@ -153,15 +171,14 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
         it_lds[b] = sw * PP_PLANE_A + (pix < PP_NPIX ? pix : PP_NPIX) * 16;
     }
     const int w_lds = PP_W0 + sw * PP_PLANE_W + nn_w * 16;                          // + tap * 1024 + parity * PP_W_BYTES
-    const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)nn_w * p.CinPad + sw * S;
-    const size_t w_tap_stride = (size_t)p.CoutPad * p.CinPad;
-    const int CinPad = p.CinPad;
+    const T* wbase = reinterpret_cast<const T*>(p.w) + nn_w * 32 + sw * S;      // packed [chunk][tap][CoutPad][32]
+    const int CoutPad = p.CoutPad;
     // MFMA fragment bases: lane (li, h) reads entry li (+ immediate) of plane ks*2 + h
     const int a_base = h * PP_PLANE_A + (wave * 2 * PP_PW + li) * 16;
     const int b_base = PP_W0 + h * PP_PLANE_W + li * 16;
 
     // ---- pipeline registers
-    uint4 raw[PP_NIT], wr[PP_WIT];
+    uint4 raw[PP_NIT] = {}, wr[PP_WIT] = {};
     float scC[S], shC[S], scL[S], shL[S];
     float slopeC = 1.f, slopeL = 1.f;
     bool liveC = false, liveL = false;
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
         raw[b] = ld16g(ldbase + (unsigned)((y * W + x) * ldC));
     };
     auto issue_w = [&](int t) {
-        wr[t] = ld16(wbase + (size_t)t * w_tap_stride + (size_t)L.n0 * CinPad + L.c * 32);
+        wr[t] = ld16(wbase + ((size_t)(L.c * 9 + t) * CoutPad + L.n0) * 32);
     };
     auto consume_item = [&](int b, int par) {
         const int y = Cs.y0 - 1 + (it_yx[b] >> 16), x = Cs.x0 - 1 + (it_yx[b] & 0xffff);
@@ -243,6 +260,89 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
 
     f32x16 acc[2][2];
 
+    // ---- LEAN: per-lane BatchNorm partial sums (sum, sum of squares of conv + bias, fp32) of the current (channel block,
+    //      group) run and that block's bias; a lane owns channels n0 + nb*32 + 16v + 8h + e of pixel column li
+    float sa[2][2][S], sb[2][2][S], bs[2][2][S];
+    int cur_n0 = -1, cur_g = -1;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < S; ++e) sa[nb][v][e] = sb[nb][v][e] = bs[nb][v][e] = 0.f;
+    auto flush_stats = [&]() {
+        if (cur_n0 < 0) return;
+        const int slot = blockIdx.x % RD_STAT_SLOTS;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int e = 0; e < S; ++e) {
+                    float a = sa[nb][v][e], b = sb[nb][v][e];
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) {
+                        a += __shfl_xor(a, o, 64);
+                        b += __shfl_xor(b, o, 64);
+                    }
+                    if constexpr (MODE == 1) {
+                        if (li == 0 && p.stats) {
+                            const size_t so = (((size_t)cur_g * RD_STAT_SLOTS + slot) * p.Cout + cur_n0 + nb * 32 + 16 * v + 8 * h + e) * 2;
+                            atomicAdd(&p.stats[so + 0], a);
+                            atomicAdd(&p.stats[so + 1], b);
+                        }
+                    } else {
+                        const int c = cur_n0 + nb * 32 + 16 * v;
+                        const int di = c >= p.c_split ? 1 : 0;
+                        const rd_dst_t d = select_dst(p, di);
+                        if (li == 0 && d.kind != RD_DST_NONE && d.bstats) {
+                            const int gd = d.g_fixed >= 0 ? d.g_fixed : cur_g;
+                            const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * d.Cd + c - (di ? p.c_split : 0) + 8 * h + e) * 2;
+                            atomicAdd(&d.bstats[so + 0], a);
+                            atomicAdd(&d.bstats[so + 1], b);
+                        }
+                    }
+                    sa[nb][v][e] = sb[nb][v][e] = 0.f;
+                }
+    };
+
+    // ---- MODE 2: producer BN coefficients of the destinations (bs = scale, dsh = shift) and the prefetched operands
+    float dsh[2][2][S];
+    uint4 zq[2][2][2], gq[2][2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                zq[mb][nb][v] = gq[mb][nb][v] = make_uint4(0, 0, 0, 0);
+                if (mb == 0) {
+#pragma unroll
+                    for (int e = 0; e < S; ++e) dsh[nb][v][e] = 0.f;
+                }
+            }
+    auto dst_index = [&](const rd_dst_t& d, int di, int nb, int v, int y, int x) -> size_t {
+        const int cd = M.n0 + nb * 32 + 16 * v - (di ? p.c_split : 0) + 8 * h;
+        return ((size_t)((M.n + d.n_off) * H + y) * W + x) * d.Cd + cd;
+    };
+    auto dgrad_prefetch = [&]() {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int y = min(M.y0 + wave * 2 + mb, H - 1), x = min(M.x0 + li, W - 1);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int di = (M.n0 + nb * 32 + 16 * v) >= p.c_split ? 1 : 0;
+                    const rd_dst_t d = select_dst(p, di);
+                    if (d.kind == RD_DST_NONE) continue;
+                    const size_t idx = dst_index(d, di, nb, v, y, x);
+                    if (d.z) zq[mb][nb][v] = ld16(reinterpret_cast<const T*>(d.z) + idx);
+                    if (d.accumulate) gq[mb][nb][v] = ld16(reinterpret_cast<const T*>(d.g) + idx);
+                }
+        }
+    };
+
     // ---- prologue: step 0 into buffer 0, step 1 requested
     begin_issue();
 #pragma unroll
@@ -269,6 +369,9 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
         }
+        if constexpr (MODE == 2) {
+            if (M.c == q.nch - 1) dgrad_prefetch();
+        }
         load_frags(0, par, fr[0]);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -280,8 +383,12 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[mb][ks]),
-                                                                              __builtin_bit_cast(bf16x8, f.b[nb][ks]), acc[mb][nb], 0, 0, 0);
+                        if constexpr (LEAN)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[nb][ks]),
+                                                                                  __builtin_bit_cast(bf16x8, f.a[mb][ks]), acc[mb][nb], 0, 0, 0);
+                        else
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[mb][ks]),
+                                                                                  __builtin_bit_cast(bf16x8, f.b[nb][ks]), acc[mb][nb], 0, 0, 0);
             // fill of step s+1 / requests of step s+2, one piece per tap
             if (t == 0) begin_issue();
             if (t >= 3) {
@@ -293,13 +400,116 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
             __builtin_amdgcn_sched_barrier(0);
         }
         if (M.c == q.nch - 1) {
-            const int slot = (M.txy + 7 * M.n) % RD_STAT_SLOTS;
-            conv_epilogue<T, 2>(p, acc, smem + PP_EPI, tid, M.n, M.g, M.y0, M.x0, M.n0, slot);
+            if constexpr (MODE == 1) {
+                if (M.n0 != cur_n0 || M.g != cur_g) {
+                    flush_stats();
+                    cur_n0 = M.n0;
+                    cur_g = M.g;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v)
+#pragma unroll
+                            for (int e = 0; e < S; ++e) bs[nb][v][e] = p.bias ? p.bias[M.n0 + nb * 32 + 16 * v + 8 * h + e] : 0.f;
+                }
+                T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const int y = M.y0 + wave * 2 + mb, x = M.x0 + li;
+                    const bool valid = y < H && x < W;
+                    T* orow = out + ((size_t)(M.n * H + y) * W + x) * p.Cout + M.n0 + 8 * h;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            // accumulator rows: channel (r&3) + 8*(r>>2) + 4*h; the swap leaves lanes h=0 with channels
+                            // 16v..16v+7 and lanes h=1 with 16v+8..16v+15 of this 32-channel block (as in conv_small.hip)
+                            float o[S];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const unsigned a = __float_as_uint(acc[mb][nb][8 * v + j]);
+                                const unsigned b = __float_as_uint(acc[mb][nb][8 * v + 4 + j]);
+                                const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                                o[j] = __uint_as_float(r[0]) + bs[nb][v][j];
+                                o[4 + j] = __uint_as_float(r[1]) + bs[nb][v][4 + j];
+                            }
+                            if (valid) {
+#pragma unroll
+                                for (int e = 0; e < S; ++e) {
+                                    sa[nb][v][e] += o[e];
+                                    sb[nb][v][e] += o[e] * o[e];
+                                }
+                                *reinterpret_cast<uint4*>(orow + nb * 32 + 16 * v) = Slot<T>::pack(o);
+                            }
+                        }
+                }
+            } else if constexpr (MODE == 2) {
+                if (M.n0 != cur_n0 || M.g != cur_g) {
+                    flush_stats();
+                    cur_n0 = M.n0;
+                    cur_g = M.g;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const int c = M.n0 + nb * 32 + 16 * v;
+                            const int di = c >= p.c_split ? 1 : 0;
+                            const rd_dst_t d = select_dst(p, di);
+                            const bool ok = d.kind != RD_DST_NONE && d.scale != nullptr;
+                            const int gd = d.g_fixed >= 0 ? d.g_fixed : M.g;
+                            const int cd = c - (di ? p.c_split : 0) + 8 * h;
+#pragma unroll
+                            for (int e = 0; e < S; ++e) {
+                                bs[nb][v][e] = ok ? d.scale[gd * d.Cd + cd + e] : 1.f;
+                                dsh[nb][v][e] = ok ? d.shift[gd * d.Cd + cd + e] : 0.f;
+                            }
+                        }
+                }
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const int y = M.y0 + wave * 2 + mb, x = M.x0 + li;
+                    const bool valid = y < H && x < W;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            float da[S];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const unsigned a = __float_as_uint(acc[mb][nb][8 * v + j]);
+                                const unsigned b = __float_as_uint(acc[mb][nb][8 * v + 4 + j]);
+                                const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                                da[j] = __uint_as_float(r[0]);
+                                da[4 + j] = __uint_as_float(r[1]);
+                            }
+                            const int di = (M.n0 + nb * 32 + 16 * v) >= p.c_split ? 1 : 0;
+                            const rd_dst_t d = select_dst(p, di);
+                            if (d.kind == RD_DST_NONE || !valid) continue;
+                            float z[S], gw[S];
+                            Slot<T>::unpack(zq[mb][nb][v], z);
+                            Slot<T>::unpack(gq[mb][nb][v], gw);
+                            const bool masked = d.act && d.z;
+#pragma unroll
+                            for (int e = 0; e < S; ++e) {
+                                const float m = masked ? act_grad(z[e] * bs[nb][v][e] + dsh[nb][v][e], d.slope) : 1.f;
+                                const float gn = da[e] * m;
+                                sa[nb][v][e] += gn;
+                                sb[nb][v][e] += gn * (d.z ? z[e] : 0.f);
+                                gw[e] = (d.accumulate ? gw[e] : 0.f) + gn;
+                            }
+                            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(d.g) + dst_index(d, di, nb, v, y, x)) = Slot<T>::pack(gw);
+                        }
+                }
+            } else {
+                const int slot = (M.txy + 7 * M.n) % RD_STAT_SLOTS;
+                conv_epilogue<T, 2>(p, acc, smem + PP_EPI, tid, M.n, M.g, M.y0, M.x0, M.n0, slot);
+            }
         }
         M = Cs;
         shift_stages();
         __syncthreads();
     }
+    if constexpr (LEAN) flush_stats();
 }
 
 // plain per-pixel single-operand sources made of whole 16-byte channel slots (the fill above is branch-free)
@@ -322,15 +532,44 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RD_CONV_PP_NA;
         n_cu = prop.multiProcessorCount;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / PP_NT);
     // Measured (gpurun_out/lb_pp*.txt): with at most one tile per CU -- the 25x25 level -- the pipelined K loop wins
     // 1.06-1.2x; on longer tile ranges the un-overlapped epilogue (2100 VALU per tile and wave, one workgroup per CU)
     // costs more than the K loop gains (0.7-0.9x), so those launches stay with conv_pf_kernel.  RD_CONV_PP_ALL=1 lifts the limit.
     static const bool pp_all = getenv("RD_CONV_PP_ALL") != nullptr;
-    if (tiles > n_cu && !pp_all) return RD_CONV_PP_NA;
+    // forward launches whose output is whole 64-channel blocks take the register epilogue (LEAN) at any size
+    // Which launches take this kernel (layer timings in gpurun_out/lb_lean*.txt, us, conv_pf_kernel -> this kernel):
+    //   forward, >= 3 tiles per CU:  64->64 @200x200 121 -> 97, 128->128 @100x100 113 -> 98, 128->64 @100x100 67 -> 62,
+    //                                64->64 @100x100 49 -> 45;  with fewer tiles it loses (128->128 @50x50 38 -> 40):
+    //                                the register epilogue pays once there are enough tiles to pipeline across;
+    //   gradient (MODE 2):           slower almost everywhere (40 -> 57, 74 -> 87; only 64->64 @200x200 gains, 155 -> 142):
+    //                                its sources are already-materialised dz tensors, which conv_pf_kernel streams with
+    //                                two workgroups per CU -- opt-in only (RD_CONV_PP_LEAN2=1).
+    static const bool lean_off = getenv("RD_CONV_PP_LEAN_OFF") != nullptr, lean2_on = getenv("RD_CONV_PP_LEAN2") != nullptr;
+    int lean = 0;
+    if (!lean_off && p.Cout == p.CoutPad) {
+        if (p.emode == 0 && (((uintptr_t)p.out) & 15) == 0 && (tiles >= 3 * n_cu || pp_all)) lean = 1;
+        if (p.emode == 1 && lean2_on && p.c_split % 16 == 0) {
+            bool ok = true, any = false;
+            for (int i = 0; i < 2; ++i) {
+                const rd_dst_t& d = p.dst[i];
+                if (i == 1 && p.c_split >= p.Cout) break;          // dst[1] unused
+                if (d.kind == RD_DST_NONE) continue;
+                any = true;
+                const int width = i == 0 ? (p.c_split < p.Cout ? p.c_split : p.Cout) : p.Cout - p.c_split;
+                ok = ok && d.kind == RD_DST_PLAIN && d.Cd % 8 == 0 && d.Cd >= width && (((uintptr_t)d.g | (uintptr_t)d.z) & 15) == 0;
+            }
+            if (ok && any) lean = 2;
+        }
+    }
+    if (!lean && tiles > n_cu && !pp_all) return RD_CONV_PP_NA;
     const int grid = tiles < n_cu ? tiles : n_cu;
-    hipLaunchKernelGGL(conv_pp_kernel, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
+    if (lean == 1) hipLaunchKernelGGL(conv_pp_kernel<1>, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
+    else if (lean == 2) hipLaunchKernelGGL(conv_pp_kernel<2>, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
+    else hipLaunchKernelGGL(conv_pp_kernel<0>, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
     return (int)hipGetLastError();
 }

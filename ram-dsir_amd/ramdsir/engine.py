@@ -421,11 +421,13 @@ class Plan:
             ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
             self.keep.append(wg)
             node.wg = wg
-            self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt), dict(kernel='wgrad', side=True, layer='%s.%s' % (node.mname, node.name))))
+            node.side_meta = [dict(kernel='wgrad', side=True, side_idx=0, layer='%s.%s' % (node.mname, node.name))]
+            self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt), node.side_meta[0]))
             if node.has_bias_grad:
                 node.bias_ws = self.alloc_f32(8192)
+                node.side_meta.append(dict(kernel='colsum', side=True, side_idx=0))
                 self.bwd.append((lib.rd_colsum, (o.grad_buf().data_ptr(), self.bank.g(node.mname, node.name + '.bias').data_ptr(),
-                                                 node.bias_ws.data_ptr(), N * H * W, o.C, o.gCs, 0.0, dt), dict(kernel='colsum', side=True)))
+                                                 node.bias_ws.data_ptr(), N * H * W, o.C, o.gCs, 0.0, dt), node.side_meta[1]))
             # dgrad (skipped when no input needs a gradient, i.e. the first conv on the image)
             dsts = []
             for (a, mode, n_off, g_fixed) in node.inputs:
@@ -484,10 +486,17 @@ class Plan:
                     bytes=N * H * W * (Cin + Cout) * esz, flops=2 * N * H * W * Cin * Cout * node.taps)
 
     def bind_workspace(self, ws):
-        """ws: float32 tensor of at least ws_bytes/4 elements, shared by all plans of a step."""
-        for node in self.nodes:
+        """ws: float32 tensor of at least ws_bytes/4 elements, or a list of them: the weight-gradient launches then
+        alternate between the workspaces, and carry side_idx = which one, so that launches on different side streams
+        never share a split workspace (Plan.run_lanes sends side_idx k to lane 'side<k>')."""
+        wss = list(ws) if isinstance(ws, (list, tuple)) else [ws]
+        k = 0
+        for node in reversed(self.nodes):                 # backward order = launch order
             if hasattr(node, 'wg'):
-                node.wg.partial = ws.data_ptr()
+                node.wg.partial = wss[k % len(wss)].data_ptr()
+                for m in node.side_meta:
+                    m['side_idx'] = k % len(wss)
+                k += 1
 
     @staticmethod
     def run(ops, stream):
@@ -500,8 +509,9 @@ class Plan:
     @staticmethod
     def run_lanes(ops, main, lanes, wrap=None):
         """Launch `ops` in list order over up to three HIP streams.  `lanes` maps lane names to torch streams:
-          'side' -- ops tagged side=True (weight gradients, bias column sums: nothing in the backward chain depends
-                    on them) go there, each behind an event recorded at its position in the main stream;
+          'side<k>' -- ops tagged side=True (weight gradients, bias column sums: nothing in the backward chain depends
+                    on them) with side_idx k go there, each behind an event recorded at its position in the main stream
+                    (two side streams: the split reduction of one layer runs beside the MFMA kernel of the next);
           'rec'  -- ops tagged lane='rec' (the restoration decoder's forward, loss and backward: independent of
                     the seg decoder between the bottleneck and the encoder backward) run there in their own
                     order, their weight gradients inline;
@@ -529,10 +539,13 @@ class Plan:
             if meta is not None:
                 if meta.get('lane') == 'rec' and 'rec' in lanes:
                     st = lanes['rec']
-                elif meta.get('side') and 'side' in lanes:
-                    st = lanes['side']
+                elif meta.get('side') and 'side0' in lanes:
+                    name = 'side%d' % meta.get('side_idx', 0)
+                    if name not in lanes:
+                        name = 'side0'
+                    st = lanes[name]
                     st.wait_stream(main)
-                    open_lanes.add('side')
+                    open_lanes.add(name)
 
             def launch(fn=fn, args=args, st=st):
                 err = fn(*args, st.cuda_stream)

@@ -55,7 +55,8 @@ class TrainStep:
         self.rec.build(self.wpack)
         # weight-gradient split workspaces: one per plan, because the restoration decoder's backward runs beside
         # the seg decoder's on its own stream
-        self.ws = torch.empty(max(self.seg.ws_bytes, 4) // 4 + 1, dtype=torch.float32, device=dev)
+        self.n_side = max(1, int(os.environ.get('RD_SIDE_STREAMS', '1')))
+        self.ws = [torch.empty(max(self.seg.ws_bytes, 4) // 4 + 1, dtype=torch.float32, device=dev) for _ in range(self.n_side)]
         self.rec_wsp = torch.empty(max(self.rec.ws_bytes, 4) // 4 + 1, dtype=torch.float32, device=dev)
         self.seg.bind_workspace(self.ws)
         self.rec.bind_workspace(self.rec_wsp)
@@ -104,7 +105,7 @@ class TrainStep:
         # RD_FORK=0: everything on one stream.  Captured into a hipGraph the same forks become parallel branches,
         # which ROCm 7's graph executor runs SLOWER than the single chain (measured), so
         # capture() records the one-stream order.
-        self.side = torch.cuda.Stream(device=dev)
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(self.n_side)]
         self.rec_stream = torch.cuda.Stream(device=dev)
         self.fork = os.environ.get('RD_FORK', '1') != '0'
         self.rec_lane = os.environ.get('RD_REC_LANE', '1') != '0'
@@ -150,7 +151,7 @@ class TrainStep:
     def lanes(self):
         if not self.fork:
             return {}
-        out = {'side': self.side}
+        out = {'side%d' % k: st for k, st in enumerate(self.side)}
         if self.rec_lane:
             out['rec'] = self.rec_stream
         return out
