@@ -26,11 +26,14 @@ for p in (ROOT, os.path.join(ROOT, 'ram-dsir_amd')):
 import numpy as np
 import torch
 
-# Largest share of step time in profiles/ (rocprofv3 --stats): the 3x3 convolutions with 64-wide output-channel tiles
-# (>= 64-channel layers, forward and dgrad) = conv_pf_kernel<bf16,9,2,*> (chunk-pipelined) + conv_kernel<bf16,9,2>
-# (pooled sources) + conv_pp_kernel (persistent variant, 25x25 level).
-DOMINANT = 'conv_kernel<bf16,9,2>'
-DOMINANT_SYMBOLS = ('conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel')   # mangled-name fragments (profiles/)
+# Kernel families of the step with their share of the summed kernel time in profiles/r01_bench_kernel_stats.csv (rocprofv3
+# --stats of this command): weight gradients (wgrad_tr / wgrad_c16_tr / wgrad_t + their split reduce) 37 %, small-channel
+# convs 20 %, 3x3 convs on 64-wide output-channel tiles 16 %.  `roofline` is the weight-gradient family (one launch =
+# one rd_wgrad call = MFMA kernel + split reduction); `roofline_conv64` keeps the previous rounds' family for continuity.
+DOMINANT = 'wgrad'
+DOMINANT_SYMBOLS = ('wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_t_kernel', 'wgrad_c16_kernel', 'wgrad_reduce_kernel')   # mangled-name fragments (profiles/)
+CONV64 = 'conv_kernel<bf16,9,2>'         # conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> (pooled sources) + conv_pp_kernel
+CONV64_SYMBOLS = ('conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel')
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF (no sparsity)
 
@@ -73,7 +76,7 @@ def init_weights(bank):
             v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * bound).to(v.device))
 
 
-def dominant_kernel_roofline(ts, eager=True):
+def kernel_roofline(ts, family, eager=True):
     """One more step, launched exactly like the timed ones (eager: weight-gradient kernels on the side stream and the
     restoration-decoder branch on its own stream, so the timed launches see the same contention), with HIP events
     recorded on the stream each launch goes to around every launch of the dominant kernel family; the algorithmic
@@ -84,7 +87,7 @@ def dominant_kernel_roofline(ts, eager=True):
 
     def wrap(op, stream, launch):
         meta = op[2] if len(op) > 2 else None
-        if meta is None or meta.get('kernel') != DOMINANT:
+        if meta is None or meta.get('kernel') != family:
             return launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -112,12 +115,15 @@ def dominant_kernel_roofline(ts, eager=True):
     tpath = os.path.join(ROOT, 'profiles', 'dominant_kernel_pmc.json')
     if os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = int(json.load(f)['traffic_bytes_per_launch'])
+            tj = json.load(f)
+        tj = tj.get(family, tj) if isinstance(tj.get(family, None), dict) else tj
+        if tj.get('family', family) == family and 'traffic_bytes_per_launch' in tj:
+            traffic = int(tj['traffic_bytes_per_launch'])
     if intensity >= ridge:
         out = dict(bound='mfma', achieved=round(tfs, 1), peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tfs / MFMA_PEAK_TFLOPS, 4))
     else:
         out = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
-    out.update(traffic=traffic, kernel=DOMINANT, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
+    out.update(traffic=traffic, kernel=family, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
                avg_algorithmic_bytes=int(nbytes / n), avg_flops=int(flops / n), flop_per_byte=round(intensity, 1),
                achieved_gbs=round(gbs, 1), achieved_tflops=round(tfs, 1))
     return out
@@ -231,7 +237,8 @@ def main():
                        'final_loss': round(losses['loss'], 4)},
         }
         if args.dtype == 'bf16':
-            out['roofline'] = dominant_kernel_roofline(ts, eager=not args.graph)
+            out['roofline'] = kernel_roofline(ts, DOMINANT, eager=not args.graph)
+            out['roofline_conv64'] = kernel_roofline(ts, CONV64, eager=not args.graph)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(host_inputs, bs)
         print(json.dumps(out), flush=True)

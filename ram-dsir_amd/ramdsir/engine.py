@@ -16,6 +16,7 @@ Design (MI355X-first):
     per-channel P*g+Q*z+R folded into the reads of the next dgrad / wgrad.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -421,7 +422,13 @@ class Plan:
             ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
             self.keep.append(wg)
             node.wg = wg
-            node.side_meta = [dict(kernel='wgrad', side=True, side_idx=0, layer='%s.%s' % (node.mname, node.name))]
+            # algorithmic work of the weight gradient (SURVEY.md 8d convention): the conv's logical input read once + the
+            # gradient w.r.t. its output read once (a BN-backward source is two tensors: g and the raw z); dW is negligible
+            esz = 2 if self.dtype == torch.bfloat16 else 4
+            dz_ops = 2 if wg.dz.mode == L.SRC_BNBWD else 1
+            dz_c = o.gCs if o.norm is None else o.C
+            node.side_meta = [dict(kernel='wgrad', side=True, side_idx=0, layer='%s.%s' % (node.mname, node.name),
+                                   bytes=N * H * W * (node.Cin + dz_ops * dz_c) * esz, flops=2 * N * H * W * node.Cin * node.Cout * node.taps)]
             self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt), node.side_meta[0]))
             if node.has_bias_grad:
                 node.bias_ws = self.alloc_f32(8192)
@@ -476,6 +483,11 @@ class Plan:
         once + the output written once, in the storage dtype."""
         esz = 2 if self.dtype == torch.bfloat16 else 4
         nb = 2 if ((Cout + 31) // 32 * 32) % 64 == 0 else 1
+        if nb == 2 and self.dtype == torch.bfloat16:
+            # csrc/conv_big.hip rd_conv_big_dispatch: grids below RD_CONV_NB1_BELOW 64-wide workgroups run 32-wide tiles
+            wgs64 = ((W + 31) // 32) * ((H + 7) // 8) * N * (((Cout + 31) // 32 * 32) // 64)
+            if wgs64 < int(os.environ.get('RD_CONV_NB1_BELOW', '300')):
+                nb = 1
         tname = 'bf16' if self.dtype == torch.bfloat16 else 'f32'
         ck = 32 if self.dtype == torch.bfloat16 else 16
         if Cin <= ck and Cout <= 32:
