@@ -111,7 +111,7 @@ class Encoder(M.FusedModule):
             for a in pl.feats:
                 a.g_written = True                      # their gradient arrives from torch first (rd_grad_in)
             pl.build(self._wpack)
-            pl.ws = torch.empty(max(pl.ws_bytes // 4, 1), dtype=torch.float32, device=x.device)
+            pl.ws = E.workspace(pl.ws_bytes // 4, x.device)
             pl.bind_workspace(pl.ws)
             return pl
         pl = self._acquire_plan((N, H, W, training, M.storage_dtype()), build)
@@ -149,7 +149,7 @@ class Decoder(M.FusedModule):
             pl.logits = E.build_decoder(pl, pl.ins, n=self._n, num_classes=self._k, mname=self._mname)
             pl.logits.g_written = True
             pl.build(self._wpack)
-            pl.ws = torch.empty(max(pl.ws_bytes // 4, 1), dtype=torch.float32, device=feats[0].device)
+            pl.ws = E.workspace(pl.ws_bytes // 4, feats[0].device)
             pl.bind_workspace(pl.ws)
             return pl
         pl = self._acquire_plan((shapes, training, M.storage_dtype()), build)
@@ -188,7 +188,7 @@ class Rec_Decoder(M.FusedModule):
                                          mname=self._mname)
             pl.out.g_written = True
             pl.build(self._wpack)
-            pl.ws = torch.empty(max(pl.ws_bytes // 4, 1), dtype=torch.float32, device=x.device)
+            pl.ws = E.workspace(pl.ws_bytes // 4, x.device)
             pl.bind_workspace(pl.ws)
             return pl
         pl = self._acquire_plan((N, Cc, H, W, d, training, M.storage_dtype()), build)

@@ -26,6 +26,14 @@ EPS = 1e-5
 MOMENTUM = 0.1
 
 
+def workspace(n, device):
+    """Scratch float32 buffer whose contents the kernels must never rely on.  RD_POISON=1 fills it with NaN, so a kernel
+    that reads a workspace element nobody wrote shows up as NaN in every GPU test instead of as a rare flake."""
+    if os.environ.get('RD_POISON') == '1':
+        return torch.full((max(int(n), 1),), float('nan'), dtype=torch.float32, device=device)
+    return torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
+
+
 # ------------------------------------------------------------------------------------------------ specs
 def _conv_spec(out, name, cin, cout, k):
     out.append((name + '.weight', (cout, cin, k, k), 'param', torch.float32))

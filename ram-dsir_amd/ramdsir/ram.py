@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import engine as E
 
 
 def window_half_width(h, w, ratio=0.1):
@@ -31,7 +32,7 @@ class RamMixer:
         self.dtype = dtype
         self.b = window_half_width(H, W, ratio)
         lib = L.lib()
-        self.ws = torch.empty(max(lib.rd_ram_workspace(B, H, W, self.b) // 4, 1), dtype=torch.float32, device=device)
+        self.ws = E.workspace(lib.rd_ram_workspace(B, H, W, self.b) // 4, device)
         self.tw_w, self.tw_h = _twiddle(W, device), _twiddle(H, device)
         p = L.RdRam()
         p.workspace, p.tw_w, p.tw_h = self.ws.data_ptr(), self.tw_w.data_ptr(), self.tw_h.data_ptr()

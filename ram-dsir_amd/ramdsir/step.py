@@ -56,8 +56,8 @@ class TrainStep:
         # weight-gradient split workspaces: one per plan, because the restoration decoder's backward runs beside
         # the seg decoder's on its own stream
         self.n_side = max(1, int(os.environ.get('RD_SIDE_STREAMS', '1')))
-        self.ws = [torch.empty(max(self.seg.ws_bytes, 4) // 4 + 1, dtype=torch.float32, device=dev) for _ in range(self.n_side)]
-        self.rec_wsp = torch.empty(max(self.rec.ws_bytes, 4) // 4 + 1, dtype=torch.float32, device=dev)
+        self.ws = [E.workspace(max(self.seg.ws_bytes, 4) // 4 + 1, dev) for _ in range(self.n_side)]
+        self.rec_wsp = E.workspace(max(self.rec.ws_bytes, 4) // 4 + 1, dev)
         self.seg.bind_workspace(self.ws)
         self.rec.bind_workspace(self.rec_wsp)
         # ---- losses
@@ -75,10 +75,10 @@ class TrainStep:
         sl.kind = 0 if dataset == 'fundus' else 1
         sl.consistency = {None: 0, 'kd': 1, 'mse': 2}[consistency]
         sl.cons_weight = 0.5
-        self.seg_ws = torch.empty(lib.rd_seg_loss_workspace(C.byref(sl)) // 4, dtype=torch.float32, device=dev)
+        self.seg_ws = E.workspace(lib.rd_seg_loss_workspace(C.byref(sl)) // 4, dev)
         sl.partial = self.seg_ws.data_ptr()
         self.sl = sl
-        self.rec_ws = torch.empty(max(lib.rd_rec_loss_workspace(B, H, W, in_channels) // 4, 1), dtype=torch.float32, device=dev)
+        self.rec_ws = E.workspace(lib.rd_rec_loss_workspace(B, H, W, in_channels) // 4, dev)
         self.lambda_rec = lambda_rec
         # ---- optimizer
         bank.ensure_adam()
