@@ -3,6 +3,7 @@ same op on the same seeded inputs.  Tolerance = 4 x gpu_util.RTOL x RMS(referenc
 bit-exact fmaf chain; only the summation order differs), bf16 4e-2 x RMS (inputs pre-rounded to bf16, operands of
 the MFMA and the stored result rounded once each: a few bf16 ulps of the largest elements)."""
 import ctypes as C
+import os
 import zlib
 
 import numpy as np
@@ -645,3 +646,26 @@ def test_layout_boundary_kernels(dtype):
     L.check(L.lib().rd_colsum(L.ptr(t3p), L.ptr(outc), L.ptr(wsb), 2 * 20 * 30, 3, 8, 0.0, U.DT[dtype][0], None), 'colsum pad')
     torch.cuda.synchronize()
     np.testing.assert_allclose(outc.cpu(), t3.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ conv_pp_kernel, every mode
+@pytest.mark.parametrize('env', [
+    {'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0'},                              # MODE 1 forward, MODE 0 (staged) gradients
+    {'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_PP_LEAN2': '1'},     # + MODE 2 register gradient epilogue
+    {'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_PP_LEAN_OFF': '1'},  # MODE 0 everywhere
+    {'RD_CONV_NB1_BELOW': '100000'},                                                # 32-wide tiles for every 64-wide launch
+], ids=['pp_lean_fwd', 'pp_lean_fwd_bwd', 'pp_staged', 'nb1_everywhere'])
+def test_conv_kernels_under_forced_dispatch(env):
+    """The persistent pipelined kernel only takes large forward launches by default (the cases above are small), and the
+    dispatch switches are read once per process: re-run the conv parity tests in a child process with every eligible
+    launch forced through conv_pp_kernel (each epilogue mode) / through the 32-wide tiles."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
+                        'test_conv_forward or test_conv_gradient_epilogues or test_conv_bnbwd'], env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-2500:]
+    assert r.returncode == 0, tail
+    assert ' passed' in tail and 'failed' not in tail, tail
