@@ -364,6 +364,21 @@ __device__ __forceinline__ GroupMap make_gm(const int32_t* gstart, int G) {
     return gm;
 }
 
+// XCD-aware block order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own
+// L2), so neighbouring tiles -- which share halo rows / columns, and the output-channel blocks of one pixel tile, which
+// share the whole input tile -- would land on 8 different L2s and each fetch the shared data from the fabric again.
+// Remap the linear id so that XCD k works on the k-th contiguous eighth of the grid (x = pixel tile fastest).
+__device__ __forceinline__ void xcd_block(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * gridDim.z;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int xcd = lin & 7, idx = lin >> 3, q = total >> 3, r = total & 7;
+    const int l2 = xcd * q + min(xcd, r) + idx;
+    bx = l2 % gx;
+    by = (l2 / gx) % gy;
+    bz = l2 / (gx * gy);
+}
+
 // ------------------------------------------------------------------------------------ MFMA atoms
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {

@@ -10,3 +10,25 @@ int64_t rd_wgrad_ws_bytes(const rd_wgrad_t& p, int dtype);
 // RD_CONV_PP_NA when the launch does not qualify (the caller falls back to conv_big's kernels)
 constexpr int RD_CONV_PP_NA = -1000;
 int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st);
+
+// Register ("lean") epilogues: accumulators leave as 16-byte NHWC vectors straight from registers (MFMA roles swapped:
+// weights x pixels, v_permlane32_swap regroup) instead of through the LDS-staged epilogue of conv_epilogue.h.
+// 0 = not eligible, 1 = forward, 2 = gradient with plain destinations only.  NT = output channels per workgroup.
+inline int rd_conv_lean_mode(const rd_conv_t& p, int NT) {
+    if (p.Cout != p.CoutPad || p.Cout % NT) return 0;
+    if (p.emode == 0) return (((uintptr_t)p.out) & 15) == 0 ? 1 : 0;
+    if (p.c_split % 16) return 0;
+    bool any = false;
+    for (int i = 0; i < 2; ++i) {
+        const rd_dst_t& d = p.dst[i];
+        if (i == 1 && p.c_split >= p.Cout) break;              // dst[1] unused
+        if (d.kind == RD_DST_NONE) continue;
+        any = true;
+        const int width = i == 0 ? (p.c_split < p.Cout ? p.c_split : p.Cout) : p.Cout - p.c_split;
+        if (d.kind != RD_DST_PLAIN || d.Cd % 8 || d.Cd < width || (((uintptr_t)d.g | (uintptr_t)d.z) & 15)) return 0;
+        if (d.scale && (((uintptr_t)d.scale | (uintptr_t)d.shift) & 3)) return 0;
+    }
+    return any ? 2 : 0;
+}
+// conv_pf_kernel with a register epilogue (conv_lean.hip); RD_CONV_PP_NA when the launch does not qualify
+int rd_conv_pf_lean_dispatch(const rd_conv_t& p, bool nb2, hipStream_t st);

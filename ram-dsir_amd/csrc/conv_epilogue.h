@@ -114,4 +114,120 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
     }
 }
 
+// ------------------------------------------------------------------------------------ register epilogue (bf16)
+// For accumulators produced with the MFMA roles swapped (A = weights, B = pixels): row (r&3) + 8*(r>>2) + 4*h of block nb
+// is an output channel, the column (lane & 31) a pixel of tile row wave*2 + mb.  v_permlane32_swap regroups a lane's 16
+// channels of a block into two vectors of 8 contiguous channels (lanes h=0: 16v..16v+7, lanes h=1: 16v+8..16v+15), which
+// are stored / combined with the destination tensors as whole 16-byte NHWC slots.  ~1/3 of the instructions of the
+// LDS-staged conv_epilogue above.  EP 1 = forward (+bias, BatchNorm sums), EP 2 = gradient into plain destinations.
+// s_epi: [NT] bias (EP 1) or [2][NT] producer scale / shift of the destination channels (EP 2), staged by the caller.
+template <typename T, int NB, int EP>
+__device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&acc)[2][NB], float* s_red, const float* s_epi,
+                                                   int tid, int n, int g, int y0, int x0, int n0, int slot) {
+    static_assert(sizeof(T) == 2 && (EP == 1 || EP == 2), "bf16, forward or plain-gradient");
+    constexpr int S = 8, NT = NB * 32;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W;
+    if (tid < NT * 2) s_red[tid] = 0.f;
+    __syncthreads();
+    float sa[NB][2][S], sb[NB][2][S];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < S; ++e) sa[nb][v][e] = sb[nb][v][e] = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int y = y0 + wave * 2 + mb, x = x0 + li;
+        const bool valid = y < H && x < W;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int cl = nb * 32 + 16 * v + 8 * h;             // first channel of this lane's vector within the tile
+                float o[S];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned a = __float_as_uint(acc[mb][nb][8 * v + j]);
+                    const unsigned b = __float_as_uint(acc[mb][nb][8 * v + 4 + j]);
+                    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                    o[j] = __uint_as_float(r[0]);
+                    o[4 + j] = __uint_as_float(r[1]);
+                }
+                if constexpr (EP == 1) {
+                    if (!valid) continue;
+#pragma unroll
+                    for (int e = 0; e < S; ++e) {
+                        o[e] += s_epi[cl + e];
+                        sa[nb][v][e] += o[e];
+                        sb[nb][v][e] += o[e] * o[e];
+                    }
+                    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + ((size_t)(n * H + y) * W + x) * p.Cout + n0 + cl) = Slot<T>::pack(o);
+                } else {
+                    const int c = n0 + nb * 32 + 16 * v;             // c_split % 16 == 0: one destination per vector pair
+                    const int di = c >= p.c_split ? 1 : 0;
+                    const rd_dst_t d = select_dst(p, di);
+                    if (d.kind == RD_DST_NONE || !valid) continue;
+                    const size_t idx = ((size_t)((n + d.n_off) * H + y) * W + x) * d.Cd + (c - (di ? p.c_split : 0)) + 8 * h;
+                    uint4 zu = make_uint4(0, 0, 0, 0), gu = make_uint4(0, 0, 0, 0);
+                    if (d.z) zu = ld16(reinterpret_cast<const T*>(d.z) + idx);
+                    if (d.accumulate) gu = ld16(reinterpret_cast<const T*>(d.g) + idx);
+                    float z[S], gw[S];
+                    Slot<T>::unpack(zu, z);
+                    Slot<T>::unpack(gu, gw);
+                    const bool masked = d.act && d.z;
+#pragma unroll
+                    for (int e = 0; e < S; ++e) {
+                        const float m = masked ? act_grad(z[e] * s_epi[cl + e] + s_epi[NT + cl + e], d.slope) : 1.f;
+                        const float gn = o[e] * m;
+                        sa[nb][v][e] += gn;
+                        sb[nb][v][e] += gn * z[e];
+                        gw[e] += gn;
+                    }
+                    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(d.g) + idx) = Slot<T>::pack(gw);
+                }
+            }
+    }
+    // per-channel sums: xor-reduce over the 32 pixel lanes of each half-wave, one LDS atomic per wave half and channel
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                float a = sa[nb][v][e], b = sb[nb][v][e];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    b += __shfl_xor(b, o, 64);
+                }
+                if (li == 0) {
+                    const int cl = nb * 32 + 16 * v + 8 * h + e;
+                    atomicAdd(&s_red[cl * 2 + 0], a);
+                    atomicAdd(&s_red[cl * 2 + 1], b);
+                }
+            }
+    __syncthreads();
+    if (tid < NT) {
+        const int cch = n0 + tid;
+        if constexpr (EP == 1) {
+            if (p.stats) {
+                const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + cch) * 2;
+                atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
+            }
+        } else {
+            const int dj = cch >= p.c_split ? 1 : 0;
+            const rd_dst_t dd = select_dst(p, dj);
+            if (dd.kind != RD_DST_NONE && dd.bstats) {
+                const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
+                const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cch - (dj ? p.c_split : 0)) * 2;
+                atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
+            }
+        }
+    }
+}
+
 }  // namespace
