@@ -98,11 +98,31 @@ class DataParallelStep:
         main = torch.cuda.current_stream()
         works = []
         # segment -> bucket that is complete when it ends: A -> decoders (2), B1 -> deep encoder (1), B2 -> shallow (0)
-        for seg_i, bucket in ((0, 2), (1, 1), (2, 0)):
-            self._run(seg_i, main)
-            self.comm.wait_stream(main)
-            with torch.cuda.stream(self.comm):
-                works.append(self.buckets.reduce(bucket, async_op=True))
+        plan = ((0, 2), (1, 1), (2, 0))
+        if self.graphs is not None:
+            for seg_i, bucket in plan:
+                self._run(seg_i, main)
+                self.comm.wait_stream(main)
+                with torch.cuda.stream(self.comm):
+                    works.append(self.buckets.reduce(bucket, async_op=True))
+        else:
+            # eager: the weight-gradient stream is NOT joined into the main stream at the segment boundaries (that
+            # would serialise the dgrad chain behind the weight gradients three times per step); a bucket's exchange
+            # waits for the main stream and for every lane with work outstanding -- the lanes are in-order queues, so
+            # their state at this point covers exactly the gradients of the segments launched so far
+            ts = self.ts
+            lanes, open_lanes = ts.lanes(), set()
+            ts.zero()
+            segs = self._segments()
+            for seg_i, bucket in plan:
+                open_lanes |= E.Plan.run_lanes(segs[seg_i], main, lanes)
+                self.comm.wait_stream(main)
+                for name in open_lanes:
+                    self.comm.wait_stream(lanes[name])
+                with torch.cuda.stream(self.comm):
+                    works.append(self.buckets.reduce(bucket, async_op=True))
+            for name in open_lanes:
+                main.wait_stream(lanes[name])
         for w in works:
             if w is not None:
                 w.wait()
