@@ -68,7 +68,13 @@ def test_modules_forward_backward_vs_reference_fixture(golden_dir, mode):
         return
     loss = (logits * T(M['wl']).to(DEV)).sum() + (r1 * T(M['wr0']).to(DEV)).sum() + (r2 * T(M['wr1']).to(DEV)).sum()
     loss.backward()
-    # ReLU-kink noise bounds element-wise agreement of deep gradients (see tests/test_gpu_step.py): relative L2
+    # Gradient agreement with the reference fixture is limited by DISCRETE events, not by arithmetic precision: the order of
+    # the fp32 atomics that accumulate the BatchNorm sums varies run to run, the last bit of a batch statistic with it, and
+    # on this 32x32 fixture (2x2-pixel, 2-image batches at the bottleneck) that flips individual ReLU kinks / max-pool ties.
+    # scripts/mod_noise.py, 40 runs on MI355X: 3 runs match to 6e-5 per tensor (2e-5 aggregate), most sit at 1.9e-2 per
+    # tensor (the same flip every time), the tail reached 6.1e-2 per tensor / 2.4e-2 aggregate.  Hence: every tensor within
+    # 1e-1, and the relative L2 error over ALL parameter gradients together within 4e-2.
+    num = den = 0.0
     for nm, m in (('enc', enc), ('dec', dec), ('rec', rec)):
         for k, p in m.named_parameters():
             g = p.grad.cpu() if p.grad is not None else torch.zeros(p.shape)
@@ -76,10 +82,15 @@ def test_modules_forward_backward_vs_reference_fixture(golden_dir, mode):
                 assert float(g.abs().max()) == 0.0
                 continue
             ref = M['train.g%s.sig.%s' % (nm, k)]
-            np.testing.assert_allclose(float(g.double().norm()), np.sqrt(ref[2]), rtol=4e-2, atol=1e-9, err_msg=k)
+            np.testing.assert_allclose(float(g.double().norm()), np.sqrt(ref[2]), rtol=1e-1, atol=1e-9, err_msg=k)
             fk = 'train.g%s.full.%s' % (nm, k)
             if fk in M.files and np.abs(M[fk]).max() > 0:
-                assert rel_l2(g, T(M[fk])) < 4e-2, k
+                r = T(M[fk]).double()
+                assert rel_l2(g, r) < 1e-1, k
+                num += float((g.double() - r).pow(2).sum())
+                den += float(r.pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 4e-2, (num / den) ** 0.5
+    for nm, m in (('enc', enc), ('dec', dec), ('rec', rec)):
         for k, v in m.state_dict().items():
             if 'running' in k or 'num_batches' in k:
                 np.testing.assert_allclose(v.cpu().numpy(), M['train.buf.%s.%s' % (nm, k)], rtol=1e-4, atol=1e-6, err_msg=k)

@@ -1,6 +1,8 @@
 """-m gpu: the fused training step (all HIP, through the C ABI) against (a) the committed fixtures of the
 reference's own step and (b) the oracle run live on the same inputs.  fp32 tolerances: losses 1e-4 rel,
 gradients 2e-3 of each tensor's RMS (fp32 reassociation through ~40 layers), bf16: loss band only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -238,3 +240,52 @@ def test_step_at_baseline_config_shapes(dataset, bs, S):
     assert int(bank.b('enc', 'convd1.bn1.num_batches_tracked')) == 12
     assert int(bank.b('rec', 'convu1.bn3.bns.%d.num_batches_tracked' % (len(bs) - 1))) == 6
     assert int(ts.iter) == 6
+
+
+def test_data_parallel_step_matches_plain_step_on_one_rank(golden_dir):
+    """ramdsir/ddp.py on a world of ONE rank (RCCL all-reduce = identity): the segmented launch (A / B1 / B2 / C with the
+    three bucket exchanges on the communication stream, lanes left open across segment boundaries) must produce the same
+    gradients and losses as the plain step, eagerly and through the per-segment hipGraphs; the buckets must tile the
+    arena.  Gradients are compared after the FIRST step at the tolerance of the other full-step tests (4e-2 relative L2):
+    on this 32x32 fixture two PLAIN runs already differ by 6e-3 (1.2e-2 in the restoration decoder) through the atomics'
+    summation order amplified by 2x2-pixel BatchNorm batches and ReLU kinks (measured; DESIGN.md 'Numerics'), and by 8e-3
+    in the parameters after two Adam steps, so the second step is only held to the loss band."""
+    import torch.distributed as dist
+    from ramdsir import ddp as D
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29577')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        G, meta, states, bank, mods, ts = _setup(golden_dir, 'fundus', torch.float32)
+        _feed(ts, G, 0)
+        ts.step()
+        torch.cuda.synchronize()
+        g_ref, l_ref = bank.grads.cpu().clone(), [ts.losses[i].item() for i in range(5)]
+        _feed(ts, G, 1)
+        ts.step()
+        torch.cuda.synchronize()
+        l_ref2 = [ts.losses[i].item() for i in range(5)]
+        for use_graph in (False, True):
+            G2, _, _, bank2, _, ts2 = _setup(golden_dir, 'fundus', torch.float32)
+            runner = D.DataParallelStep(ts2)
+            b = runner.buckets.bounds
+            assert b[0] == 0 and b[-1] == bank2.n and b == sorted(b) and len(b) == 4
+            assert b[2] == bank2.module_range['enc'][1] and 0 < b[1] < b[2]            # encoder levels 1-2 | 3-5 | decoders
+            if use_graph:
+                runner.capture()
+            _feed(ts2, G2, 0)
+            runner.step()
+            torch.cuda.synchronize()
+            np.testing.assert_allclose([ts2.losses[i].item() for i in range(5)], l_ref, rtol=1e-5)
+            assert rel_l2(bank2.grads.cpu(), g_ref) < 4e-2, use_graph
+            assert float(bank2.grads.abs().max()) > 0
+            _feed(ts2, G2, 1)
+            runner.step()
+            torch.cuda.synchronize()
+            assert int(ts2.iter) == 2
+            np.testing.assert_allclose([ts2.losses[i].item() for i in range(5)], l_ref2, rtol=1e-2)
+    finally:
+        if created:
+            dist.destroy_process_group()
