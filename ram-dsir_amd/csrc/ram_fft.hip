@@ -34,7 +34,7 @@ __device__ __forceinline__ float2 imul(float2 a, float s) { return make_float2(-
 
 // `batch` independent length-N Stockham autosort FFTs in LDS.  Transform t ping-pongs between
 // buf[(t*2+0)*N ..] and buf[(t*2+1)*N ..]; returns which half holds the result (same for every t).
-// tw[k] = (cos 2*pi*k/N, -sin 2*pi*k/N) in global memory (fp64-accurate table from the host).
+// tw[k] = (cos 2*pi*k/N, -sin 2*pi*k/N): the fp64-accurate table from the host, copied into LDS by the caller.
 __device__ int fft_stockham(float2* buf, int batch, const FftPlan& pl, const float2* tw, bool inverse, int tid, int nthreads) {
     const int N = pl.N;
     const float sgn = inverse ? 1.f : -1.f;
@@ -113,15 +113,17 @@ struct RamArgs {
 // divides by |F_src| (the reference's angle()==0 branch, fundus.py:48 on a constant-zero plane).
 __global__ __launch_bounds__(256) void ram_row_fwd_kernel(const RamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    float2* buf = reinterpret_cast<float2*>(smem_);        // [3 transforms][2][W]
+    float2* buf = reinterpret_cast<float2*>(smem_);        // [3 transforms][2][W], then the twiddle table [W]
     const int y = blockIdx.x, n = blockIdx.y, W = a.W, H = a.H;
+    float2* s_tw = buf + 6 * W;                            // twiddles out of LDS: a butterfly no longer waits on L2 for them
+    for (int i = threadIdx.x; i < W; i += blockDim.x) s_tw[i] = a.tw_w[i];
     const float* img = (n < a.B ? a.src + (size_t)n * H * W * 3 : a.trg + (size_t)(n - a.B) * H * W * 3) + (size_t)y * W * 3;
     for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) {
         const int x = i / 3, c = i - 3 * x;
         buf[(size_t)c * 2 * W + x] = make_float2(img[i], 0.f);
     }
     __syncthreads();
-    const int cur = fft_stockham(buf, 3, a.pw, a.tw_w, false, threadIdx.x, blockDim.x);
+    const int cur = fft_stockham(buf, 3, a.pw, s_tw, false, threadIdx.x, blockDim.x);
     const int nb1 = a.b + 1;
     for (int i = threadIdx.x; i < 3 * nb1; i += blockDim.x) {
         const int c = i / nb1, kx = i - c * nb1;
@@ -132,8 +134,10 @@ __global__ __launch_bounds__(256) void ram_row_fwd_kernel(const RamArgs a) {
 // B: grid (b+1, 3, B)
 __global__ __launch_bounds__(256) void ram_col_kernel(const RamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    float2* buf = reinterpret_cast<float2*>(smem_);        // [2 transforms][2][H]
+    float2* buf = reinterpret_cast<float2*>(smem_);        // [2 transforms][2][H], then the twiddle table [H]
     const int kx = blockIdx.x, c = blockIdx.y, n = blockIdx.z, H = a.H, nb1 = a.b + 1;
+    float2* s_tw = buf + 4 * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) s_tw[i] = a.tw_h[i];
     const float2* cs = a.rowspec + ((size_t)(n * 3 + c) * nb1 + kx) * H;
     const float2* ct = a.rowspec + ((size_t)((n + a.B) * 3 + c) * nb1 + kx) * H;
     for (int y = threadIdx.x; y < H; y += blockDim.x) {
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void ram_col_kernel(const RamArgs a) {
         buf[2 * H + y] = ct[y];
     }
     __syncthreads();
-    const int cur = fft_stockham(buf, 2, a.ph, a.tw_h, false, threadIdx.x, blockDim.x);
+    const int cur = fft_stockham(buf, 2, a.ph, s_tw, false, threadIdx.x, blockDim.x);
     const float2* fs = buf + cur * H;
     const float2* ft = buf + (2 + cur) * H;
     float2* din = buf + (cur ^ 1) * H;                      // free half of transform 0 becomes the inverse input
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void ram_col_kernel(const RamArgs a) {
         for (int y = threadIdx.x; y < H; y += blockDim.x) ibuf[y] = din[y];
         __syncthreads();
     }
-    const int c2 = fft_stockham(ibuf, 1, a.ph, a.tw_h, true, threadIdx.x, blockDim.x);
+    const int c2 = fft_stockham(ibuf, 1, a.ph, s_tw, true, threadIdx.x, blockDim.x);
     const float2* yv = ibuf + c2 * H;
     float2* out = a.colout + ((size_t)(n * 3 + c) * nb1 + kx) * H;
     for (int y = threadIdx.x; y < H; y += blockDim.x) out[y] = yv[y];
@@ -174,11 +178,13 @@ __global__ __launch_bounds__(256) void ram_col_kernel(const RamArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void ram_row_inv_kernel(const RamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    float2* buf = reinterpret_cast<float2*>(smem_);        // [2 transforms][2][W]
+    float2* buf = reinterpret_cast<float2*>(smem_);        // [2 transforms][2][W], then the twiddle table [W]
     const int y = blockIdx.x, n = blockIdx.y, W = a.W, H = a.H, nb1 = a.b + 1;
+    float2* s_tw = buf + 4 * W;
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         buf[x] = make_float2(0.f, 0.f);
         buf[2 * W + x] = make_float2(0.f, 0.f);
+        s_tw[x] = a.tw_w[x];
     }
     __syncthreads();
     for (int kx = threadIdx.x; kx < nb1; kx += blockDim.x) {
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256) void ram_row_inv_kernel(const RamArgs a) {
         }
     }
     __syncthreads();
-    const int cur = fft_stockham(buf, 2, a.pw, a.tw_w, true, threadIdx.x, blockDim.x);
+    const int cur = fft_stockham(buf, 2, a.pw, s_tw, true, threadIdx.x, blockDim.x);
     const float2* r01 = buf + cur * W;
     const float2* r2 = buf + (2 + cur) * W;
     const float inv = 1.0f / ((float)H * (float)W);
@@ -247,8 +253,8 @@ int rd_ram_mix(const rd_ram_t* p, int dtype, void* stream) {
     if (a.cs < 3) return -1;
     a.clip_lo = p->clip_lo; a.clip_hi = p->clip_hi; a.scale = p->scale; a.offset = p->offset;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lw = (size_t)4 * p->W * sizeof(float2), lh = (size_t)4 * p->H * sizeof(float2);
-    hipLaunchKernelGGL(ram_row_fwd_kernel, dim3(p->H, 2 * p->B), dim3(256), (size_t)6 * p->W * sizeof(float2), st, a);
+    const size_t lw = (size_t)5 * p->W * sizeof(float2), lh = (size_t)5 * p->H * sizeof(float2);      // + twiddle table
+    hipLaunchKernelGGL(ram_row_fwd_kernel, dim3(p->H, 2 * p->B), dim3(256), (size_t)7 * p->W * sizeof(float2), st, a);
     hipLaunchKernelGGL(ram_col_kernel, dim3(p->b + 1, 3, p->B), dim3(256), lh, st, a);
     if (dtype == RD_BF16) hipLaunchKernelGGL(ram_row_inv_kernel<bf16_t>, dim3(p->H, p->B), dim3(256), lw, st, a);
     else hipLaunchKernelGGL(ram_row_inv_kernel<float>, dim3(p->H, p->B), dim3(256), lw, st, a);
