@@ -1,9 +1,10 @@
 // conv_pp.hip -- persistent, software-pipelined 3x3 convolution for the >=64-channel layers (bf16, 64 output channels
-// per tile, plain per-pixel sources).  Same implicit GEMM, tile (8 x 32 pixels x 64 channels), LDS layout and MFMA
-// (v_mfma_f32_32x32x16_bf16) as conv_big.hip; what changes is WHEN things happen:
+// per tile, plain per-pixel sources).  Same implicit GEMM, tile (8 x 32 pixels x 64 channels) and MFMA
+// (v_mfma_f32_32x32x16_bf16) as conv_pf_kernel (conv_pf.h); what changes is WHEN things happen:
 //
 //   * ONE workgroup per CU (4 wave64, one per SIMD, up to 512 VGPRs), persistent over a contiguous range of tiles
-//     (output-channel block fastest, so the blocks of one pixel tile re-read it from this XCD's L2);
+//     (MODE 0: output-channel block fastest, so the blocks of one pixel tile re-read it from this XCD's L2; MODE 1/2:
+//     channel block slowest, so the BatchNorm sums of a block stay in registers across its tiles);
 //   * the (tile, 32-channel chunk) pairs of that range form one stream of STEPS.  While the MFMAs of step s run out
 //     of LDS buffer s&1, the same waves transform the raw vectors of step s+1 (BN affine + activation, bf16 pack)
 //     into buffer (s+1)&1 and request the vectors of step s+2 from HBM/L2 -- item by item, placed BETWEEN the MFMA
@@ -13,9 +14,10 @@
 //     buffer), one barrier per step, and the pipeline runs ACROSS tiles: the first chunk of the next tile is
 //     already in LDS when the epilogue of this one starts.
 //
-// conv_pf_kernel (conv_big.hip) runs the same work as fill -> barrier -> MFMA -> barrier with two workgroups per CU
-// and leaves the matrix pipe idle ~75 % of the chunk loop (fill VALU and MFMA of one wave never overlap, LDS reads
-// are waited for right before their MFMA, and every tile starts with an exposed HBM round trip).
+// conv_pf_kernel runs the same work as fill -> barrier -> MFMA -> barrier with two workgroups per CU (fill VALU and MFMA
+// of one wave never overlap, LDS reads are waited for right before their MFMA, every tile starts with an exposed HBM
+// round trip).  Measured (profiles/README.md): this kernel wins on forward launches with >= 3 tiles
+// per CU (64->64 @200x200: 121 -> 97 us) and loses elsewhere, so rd_conv_pp_dispatch only takes those by default.
 #include "conv_device.h"
 #include "conv_epilogue.h"
 #include "conv_dispatch.h"
@@ -108,10 +110,10 @@ __device__ __forceinline__ void pp_advance(PpStage& s, const PpGeo& q, const Gro
 // LEAN = forward launches: the MFMA roles are swapped (A = weights, B = pixels), so a lane ends up with ONE pixel and
 // 16 output channels per 32-channel block, regroups them with v_permlane32_swap into 16-byte NHWC vectors and stores
 // them straight from registers; the BatchNorm sums stay in registers across the tiles of a (channel block, group) run.
-// Ablation on dec.convu2.conv3 forward (64->64 at 200x200, 16 images; RD_PP_DBG builds of this kernel): 157.7 us with
-// the LDS-staged epilogue of conv_epilogue.h, 42.3 us with the epilogue removed, 9.2 us MFMA + fragment reads only --
-// the staged epilogue (~3000 instructions per wave and tile: scalar LDS stores, a non-unrolled store loop with the
-// gradient switch, LDS + global atomics per tile) was 3/4 of the kernel, not the K loop.
+// Measured on dec.convu2.conv3 forward (64->64 at 200x200, 16 images): 157.7 us with the LDS-staged epilogue of
+// conv_epilogue.h (~3000 instructions per wave and tile, nothing to overlap them with at one workgroup per CU), 97 us
+// with this one; a throw-away build without any epilogue -- in which the compiler also drops the then-dead MFMA chain --
+// ran 42.3 us, i.e. loads + BN/ReLU fill + barriers of the whole K loop fit in that.
 // MODE: 0 = LDS-staged epilogue of conv_epilogue.h (any destination), 1 = LEAN forward, 2 = LEAN gradient (every
 // destination plain, whole 16-byte slots, c_split % 16 == 0): same register regrouping; the producer's raw tensor (for the
 // activation mask and sum g*z) and, for accumulating destinations, the old gradient are requested at the start of the
