@@ -552,22 +552,9 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     //                                its sources are already-materialised dz tensors, which conv_pf_kernel streams with
     //                                two workgroups per CU -- opt-in only (RD_CONV_PP_LEAN2=1).
     static const bool lean_off = getenv("RD_CONV_PP_LEAN_OFF") != nullptr, lean2_on = getenv("RD_CONV_PP_LEAN2") != nullptr;
-    int lean = 0;
-    if (!lean_off && p.Cout == p.CoutPad) {
-        if (p.emode == 0 && (((uintptr_t)p.out) & 15) == 0 && (tiles >= 3 * n_cu || pp_all)) lean = 1;
-        if (p.emode == 1 && lean2_on && p.c_split % 16 == 0) {
-            bool ok = true, any = false;
-            for (int i = 0; i < 2; ++i) {
-                const rd_dst_t& d = p.dst[i];
-                if (i == 1 && p.c_split >= p.Cout) break;          // dst[1] unused
-                if (d.kind == RD_DST_NONE) continue;
-                any = true;
-                const int width = i == 0 ? (p.c_split < p.Cout ? p.c_split : p.Cout) : p.Cout - p.c_split;
-                ok = ok && d.kind == RD_DST_PLAIN && d.Cd % 8 == 0 && d.Cd >= width && (((uintptr_t)d.g | (uintptr_t)d.z) & 15) == 0;
-            }
-            if (ok && any) lean = 2;
-        }
-    }
+    int lean = lean_off ? 0 : rd_conv_lean_mode(p, PP_NT);               // 0 none, 1 forward, 2 plain gradient (conv_dispatch.h)
+    if (lean == 1 && !(tiles >= 3 * n_cu || pp_all)) lean = 0;
+    if (lean == 2 && !lean2_on) lean = 0;
     if (!lean && tiles > n_cu && !pp_all) return RD_CONV_PP_NA;
     const int grid = tiles < n_cu ? tiles : n_cu;
     if (lean == 1) hipLaunchKernelGGL(conv_pp_kernel<1>, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
