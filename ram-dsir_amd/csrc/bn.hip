@@ -176,10 +176,22 @@ __global__ __launch_bounds__(256) void up_stats_kernel(const T* t, float* stats,
             a2[e] += uu[e] * uu[e];
         }
     }
+    // lanes with the same channel slot (lane % SL; SL is a power of two <= 32) are summed inside the wave first: one LDS
+    // atomic per wave and channel instead of one per thread (16-channel tensors had 128 adds queueing on every address)
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int e = 0; e < S; ++e) {
-        atomicAdd(&s_red[(sl * S + e) * 2 + 0], a1[e]);
-        atomicAdd(&s_red[(sl * S + e) * 2 + 1], a2[e]);
+        for (int o = SL; o < 64; o <<= 1) {
+            a1[e] += __shfl_xor(a1[e], o, 64);
+            a2[e] += __shfl_xor(a2[e], o, 64);
+        }
+    }
+    if (lane < SL) {
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            atomicAdd(&s_red[(sl * S + e) * 2 + 0], a1[e]);
+            atomicAdd(&s_red[(sl * S + e) * 2 + 1], a2[e]);
+        }
     }
     __syncthreads();
     const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
@@ -422,7 +434,8 @@ int rd_up_stats(const void* t, float* stats, void* y_out, int N, int h, int w, i
     if (C % S || 256 % (C / S)) return -2;
     const GroupMap gm = host_gm(G, gstart_host);
     const int items = 4 * h * w * (C / S);
-    int bx = grid_for(items, 256 * 8, 512);
+    static const int us_per = getenv("RD_UPS_PER") ? atoi(getenv("RD_UPS_PER")) : 8;
+    int bx = grid_for(items, 256 * us_per, 4096);
     dim3 grid(bx, N);
     if (dtype == RD_BF16)
         hipLaunchKernelGGL(up_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
