@@ -237,32 +237,47 @@ __global__ __launch_bounds__(256) void up_bwd_kernel(const T* g2, const T* t, T*
         for (int e = 0; e < S; ++e) G[e] = TU[e] = 0.f;
         const T* gb = g2 + (size_t)n * H * W * C + sl * S;
         const T* tb = t + (size_t)n * h * w * C + sl * S;
+        // branch-free: out-of-image taps have weight exactly 0 (up_adjoint_1d) and read a clamped, valid address, so the
+        // 16 + 9 loads of an item are issued back to back instead of one per conditional block
+        uint4 gq[4][4], tq[3][3];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (wy[j] == 0.f) continue;
+            const int Yc = min(max(2 * y - 1 + j, 0), H - 1);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float wgt = wy[j] * wx[k];
-                if (wgt == 0.f) continue;
-                float v[S];
-                ldv<T>(gb + ((size_t)(2 * y - 1 + j) * W + (2 * x - 1 + k)) * C, v);
-#pragma unroll
-                for (int e = 0; e < S; ++e) G[e] += wgt * v[e];
+                const int Xc = min(max(2 * x - 1 + k, 0), W - 1);
+                gq[j][k] = *reinterpret_cast<const uint4*>(gb + ((size_t)Yc * W + Xc) * C);
             }
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            if (Ay[a] == 0.f) continue;
+            const int yc = min(max(y + a - 1, 0), h - 1);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int xc = min(max(x + b - 1, 0), w - 1);
+                tq[a][b] = *reinterpret_cast<const uint4*>(tb + ((size_t)yc * w + xc) * C);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float wgt = wy[j] * wx[k];
+                float v[S];
+                Slot<T>::unpack(gq[j][k], v);
+#pragma unroll
+                for (int e = 0; e < S; ++e) G[e] += wgt * v[e];
+            }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const float cf = Ay[a] * Ax[b];
-                if (cf == 0.f) continue;
                 float v[S];
-                ldv<T>(tb + ((size_t)(y + a - 1) * w + (x + b - 1)) * C, v);
+                Slot<T>::unpack(tq[a][b], v);
 #pragma unroll
                 for (int e = 0; e < S; ++e) TU[e] += cf * v[e];
             }
-        }
         const float Wsum = (wy[0] + wy[1] + wy[2] + wy[3]) * (wx[0] + wx[1] + wx[2] + wx[3]);
         float o[S];
 #pragma unroll
