@@ -43,12 +43,16 @@ __device__ int fft_stockham(float2* buf, int batch, const FftPlan& pl, const flo
         const int R = pl.radix[st];
         const int nb = N / R;
         const int tstep = N / (Ns * R);
+        // integer quotients by the run-time stage constants through float reciprocals: exact for these ranges
+        // (a < 2^12, divisor <= 1024: |rounding| ~ 1e-4 of the 0.5/divisor margin), a fraction of the cost of a division
+        const float inv_nb = 1.0f / (float)nb, inv_Ns = 1.0f / (float)Ns;
         for (int jj = tid; jj < batch * nb; jj += nthreads) {
-            const int t = jj / nb, j = jj - t * nb;
+            const int t = (int)(((float)jj + 0.5f) * inv_nb), j = jj - t * nb;
             const float2* a = buf + (size_t)(t * 2 + cur) * N;
             float2* o = buf + (size_t)(t * 2 + (cur ^ 1)) * N;
-            const int k = j % Ns;
-            const int j0 = (j / Ns) * Ns * R + k;
+            const int q = (int)(((float)j + 0.5f) * inv_Ns);
+            const int k = j - q * Ns;
+            const int j0 = q * Ns * R + k;
             float2 v[5];
 #pragma unroll
             for (int r = 0; r < 5; ++r)
