@@ -15,54 +15,64 @@ def to_multilabel(pre_mask, classes=2):
     return mask
 
 
+def _map_images(sample, f_img, f_mask):
+    """Apply f_img to every image-like entry ('img', and 'img_freq' when a caller carries one along,
+    transform.py:38-40) and f_mask to the mask; other keys are dropped like the reference does."""
+    out = {'img': f_img(sample['img']), 'mask': f_mask(sample['mask'])}
+    if 'img_freq' in sample:
+        out['img_freq'] = f_img(sample['img_freq'])
+    return out
+
+
 class RandomCrop(object):
-    def __init__(self, size, padding=0):
-        self.size = (int(size), int(size)) if isinstance(size, (int, float)) else size   # (h, w)
-        self.padding = padding
+    """transform.py:16-44.  output_size = (w, h).  An image smaller than the crop is first padded on the right /
+    bottom (image with 0, mask with 255 = background); the two offsets are ALWAYS drawn (x, then y) -- also when the
+    image already has the crop size, where randint(0, 0) still advances python's generator -- so the draw order of a
+    training run matches the reference's."""
+
+    def __init__(self, output_size):
+        self.output_size = output_size
 
     def __call__(self, sample):
-        img, mask = sample['img'], sample['mask']
-        if self.padding > 0:
-            img = ImageOps.expand(img, border=self.padding, fill=0)
-            mask = ImageOps.expand(mask, border=self.padding, fill=0)
-        assert img.width == mask.width and img.height == mask.height
-        w, h = img.size
-        th, tw = self.size
-        if w == tw and h == th:
-            return {'img': img, 'mask': mask}
-        if w < tw or h < th:
-            img = img.resize((tw, th), Image.BILINEAR)
-            mask = mask.resize((tw, th), Image.NEAREST)
-            return {'img': img, 'mask': mask}
-        x1 = random.randint(0, w - tw)
-        y1 = random.randint(0, h - th)
-        return {'img': img.crop((x1, y1, x1 + tw, y1 + th)), 'mask': mask.crop((x1, y1, x1 + tw, y1 + th))}
+        cw, ch = self.output_size[0], self.output_size[1]
+        w, h = sample['img'].size
+        pad = (0, 0, max(cw - w, 0), max(ch - h, 0))
+        sample = _map_images(sample, lambda im: ImageOps.expand(im, border=pad, fill=0),
+                             lambda m: ImageOps.expand(m, border=pad, fill=255))
+        w, h = sample['img'].size
+        x = random.randint(0, w - cw)
+        y = random.randint(0, h - ch)
+        box = (x, y, x + cw, y + ch)
+        return _map_images(sample, lambda im: im.crop(box), lambda m: m.crop(box))
 
 
 class Resize(object):
-    def __init__(self, size):
-        self.size = tuple(reversed(size))                    # size: (h, w)
+    """transform.py:163-177.  target_size = (w, h) as PIL orders it; bilinear image, nearest mask."""
+
+    def __init__(self, target_size):
+        self.target_size = target_size
 
     def __call__(self, sample):
-        img, mask = sample['img'], sample['mask']
-        assert img.width == mask.width and img.height == mask.height
-        return {'img': img.resize(self.size, Image.BILINEAR), 'mask': mask.resize(self.size, Image.NEAREST)}
+        size = (self.target_size[0], self.target_size[1])
+        return _map_images(sample, lambda im: im.resize(size, Image.BILINEAR), lambda m: m.resize(size, Image.NEAREST))
 
 
 class RandomScaleCrop(object):
+    """transform.py:180-204: with probability 1/2 enlarge width and height by independent factors U(1, 1.5)
+    (draw order: the coin, the width factor, the height factor), then RandomCrop(size)."""
+
     def __init__(self, size):
         self.size = size
         self.crop = RandomCrop(self.size)
 
     def __call__(self, sample):
         img, mask = sample['img'], sample['mask']
-        assert img.width == mask.width and img.height == mask.height
-        seed = random.random()
-        if seed > 0.5:
+        assert img.width == mask.width
+        assert img.height == mask.height
+        if random.random() > 0.5:
             w = int(random.uniform(1, 1.5) * img.size[0])
             h = int(random.uniform(1, 1.5) * img.size[1])
-            img, mask = img.resize((w, h), Image.BILINEAR), mask.resize((w, h), Image.NEAREST)
-            sample['img'], sample['mask'] = img, mask
+            sample = _map_images(sample, lambda im: im.resize((w, h), Image.BILINEAR), lambda m: m.resize((w, h), Image.NEAREST))
         return self.crop(sample)
 
 

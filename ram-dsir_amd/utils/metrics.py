@@ -22,6 +22,29 @@ def dice_coeff_2label(pred, target):
     return sum(cup) / len(cup), sum(disc) / len(disc)
 
 
+def dice(input, target, ignore_index=None):
+    """metrics.py:28-38 (torch tensors, +1 smoothing over the flattened batch); unused by the scripts, kept for API parity."""
+    smooth = 1.
+    iflat, tflat = input.clone().view(-1), target.clone().view(-1)
+    if ignore_index is not None:
+        m = tflat == ignore_index
+        tflat[m] = 0
+        iflat[m] = 0
+    return (2. * (iflat * tflat).sum() + smooth) / (iflat.sum() + tflat.sum() + smooth)
+
+
+def dice_multi(input, target, num_classes=3, ignore_index=None):
+    """metrics.py:40-53: mean over classes (minus ignore_index) of the label-map Dice, 1e-5 smoothing."""
+    smooth, count, total = 1e-5, 0, 0
+    for i in range(num_classes):
+        if i == ignore_index:
+            continue
+        count += 1
+        a, b = (input == i), (target == i)
+        total = total + (2 * (a * b).sum() + smooth) / (a.sum() + b.sum() + smooth)
+    return total / count
+
+
 def get_largest_fillhole(binary):
     binary = np.array(binary)
     lab, n = ndi.label(binary, structure=np.ones((3, 3)))

@@ -379,22 +379,156 @@ def gen_masks(ref_transform):
     print('masks.npz')
 
 
+# ------------------------------------------------------------------------------------------ R4 sampling
+def gen_sampling(ref_fundus, ref_prostate, ref_transform):
+    """The REFERENCE's Fundus_Multi / Prostate_Multi (fundus.py:160-240, prostate.py:152-202) on the synthetic trees of
+    tests/synth_data.py under fixed seeds: every random draw in order (crop/scale, partner domain, partner image,
+    lambda) and what __getitem__ returned (img, img_freq, mask; images subsampled 8x to keep the fixture small --
+    a wrong partner or lambda changes every pixel)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import synth_data as SD
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        base = SD.make_fundus_tree(tmp)
+        tf = [ref_transform.Resize((256, 256)), ref_transform.RandomScaleCrop((256, 256))]       # train.py:541
+
+        def compose(sample):
+            for t in tf:
+                sample = t(sample)
+            return sample
+        for tag, dom, ood, tdi in (('f_ood', [1], True, 0), ('f_ind', [2, 3], False, 1)):
+            ds = ref_fundus.Fundus_Multi(domain_idx_list=dom, base_dir=base, split='train', transform=compose,
+                                         is_out_domain=ood, test_domain_idx=tdi)
+            random.seed(1337)
+            np.random.seed(1337)
+            n = min(len(ds), 6)
+            for i in range(n):
+                with SD.DrawLog() as dl:
+                    img, frq, mask = ds[i]
+                out['%s.%d.draws' % (tag, i)] = np.array(dl.log)
+                out['%s.%d.img' % (tag, i)] = img.numpy()[:, ::8, ::8].copy()
+                out['%s.%d.frq' % (tag, i)] = frq.numpy()[:, ::8, ::8].copy()
+                out['%s.%d.mask' % (tag, i)] = mask.numpy()[:, ::4, ::4].astype(np.uint8)
+                out['%s.%d.sig' % (tag, i)] = np.stack([sig(img), sig(frq), sig(mask)])
+            out[tag + '.n'] = np.array(n)
+        pbase = SD.make_prostate_tree(tmp)
+        real_listdir = os.listdir
+
+        def logged_listdir(p):
+            r = sorted(real_listdir(p))                       # fixed order: the file system's own order does not travel
+            return r
+        os.listdir = logged_listdir
+        try:
+            ds = ref_prostate.Prostate_Multi(domain_idx_list=[0, 2], base_dir=pbase, split='train', is_out_domain=True,
+                                             test_domain_idx=4)
+            random.seed(1337)
+            np.random.seed(1337)
+            n = min(len(ds), 6)
+            for i in range(n):
+                with SD.DrawLog() as dl:
+                    img, frq, mask = ds[i]
+                out['p_ood.%d.draws' % i] = np.array(dl.log)
+                out['p_ood.%d.img' % i] = img.numpy()[:, ::4, ::4].copy()
+                out['p_ood.%d.frq' % i] = frq.numpy()[:, ::4, ::4].copy()
+                out['p_ood.%d.sig' % i] = np.stack([sig(img), sig(frq), sig(mask.float())])
+            out['p_ood.n'] = np.array(n)
+        finally:
+            os.listdir = real_listdir
+    np.savez_compressed(os.path.join(HERE, 'sampling.npz'), **out)
+    print('sampling.npz', len(out), 'arrays')
+
+
+# ------------------------------------------------------------------------------------------ evaluation metrics
+def gen_metrics(ref_root):
+    """utils/metrics.py:55-109 (dice_coefficient_numpy, dice_coeff_2label: the Fundus Dice of BASELINE.json) and
+    :33-53 (dice, dice_multi) on synthetic masks, incl. empty / full / disjoint cases.  The module does
+    ``from medpy import metric`` at import and only calculate_metric_percase touches it: an EMPTY placeholder module
+    satisfies the import (nothing from medpy is executed or emulated)."""
+    import types
+    ph = types.ModuleType('medpy')
+    ph.metric = types.ModuleType('medpy.metric')
+    sys.modules.setdefault('medpy', ph)
+    sys.modules.setdefault('medpy.metric', ph.metric)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_metrics', os.path.join(ref_root, 'code', 'utils', 'metrics.py'))
+    RM = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(RM)
+    rng = np.random.RandomState(5)
+    out = {}
+    H = W = 24
+    yy, xx = np.mgrid[0:H, 0:W]
+    cases = []
+    for i in range(10):
+        if i == 0:
+            p, t = np.zeros((H, W), bool), np.zeros((H, W), bool)             # both empty -> (0+1)/(1+0+0) = 1
+        elif i == 1:
+            p, t = np.ones((H, W), bool), np.ones((H, W), bool)
+        elif i == 2:
+            p, t = np.zeros((H, W), bool), np.ones((H, W), bool)
+        elif i == 3:
+            p, t = xx < 5, xx > 15                                             # disjoint
+        else:
+            c = rng.uniform(6, 18, 4)
+            r = rng.uniform(3, 9, 2)
+            p = (yy - c[0]) ** 2 + (xx - c[1]) ** 2 < r[0] ** 2
+            t = (yy - c[2]) ** 2 + (xx - c[3]) ** 2 < r[1] ** 2
+        out['d%d.pred' % i], out['d%d.gt' % i] = p.astype(np.uint8), t.astype(np.uint8)
+        out['d%d.dice' % i] = np.array(RM.dice_coefficient_numpy(p, t))
+        cases.append(i)
+    out['ncases'] = np.array(len(cases))
+    # dice_coeff_2label: (2,H,W) single sample and (B,2,H,W) batch means
+    pred = (rng.uniform(size=(5, 2, H, W)) > 0.6)
+    targ = (rng.uniform(size=(5, 2, H, W)) > 0.5)
+    pred[1] = False
+    targ[2] = False
+    out['b.pred'], out['b.gt'] = pred.astype(np.uint8), targ.astype(np.uint8)
+    out['b.single'] = np.array(RM.dice_coeff_2label(pred[0].astype(np.float32), torch.from_numpy(targ[0].astype(np.float32))))
+    out['b.batch'] = np.array(RM.dice_coeff_2label(pred.astype(np.float32), torch.from_numpy(targ.astype(np.float32))))
+    # torch dice / dice_multi (metrics.py:28-53)
+    a = torch.from_numpy((rng.uniform(size=(3, H, W)) > 0.5).astype(np.float32))
+    b = torch.from_numpy((rng.uniform(size=(3, H, W)) > 0.5).astype(np.float32))
+    out['t.a'], out['t.b'] = a.numpy(), b.numpy()
+    out['t.dice'] = np.array(RM.dice(a, b).item())
+    li = torch.from_numpy(rng.randint(0, 3, (2, H, W)))
+    lt = torch.from_numpy(rng.randint(0, 3, (2, H, W)))
+    out['m.a'], out['m.b'] = li.numpy(), lt.numpy()
+    out['m.dice_multi'] = np.array(float(RM.dice_multi(li, lt, num_classes=3)))
+    out['m.dice_multi_ign0'] = np.array(float(RM.dice_multi(li, lt, num_classes=3, ignore_index=0)))
+    np.savez_compressed(os.path.join(HERE, 'metrics.npz'), **out)
+    print('metrics.npz', len(out), 'arrays')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
+    ap.add_argument('--only', default='', help='comma list of fixture groups (ram,masks,losses,blocks,modules,steps,sampling,metrics)')
     args = ap.parse_args()
+    only = set(filter(None, args.only.split(',')))
     sys.path.insert(0, os.path.join(args.ref, 'code'))
     import networks.unet as RU
     import utils.losses as ref_losses
     import dataset.fundus as ref_fundus
+    import dataset.prostate as ref_prostate
     import dataset.transform as ref_transform
     torch.set_num_threads(4)
-    gen_ram(ref_fundus)
-    gen_masks(ref_transform)
-    gen_losses(ref_losses)
-    gen_blocks(RU)
-    gen_modules(RU)
-    gen_steps(RU, ref_losses)
+    want = lambda g: not only or g in only
+    if want('ram'):
+        gen_ram(ref_fundus)
+    if want('masks'):
+        gen_masks(ref_transform)
+    if want('losses'):
+        gen_losses(ref_losses)
+    if want('blocks'):
+        gen_blocks(RU)
+    if want('modules'):
+        gen_modules(RU)
+    if want('steps'):
+        gen_steps(RU, ref_losses)
+    if want('sampling'):
+        gen_sampling(ref_fundus, ref_prostate, ref_transform)
+    if want('metrics'):
+        gen_metrics(args.ref)
     with open(os.path.join(HERE, 'VERSIONS.json'), 'w') as f:
         json.dump(dict(torch=torch.__version__, numpy=np.__version__, python=sys.version.split()[0]), f)
 
