@@ -39,11 +39,11 @@ MFMA_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA 
 
 
 def synth_inputs(B, S, rank, device):
-    """U[0,255] uint8-valued source and partner images, lambda from random.Random(1337),
+    """U[0,255] uint8 source and partner images (what a decoded PNG is), lambda from random.Random(1337),
     masks = two concentric random discs (cup inside disc)."""
     rng = np.random.RandomState(1337 + rank)
-    src = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.float32)
-    trg = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.float32)
+    src = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.uint8)
+    trg = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.uint8)
     pr = random.Random(1337 + rank)
     lam = np.array([pr.randint(1, 10) / 10 for _ in range(B)], np.float32)
     yy, xx = np.mgrid[0:S, 0:S]
@@ -108,10 +108,11 @@ def kernel_roofline(ts, family, eager=True):
     tfs = flops / (total_ms * 1e-3) / 1e12
     # which roof binds: arithmetic intensity of the launches against the ridge point of the chip
     intensity, ridge = flops / nbytes, MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-    # HBM bytes per launch from the PMC counters of the same kernels: collected OFFLINE with
-    # `rocprofv3 -i scripts/pmc_hbm.txt` (separate FETCH_SIZE / WRITE_SIZE passes) on this command and corrected as
-    # MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for 16-B/lane streaming reads, KB -> B); see profiles/README.md
-    traffic = None
+    # HBM bytes per launch from the PMC counters of the same kernels: NOT measured in this run (PMC collection needs
+    # rocprofv3 around the process) but read from the committed summary of `rocprofv3 -i scripts/pmc_hbm.txt` (separate
+    # FETCH_SIZE / WRITE_SIZE passes) on this command, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for
+    # 16-B/lane streaming reads, KB -> B); `traffic_source` names the file, profiles/README.md the procedure
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, 'profiles', 'dominant_kernel_pmc.json')
     if os.path.exists(tpath):
         with open(tpath) as f:
@@ -119,43 +120,89 @@ def kernel_roofline(ts, family, eager=True):
         tj = tj.get(family, tj) if isinstance(tj.get(family, None), dict) else tj
         if tj.get('family', family) == family and 'traffic_bytes_per_launch' in tj:
             traffic = int(tj['traffic_bytes_per_launch'])
+            traffic_source = 'profiles/dominant_kernel_pmc.json (%s)' % tj.get('collected', 'rocprofv3 PMC, offline')
     if intensity >= ridge:
         out = dict(bound='mfma', achieved=round(tfs, 1), peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tfs / MFMA_PEAK_TFLOPS, 4))
     else:
         out = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
-    out.update(traffic=traffic, kernel=family, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
+    out.update(traffic=traffic, traffic_source=traffic_source, kernel=family, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
                avg_algorithmic_bytes=int(nbytes / n), avg_flops=int(flops / n), flop_per_byte=round(intensity, 1),
                achieved_gbs=round(gbs, 1), achieved_tflops=round(tfs, 1))
     return out
 
 
 def cpu_baseline(host_inputs, bs):
-    """The oracle (torch CPU restatement of train.py:225-296 + numpy RAM of fundus.py:13-61) timed on this
-    box's host cores on two steps of the same workload (8 images at 400x400 per step)."""
+    """The oracle (torch CPU restatement of train.py:225-296 + numpy RAM of fundus.py:13-61) timed on this box's host
+    cores on the same workload (8 images at 400x400 per step): 1 warm-up step + 3 timed steps, the numpy
+    RAM per image on ONE core as a DataLoader worker runs it.  `value` = images/s of step + RAM / 8 workers (the
+    reference's num_workers=8, train.py:558, assuming perfect overlap across the workers); `step_only` and
+    `step_plus_ram_serial` are reported beside it."""
     from oracle import ram as OR, step as OS, unet as OU
     src, trg, lam, mask = host_inputs
-    # torch's CPU conv kernels stop scaling (and then regress) well before the 100+ cores of a GPU host:
-    # 16 threads is the fastest setting we measured for this step; `cores` reports the threads actually used
-    cores = min(os.cpu_count() or 1, 16)
+    # torch's CPU conv kernels stop scaling (and then regress) well before the 100+ cores of a GPU host: 16 threads is
+    # the fastest setting measured for this step (RD_CPU_THREADS overrides); `cores` reports the threads actually used
+    cores = int(os.environ.get('RD_CPU_THREADS', '0')) or min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     B = src.shape[0]
     t0 = time.time()
-    pairs = [OR.ram_fundus(src[i], trg[i], float(lam[i]), dtype=np.float32) for i in range(B)]
-    t_ram = time.time() - t0
+    pairs = [OR.ram_fundus(src[i].astype(np.float32), trg[i].astype(np.float32), float(lam[i]), dtype=np.float32) for i in range(B)]
+    t_ram = time.time() - t0                   # B images, one core
     img = torch.from_numpy(np.stack([p[0] for p in pairs]))
     frq = torch.from_numpy(np.stack([p[1] for p in pairs]))
     enc, dec, rec = OU.encoder_state(seed=1), OU.decoder_state(seed=2), OU.rec_decoder_state(num_classes=3, num_domains=len(bs), seed=3)
     opt = dict(enc=OS.adam_state({k: enc[k] for k in OU.param_keys(enc)}), dec=OS.adam_state({k: dec[k] for k in OU.param_keys(dec)}),
                rec=OS.adam_state({k: rec[k] for k in OU.param_keys(rec)}))
     cfg = OS.StepConfig(dataset='fundus', batch_sizes=bs, consistency='kd')
-    nstep = 2                                  # ~12 s of CPU work: enough to be past the first-call allocations
-    t0 = time.time()
-    for it in range(nstep):
+    times = []
+    for it in range(4):                        # 1 warm-up + 3 timed
+        t0 = time.time()
         OS.train_step(enc, dec, rec, opt, img, frq, torch.from_numpy(mask), cfg, it)
-    t_step = (time.time() - t0) / nstep
-    return dict(value=round(B / (t_step + t_ram), 3), unit='images/s', cores=cores, kind='port',
-                sample='%d steps of the same workload (8 images 400x400 each: numpy RAM %.2f s per batch on 1 core + torch-CPU step '
-                       '%.2f s per step on %d threads)' % (nstep, t_ram, t_step, cores))
+        times.append(time.time() - t0)
+    t_step = float(np.median(times[1:]))
+    return dict(value=round(B / (t_step + t_ram / 8), 3), unit='images/s', cores=cores, kind='port',
+                step_only=round(B / t_step, 3), step_plus_ram_serial=round(B / (t_step + t_ram), 3),
+                sample='1 warm-up + 3 timed steps of the same workload (8 images 400x400 each): torch-CPU step median %.2f s on %d threads '
+                       '(warm-up %.2f s); numpy RAM %.2f s per batch of 8 on 1 core; value = step + RAM/8 workers' % (t_step, cores, times[0], t_ram))
+
+
+def fp32_leg(bank_init, bs, Sz, dev, src, trg, lam, mask, steps=6, warmup=2):
+    """The same step in fp32 storage -- the reference's own precision and the parity path of the tests."""
+    from ramdsir import step as S
+    bank, mods = S.make_bank(dev, 3, 16, 2, len(bs))
+    bank.params.copy_(bank_init)
+    ts = S.TrainStep(bank, mods, torch.float32, bs, Sz, Sz, dataset='fundus', consistency='kd', lambda_rec=0.1, lr=2e-3,
+                     total_iters=21200, ram='u8')
+    ts.wpack.refresh()
+    ts.load_raw(src, trg, lam)
+    ts.load_target(mask)
+    for _ in range(warmup):
+        ts.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts.step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = dict(dtype='f32', images_per_s=round(sum(bs) * steps / el, 1), ms_per_step=round(1e3 * el / steps, 3), steps=steps,
+               final_loss=round(ts.loss_dict()['loss'], 4))
+    del ts, bank
+    torch.cuda.empty_cache()
+    return out
+
+
+def whole_step_roofline(B, Sz, ms_per_step, dtype):
+    """SURVEY.md 8(d) conventions for the WHOLE step: algorithmic bytes = every conv reads its logical input once and
+    writes its output once, everything else fused (170.3 M elements forward per image at 400x400, x3 for forward +
+    backward, x (S/400)^2) + the RAM bytes 12*C*S^2; algorithmic flops = conv MACs x 2, forward + dgrad + wgrad
+    (170.9 GFLOP per image at 400x400)."""
+    esz = 2 if dtype == 'bf16' else 4
+    sc = (Sz / 400.0) ** 2
+    nbytes = B * (3 * 170.3e6 * esz * sc + 12 * 3 * Sz * Sz)
+    flops = B * 170.9e9 * sc
+    t = ms_per_step * 1e-3
+    return dict(algorithmic_gbs=round(nbytes / t / 1e9, 1), hbm_frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+                algorithmic_tflops=round(flops / t / 1e12, 1), mfma_frac=round(flops / t / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                bytes_per_image=int(nbytes / B), flops_per_image=int(flops / B))
 
 
 def main():
@@ -168,6 +215,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay one captured hipGraph per step instead of the 3-stream eager launch (slower on ROCm 7: DESIGN.md section 3)')
     ap.add_argument('--no-graph', action='store_true', help='(default; kept for older command lines)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32-leg', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -187,8 +235,9 @@ def main():
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     bank, mods = S.make_bank(dev, 3, 16, 2, len(bs))
     init_weights(bank)
+    params0 = bank.params.clone()
     ts = S.TrainStep(bank, mods, dtype, bs, Sz, Sz, dataset='fundus', consistency='kd', lambda_rec=0.1, lr=2e-3,
-                     total_iters=21200, ram=True)
+                     total_iters=21200, ram='u8')
     ts.wpack.refresh()
     src, trg, lam, mask, host_inputs = synth_inputs(B, Sz, rank, dev)
     ts.load_raw(src, trg, lam)
@@ -235,12 +284,16 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'Fundus target0 --ram --rec --consistency kd, batch 8=[2,3,3] per GPU, %dx%dx3' % (Sz, Sz),
-                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hipgraph': bool(args.graph), 'streams': 1 if (args.graph or not ts.fork) else 1 + len(ts.lanes()),
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                       'process_group': ('%s world %d' % (dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else 'none (single process)', 'hipgraph': bool(args.graph), 'streams': 1 if (args.graph or not ts.fork) else 1 + len(ts.lanes()),
                        'final_loss': round(losses['loss'], 4)},
         }
+        out['roofline_step'] = whole_step_roofline(B, Sz, out['ms_per_step'], args.dtype)
         if args.dtype == 'bf16':
             out['roofline'] = kernel_roofline(ts, DOMINANT, eager=not args.graph)
             out['roofline_conv64'] = kernel_roofline(ts, CONV64, eager=not args.graph)
+        if world == 1 and args.dtype == 'bf16' and not args.no_fp32_leg:
+            out['extra'] = {'fp32': fp32_leg(params0, bs, Sz, dev, src, trg, lam, mask)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(host_inputs, bs)
         print(json.dumps(out), flush=True)

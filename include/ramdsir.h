@@ -29,7 +29,11 @@ extern "C" {
 #define RD_MAX_GROUPS_C 8
 /* BatchNorm sums are accumulated with atomics; to keep thousands of workgroups off the same few addresses
  * every statistics buffer has RD_STAT_SLOTS copies, [G][RD_STAT_SLOTS][C][2]; a workgroup adds into slot
- * (its tile index mod RD_STAT_SLOTS) and the finalize kernels sum the slots. */
+ * (its tile index mod RD_STAT_SLOTS) and the finalize kernels sum the slots.
+ * Numerics (ATen's batch_norm uses a mean-then-deviation / Welford reduction, never E[x^2]-E[x]^2 in fp32): a workgroup
+ * sums its tile in fp32, but (a) the forward sums are those of the conv result WITHOUT its bias (the bias -- the one
+ * structural source of |mean| >> sigma -- is added back to the mean by rd_bn_finalize_fwd), and (b) everything across
+ * workgroups -- the slot atomics, the slot sum, var = E[x^2]-E[x]^2 and sum g*z - mean * sum g -- is fp64. */
 #define RD_STAT_SLOTS 64
 
 /* how a conv reads one of its (virtual) input tensors -- the producer's BatchNorm + activation
@@ -68,7 +72,7 @@ typedef struct {
     const void* z;       /* producer's raw tensor (PLAIN/POOL: same dims as g; UPY: t_lo, half res) */
     const float* scale;  /* producer BN scale/shift [G][Cd] (mask needs the sign of the BN output)  */
     const float* shift;
-    float* bstats;       /* [G][RD_STAT_SLOTS][Cd][2] += (sum g, sum g*z)  or NULL                  */
+    double* bstats;      /* [G][RD_STAT_SLOTS][Cd][2] += (sum g, sum g*z)  or NULL                  */
     int32_t kind;
     int32_t act;         /* 1: an activation follows the producer BN                                */
     int32_t accumulate;  /* 1: g += (skip connection / second consumer)                             */
@@ -94,7 +98,7 @@ typedef struct {
     int32_t gstart[RD_MAX_GROUPS_C + 1];
     int32_t emode;       /* 0 forward: write out (+stats); 1 gradient: write through dst[] */
     void* out;           /* forward: NHWC [N][H][W][Cout] */
-    float* stats;        /* forward: [G][RD_STAT_SLOTS][Cout][2] += (sum, sum of squares) or NULL */
+    double* stats;       /* forward: [G][RD_STAT_SLOTS][Cout][2] += (sum, sum of squares) of the result BEFORE the bias, or NULL */
     rd_dst_t dst[2];     /* gradient: channels [0,c_split) -> dst[0], [c_split,Cout) -> dst[1] */
     int32_t c_split;
     int32_t pad_;
@@ -150,7 +154,8 @@ int rd_pack_weights_batched(const float* params, void* packed, const rd_pack_ent
  * BN (same pointers in both groups -> running stats updated twice, in order); DSBN gives each domain
  * group its own bns[d]. */
 typedef struct {
-    const float* stats;   /* [G][RD_STAT_SLOTS][C][2] sum, sum of squares of the conv output */
+    const double* stats;  /* [G][RD_STAT_SLOTS][C][2] sum, sum of squares of (conv output - conv_bias) */
+    const float* conv_bias; /* [C] bias of the producing conv (its sums exclude it) or NULL            */
     float* scale;         /* [G][C] out: gamma*invstd          */
     float* shift;         /* [G][C] out: beta - mean*scale     */
     float* mean;          /* [G][C] out (saved for backward)   */
@@ -171,7 +176,7 @@ int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream);
 /* BatchNorm backward, second half: from (sum g, sum g*z) produce the per-channel coefficients
  * dz = P*g + Q*z + R that the next dgrad / wgrad fold into their reads, and accumulate dgamma, dbeta. */
 typedef struct {
-    const float* bstats;  /* [G][RD_STAT_SLOTS][C][2] */
+    const double* bstats; /* [G][RD_STAT_SLOTS][C][2] */
     const float* mean;    /* [G][C] */
     const float* invstd;  /* [G][C] */
     const float* gamma[RD_MAX_GROUPS_C];
@@ -184,17 +189,33 @@ typedef struct {
 int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream);
 
 /* statistics of y = bilinear_x2(t) (nn.Upsample(scale_factor=2, 'bilinear', align_corners=False),
- * unet.py:84): stats[G][C][2] += (sum y, sum y^2).  t: NHWC [N][h][w][C].  y_out == NULL: y is not
+ * unet.py:84): stats[G][slot][C][2] += (sum y, sum y^2) (each thread sums deviations from the first value it sees and
+ * converts to plain sums in fp64).  t: NHWC [N][h][w][C].  y_out == NULL: y is not
  * materialised (its readers interpolate t on the fly, RD_SRC_UP / RD_DST_UPY); otherwise y is also written to
  * y_out NHWC [N][2h][2w][C] in `dtype` and the statistics are those of the STORED (rounded) values, so that
  * plain RD_SRC_AFFACT / RD_DST_PLAIN readers normalise exactly what was measured. */
-int rd_up_stats(const void* t, float* stats, void* y_out, int N, int h, int w, int C, int G, const int32_t* gstart_host,
+int rd_up_stats(const void* t, double* stats, void* y_out, int N, int h, int w, int C, int G, const int32_t* gstart_host,
                 int dtype, void* stream);
+
+/* statistics of a plain NHWC tensor x [N][H][W][C]: stats[G][slot][C][2] += (sum x, sum x^2) -- the standalone
+ * nn.BatchNorm2d / DomainSpecificBatchNorm2d.forward (code/networks/dsbn.py:24-27), where no conv produced x. */
+int rd_bn_stats(const void* x, double* stats, int N, int H, int W, int C, int G, const int32_t* gstart_host, int dtype,
+                void* stream);
 
 /* backward of y = up2(t) followed by BN: dt = up2^T( P*g + Q*up2(t) + R ), g: NHWC [N][2h][2w][C],
  * dt/t: NHWC [N][h][w][C]. */
 int rd_up_bwd(const void* g, const void* t, void* dt, const float* P, const float* Q, const float* R, int N, int h,
               int w, int C, int G, const int32_t* gstart_host, int dtype, void* stream);
+
+/* nn.MaxPool2d(2) at the head of ConvD levels 2-5 (unet.py:45,56), materialised: out[N][Ho][Wo][C] = max over the 2x2 window of
+ * act(z*scale+shift) (scale == NULL: identity coefficients; slope 1: no activation), z: NHWC [N][2Ho][2Wo][C].  The conv behind
+ * it then reads `out` as a plain tensor in forward, dgrad and wgrad. */
+int rd_pool_fwd(const void* z, const float* scale, const float* shift, float slope, void* out, int N, int Ho, int Wo, int C, int G,
+                const int32_t* gstart_host, int dtype, void* stream);
+/* its backward: g[N][2Ho][2Wo][C] (+)= gp scattered to the FIRST maximum of each window (ATen's tie rule), times the
+ * activation derivative there when act != 0; bstats (or NULL) += (sum g_new, sum g_new*z) of the scattered values. */
+int rd_pool_bwd(const void* gp, const void* z, const float* scale, const float* shift, float slope, int act, void* g, int accumulate,
+                double* bstats, int N, int Ho, int Wo, int C, int G, const int32_t* gstart_host, int dtype, void* stream);
 
 /* Elementwise materialisation  out = act( a*x + b*x2 + c ; slope )  over NHWC [N][H][W][C] with per-(group, channel)
  * coefficients a, b, c [G][C] (b, x2 may be NULL; slope 1 = no activation):
@@ -214,7 +235,7 @@ int rd_nhwc_to_nchw(const void* z_nhwc, float* y_nchw, const float* scale, const
                     int N, int C, int H, int W, int G, const int32_t* gstart_host, int dtype, void* stream);
 /* gradient entering a module from torch: g_nhwc (+)= mask(dy_nchw), bstats += (sum g, sum g*z) */
 int rd_grad_in(const float* dy_nchw, const void* z_nhwc, void* g_nhwc, const float* scale, const float* shift,
-               float* bstats, int act, float slope, int accumulate, int N, int C, int H, int W, int G,
+               double* bstats, int act, float slope, int accumulate, int N, int C, int H, int W, int G,
                const int32_t* gstart_host, int dtype, void* stream);
 /* column sums of an NHWC tensor: out[c] (+)= sum over pixels (bias gradient of the two out1 convs) */
 int rd_colsum(const void* x_nhwc, float* out, float* partial_ws /* >= 8192 floats */, int64_t npix, int C, int cstride /* 0: C */,
@@ -275,24 +296,41 @@ int rd_adam_step(const rd_adam_t* p, void* stream);
  * Random Amplitude Mixup for a whole batch on the GPU.  Replaces extract_amp_spectrum /
  * low_freq_mutate_np / source_to_target_freq (code/dataset/fundus.py:13-61 == prostate.py:10-62) and
  * the call sites fundus.py:211-225 (clip [0,255], /127.5-1) and prostate.py:186-188 (clip [-1,1]).
- * src/trg: NHWC fp32 [B][H][W][3] (HWC like the PIL / .npy arrays the reference feeds the trio);
- * lam[B]: the per-sample ratio the reference draws with random.randint(1,10)/10 (fundus.py:35);
- * b = floor(0.1*min(H,W)) (fundus.py:26).  out_img = src*scale+offset, out_freq =
- * clip(RAM(src,trg,lam), clip_lo, clip_hi)*scale+offset, both NHWC `dtype` [B][H][W][3] -- normally the two
- * halves of the network input batch.  tw_w / tw_h: (cos, -sin)(2*pi*k/N) tables of W / H entries.
- * H and W must factor into 2, 3 and 5 (256, 384, 400, 512 do). */
+ * src/trg: NHWC [B][H][W][3] (HWC like the PIL / .npy arrays the reference feeds the trio), fp32 or -- src_u8 != 0 --
+ * uint8 (decoded PNG pixels: 1 byte per value to upload and to read); lam[B]: the per-sample ratio the reference draws
+ * with random.randint(1,10)/10 (fundus.py:35); b = floor(0.1*min(H,W)) (fundus.py:26).
+ * out_img = f(src), out_freq = f(clip(RAM(src,trg,lam), clip_lo, clip_hi)) with f(v) = v/div + offset when div != 0
+ * (bit for bit the reference's `img /= 127.5; img -= 1.0`, fundus.py:217-218) else v*scale + offset; both NHWC `dtype`
+ * [B][H][W][out_cstride] -- normally the two halves of the network input batch.
+ * trg_amp != NULL: the partner is given as its amplitude spectrum [B][3][H][W] (what extract_amp_spectrum returns) instead
+ * of as an image -- source_to_target_freq(src_img, amp_trg) of fundus.py:41; trg is then ignored.
+ * tw_w / tw_h: (cos, -sin)(2*pi*k/N) tables of W / H entries.  H and W must factor into 2, 3 and 5 and be <= 1024; 256,
+ * 384, 400 and 512 run compile-time radix plans. */
 typedef struct {
-    const float* src; const float* trg; const float* lam;
+    const void* src; const void* trg; const float* lam;
     void* out_img; void* out_freq;
     void* workspace;            /* rd_ram_workspace() bytes */
     const float* tw_w; const float* tw_h;
     int32_t B, H, W, C, b;
     float clip_lo, clip_hi, scale, offset;
-    int32_t out_cstride;        /* elements between pixels of out_img / out_freq (0 or 3: dense; e.g. 8: padded so the
-                                 * first conv reads whole 16-byte channel vectors; the pad is never written) */
+    int32_t out_cstride;        /* elements between pixels of out_img / out_freq (0 or 3: dense; one 16-byte slot (8 bf16 /
+                                 * 4 fp32): the first conv reads whole channel vectors, channels 3.. are written as zeros) */
+    int32_t src_u8;             /* src / trg are uint8 */
+    float div;
+    int32_t pad_;
+    const float* trg_amp;
 } rd_ram_t;
 int64_t rd_ram_workspace(int B, int H, int W, int b);
 int rd_ram_mix(const rd_ram_t* p, int dtype, void* stream);
+
+/* The reference's free functions on their own (API parity; the training step uses rd_ram_mix):
+ *   rd_ram_amp     extract_amp_spectrum (fundus.py:13-19): amp[C][H][W] = |fft2(img[C][H][W])|, fp32
+ *   rd_ram_mutate  low_freq_mutate_np (fundus.py:21-39) with the ratio given: out = amp_src, and inside the centred window
+ *                  |ky| <= b, |kx| <= b (fftshift'ed coordinates c-b..c+b): lam*amp_src + (1-lam)*amp_trg */
+int64_t rd_ram_amp_workspace(int C, int H, int W);
+int rd_ram_amp(const float* img_chw, float* amp_chw, int C, int H, int W, void* workspace, const float* tw_w, const float* tw_h,
+               void* stream);
+int rd_ram_mutate(const float* amp_src, const float* amp_trg, float* out, int C, int H, int W, int b, float lam, void* stream);
 
 #ifdef __cplusplus
 }

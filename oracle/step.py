@@ -68,7 +68,7 @@ def forward_losses(enc, dec, rec, img, img_freq, mask, cfg):
     for d, b in enumerate(cfg.batch_sizes):
         right = left + b
         r = torch.tanh(U.rec_decoder_forward(feats2[-1][left:right], rec, d, True, cfg.slope))
-        lr_ = F.mse_loss(r, img[left:right])                       # target is the ORIGINAL image (train.py:273)
+        lr_ = F.mse_loss(r, U.q(img[left:right]))                  # target is the ORIGINAL image (train.py:273); U.q: identity unless the bf16 rounding model is on
         loss = loss + cfg.lambda_rec * lr_
         rec_losses.append(lr_)
         rec_soft.append(r)

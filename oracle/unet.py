@@ -21,6 +21,54 @@ import torch.nn.functional as F
 EPS = 1e-5
 MOMENTUM = 0.1
 
+# ----------------------------------------------------------------------------- rounding model (bf16 checker)
+# The reference computes in fp32 throughout.  The HIP path's production mode stores activations, activation
+# gradients and MFMA operands in bf16 (fp32 accumulation, fp32 BN statistics, fp32 parameters / optimizer).
+# ``with rounding(torch.bfloat16):`` makes this restatement round at the SAME points (DESIGN.md section 2 'Numerics'):
+#   forward   conv operands (activations after BN/act/pool/concat, weights) -> bf16; fp32 accumulate + bias;
+#             BN batch statistics from the fp32 conv result; the stored (rounded) result is what gets normalised;
+#             the 1x1 conv of ConvU/ConvU_Rec is evaluated BELOW the x2 upsample (exact commute in real arithmetic),
+#             t and y = up2(t) are both stored rounded and BN2's statistics are taken from the stored y;
+#             logits are stored rounded.
+#   backward  the gradient w.r.t. every BN output (pre-activation) and w.r.t. every raw conv output is rounded
+#             (they are what the dgrad / wgrad kernels read from HBM as bf16).
+# Straight-through: rounding has gradient 1.  With ROUND = None (default) nothing below changes the fp32 restatement.
+ROUND = None
+
+
+class rounding:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global ROUND
+        self.prev, ROUND = ROUND, self.dtype
+
+    def __exit__(self, *exc):
+        global ROUND
+        ROUND = self.prev
+        return False
+
+
+def _rn(x):
+    return x.to(ROUND).to(x.dtype)
+
+
+def q(x):
+    """Round values to the storage dtype (straight-through gradient)."""
+    if ROUND is None:
+        return x
+    if not x.requires_grad:
+        return _rn(x)
+    return x + (_rn(x) - x).detach()
+
+
+def qg(x):
+    """Round the gradient that flows back into x."""
+    if ROUND is not None and x.requires_grad:
+        x.register_hook(_rn)
+    return x
+
 
 # ----------------------------------------------------------------------------- state construction
 def _conv_entry(sd, name, cin, cout, k, gen):
@@ -108,18 +156,43 @@ def _act(x, slope):
 
 
 def _conv(x, sd, name, pad):
-    return F.conv2d(x, sd[name + '.weight'], sd[name + '.bias'], stride=1, padding=pad)
+    return F.conv2d(q(x), q(sd[name + '.weight']), sd[name + '.bias'], stride=1, padding=pad)
 
 
-def _bn(x, sd, name, training, domain=None):
+def _bn(x, sd, name, training, domain=None, stats_from_stored=False):
     """nn.BatchNorm2d (train: batch stats, biased var to normalise, unbiased into running_var,
     momentum 0.1) or DomainSpecificBatchNorm2d with ``domain`` = domain_label[0] (dsbn.py:26)."""
     if domain is not None:
         name = '%s.bns.%d' % (name, int(domain))
     if training:
         sd[name + '.num_batches_tracked'] += 1
+    if ROUND is not None:
+        return _bn_rounded(x, sd, name, training, stats_from_stored)
     return F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'],
                         sd[name + '.weight'], sd[name + '.bias'], training, MOMENTUM, EPS)
+
+
+def _bn_rounded(z, sd, name, training, stats_from_stored):
+    """BatchNorm under the rounding model: statistics from the fp32 conv result (or from the stored tensor when
+    the producer is the upsample), normalisation applied to the stored (rounded) tensor."""
+    if stats_from_stored:
+        zs = src = z                   # y = up2(t): already stored rounded; its gradient is never materialised (rd_up_bwd)
+    else:
+        qg(z)                          # dz = the dgrad / wgrad operand
+        zs, src = q(z), z
+    if training:
+        mean = src.mean((0, 2, 3))
+        var = src.var((0, 2, 3), unbiased=False)
+        with torch.no_grad():
+            n = src.numel() / src.shape[1]
+            rm, rv = sd[name + '.running_mean'], sd[name + '.running_var']
+            rm.mul_(1 - MOMENTUM).add_(MOMENTUM * mean)
+            rv.mul_(1 - MOMENTUM).add_(MOMENTUM * var * (n / max(n - 1, 1)))
+    else:
+        mean, var = sd[name + '.running_mean'], sd[name + '.running_var']
+    sc = sd[name + '.weight'] / torch.sqrt(var + EPS)
+    y = zs * sc[None, :, None, None] + (sd[name + '.bias'] - mean * sc)[None, :, None, None]
+    return qg(y)
 
 
 def convd(x, sd, p, first, training, slope=0.0):
@@ -131,11 +204,21 @@ def convd(x, sd, p, first, training, slope=0.0):
     return z
 
 
+def _up_conv1(x, sd, p, training, domain, slope):
+    """up x2 -> conv1x1 -> BN -> act (unet.py:104-108 / 152-156).  Rounding model: conv1x1 at low resolution, then
+    the upsample (what the HIP path does; equal in real arithmetic because bilinear weights sum to 1)."""
+    if ROUND is None:
+        y = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+        return _act(_bn(_conv(y, sd, p + '.conv2', 0), sd, p + '.bn2', training, domain), slope)
+    t = qg(q(_conv(x, sd, p + '.conv2', 0)))
+    y = q(F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False))
+    return _act(_bn(y, sd, p + '.bn2', training, domain, stats_from_stored=True), slope)
+
+
 def convu(x, prev, sd, p, first, training, slope=0.0):
     if not first:
         x = _act(_bn(_conv(x, sd, p + '.conv1', 1), sd, p + '.bn1', training), slope)
-    y = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
-    y = _act(_bn(_conv(y, sd, p + '.conv2', 0), sd, p + '.bn2', training), slope)
+    y = _up_conv1(x, sd, p, training, None, slope)
     y = torch.cat([prev, y], 1)                                                  # skip first (unet.py:110)
     y = _act(_bn(_conv(y, sd, p + '.conv3', 1), sd, p + '.bn3', training), slope)
     return y
@@ -143,8 +226,7 @@ def convu(x, prev, sd, p, first, training, slope=0.0):
 
 def convu_rec(x, sd, p, domain, training, slope=0.0):
     x = _act(_bn(_conv(x, sd, p + '.conv1', 1), sd, p + '.bn1', training, domain), slope)
-    y = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
-    y = _act(_bn(_conv(y, sd, p + '.conv2', 0), sd, p + '.bn2', training, domain), slope)
+    y = _up_conv1(x, sd, p, training, domain, slope)
     y = _act(_bn(_conv(y, sd, p + '.conv3', 1), sd, p + '.bn3', training, domain), slope)
     return y
 
@@ -163,14 +245,14 @@ def decoder_forward(feats, sd, training=True, slope=0.0):
     y = convu(y, feats[-3], sd, 'convu3', False, training, slope)
     y = convu(y, feats[-4], sd, 'convu2', False, training, slope)
     y = convu(y, feats[-5], sd, 'convu1', False, training, slope)
-    return _conv(y, sd, 'out1', 1)
+    return q(qg(_conv(y, sd, 'out1', 1)))
 
 
 def rec_decoder_forward(x, sd, domain, training=True, slope=0.0):
     y = x
     for l in (4, 3, 2, 1):
         y = convu_rec(y, sd, 'convu%d' % l, domain, training, slope)
-    return _conv(y, sd, 'out1', 1)
+    return q(qg(_conv(y, sd, 'out1', 1)))
 
 
 def clone_state(sd, requires_grad=False):

@@ -18,13 +18,14 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_fwd_kernel(con
     __shared__ float s_mean[RD_MAX_GROUPS], s_unb[RD_MAX_GROUPS], s_rm[RD_MAX_GROUPS], s_rv[RD_MAX_GROUPS];
     const int c = blockIdx.x, lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float s1 = 0.f, s2 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
     if (p.training) {
         for (int k = lane; k < RD_STAT_SLOTS; k += 64) {
             s1 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
             s2 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
         }
     }
+    const float cbias = p.conv_bias ? p.conv_bias[c] : 0.f;      // the sums are those of (conv result - bias)
     const float gam = p.gamma[g][c], bet = p.beta[g][c];
     const bool has_run = p.running_mean[g] != nullptr;
     float rm = 0.f, rv = 1.f;
@@ -34,14 +35,16 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_fwd_kernel(con
     }
     float mean, invstd, unb = 0.f;
     if (p.training) {
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        const float cnt = p.count[g];
-        mean = s1 / cnt;
-        float var = s2 / cnt - mean * mean;
-        if (var < 0.f) var = 0.f;
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        const double cnt = (double)p.count[g];
+        const double m0 = s1 / cnt;                            // mean of the bias-free result
+        double vard = s2 / cnt - m0 * m0;                      // fp64: safe against |mean| >> sigma (ramdsir.h, RD_STAT_SLOTS)
+        if (vard < 0.0) vard = 0.0;
+        const float var = (float)vard;
+        mean = (float)(m0 + (double)cbias);
         invstd = 1.0f / sqrtf(var + p.eps);
-        unb = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
+        unb = cnt > 1.0 ? (float)(vard * cnt / (cnt - 1.0)) : var;
     } else {
         mean = rm;
         invstd = 1.0f / sqrtf(rv + p.eps);
@@ -83,17 +86,18 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_bwd_kernel(con
     __shared__ float s_s1[RD_MAX_GROUPS], s_s2[RD_MAX_GROUPS];
     const int c = blockIdx.x, lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float s1 = 0.f, sgz = 0.f;
+    double s1d = 0.0, sgzd = 0.0;
     for (int k = lane; k < RD_STAT_SLOTS; k += 64) {
-        s1 += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
-        sgz += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
+        s1d += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
+        sgzd += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
     }
     const float mu = p.mean[g * p.C + c], is = p.invstd[g * p.C + c], gam = p.gamma[g][c];
-    s1 = wave_sum(s1);
-    sgz = wave_sum(sgz);
+    s1d = wave_sum_d(s1d);
+    sgzd = wave_sum_d(sgzd);
     if (lane == 0) {
         const float cnt = p.count[g];
-        const float s2 = is * (sgz - mu * s1);            // sum g * zhat
+        const float s1 = (float)s1d;
+        const float s2 = is * (float)(sgzd - (double)mu * s1d);   // sum g * zhat (the subtraction cancels when |mean| >> sigma: fp64)
         const float P = gam * is;
         const float Q = -gam * is * is * s2 / cnt;
         p.P[g * p.C + c] = P;
@@ -131,21 +135,53 @@ __device__ __forceinline__ void ldv(const T* p, float* f) {
     Slot<T>::unpack(*reinterpret_cast<const uint4*>(p), f);
 }
 
+// Shifted sums of one thread (pivot k = the first value it saw, count n) -> plain sums in fp64:
+//   sum x = s1 + n k,   sum x^2 = s2 + 2 k s1 + n k^2      (|x - k| ~ sigma, so s1, s2 are accurate in fp32)
+__device__ __forceinline__ void unshift(float s1, float s2, float k, int n, double& S1, double& S2) {
+    const double kd = (double)k, nd = (double)n;
+    S1 = (double)s1 + nd * kd;
+    S2 = (double)s2 + 2.0 * kd * (double)s1 + nd * kd * kd;
+}
+
+// lanes with the same channel slot (lane % SL; SL a power of two <= 32) are summed inside the wave, one LDS atomic per wave
+// and channel, then one global fp64 atomic per workgroup and channel into the workgroup's statistics slot
+template <int S>
+__device__ __forceinline__ void reduce_stats_d(double (&A1)[S], double (&A2)[S], double* s_red, int SL, int sl, double* stats_gc, int C) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        for (int o = SL; o < 64; o <<= 1) {
+            A1[e] += __shfl_xor(A1[e], o, 64);
+            A2[e] += __shfl_xor(A2[e], o, 64);
+        }
+    }
+    if (lane < SL) {
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            atomicAdd(&s_red[(sl * S + e) * 2 + 0], A1[e]);
+            atomicAdd(&s_red[(sl * S + e) * 2 + 1], A2[e]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&stats_gc[i], s_red[i]);
+}
+
 // sum / sum of squares of the virtual upsampled tensor; grid (blocks, N)
 template <typename T>
-__global__ __launch_bounds__(256) void up_stats_kernel(const T* t, float* stats, T* y_out, int h, int w, int C, GroupMap gm) {
+__global__ __launch_bounds__(256) void up_stats_kernel(const T* t, double* stats, T* y_out, int h, int w, int C, GroupMap gm) {
     constexpr int S = Slot<T>::N;
-    extern __shared__ float s_red[];                       // [C][2]
+    extern __shared__ double s_redd[];                     // [C][2]
     const int n = blockIdx.y, g = group_of(gm, n);
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_red[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_redd[i] = 0.0;
     __syncthreads();
     const int SL = C / S;
     const int H = 2 * h, W = 2 * w;
     const int items = H * W * SL;
     const int sl = threadIdx.x % SL;                       // constant per thread (256 % SL == 0, stride % SL == 0)
-    float a1[S], a2[S];
+    float a1[S], a2[S], piv[S];
+    int cnt = 0;
 #pragma unroll
-    for (int e = 0; e < S; ++e) a1[e] = a2[e] = 0.f;
+    for (int e = 0; e < S; ++e) a1[e] = a2[e] = piv[e] = 0.f;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < items; idx += gridDim.x * blockDim.x) {
         const int pix = idx / SL;
         const int Y = pix / W, X = pix - Y * W;
@@ -170,32 +206,164 @@ __global__ __launch_bounds__(256) void up_stats_kernel(const T* t, float* stats,
             *reinterpret_cast<uint4*>(y_out + ((size_t)n * H * W + pix) * C + sl * S) = pk;
             Slot<T>::unpack(pk, uu);
         }
+        if (cnt == 0) {
+#pragma unroll
+            for (int e = 0; e < S; ++e) piv[e] = uu[e];
+        }
+        ++cnt;
 #pragma unroll
         for (int e = 0; e < S; ++e) {
-            a1[e] += uu[e];
-            a2[e] += uu[e] * uu[e];
+            const float d = uu[e] - piv[e];
+            a1[e] += d;
+            a2[e] += d * d;
         }
     }
-    // lanes with the same channel slot (lane % SL; SL is a power of two <= 32) are summed inside the wave first: one LDS
-    // atomic per wave and channel instead of one per thread (16-channel tensors had 128 adds queueing on every address)
-    const int lane = threadIdx.x & 63;
+    double A1[S], A2[S];
 #pragma unroll
-    for (int e = 0; e < S; ++e) {
-        for (int o = SL; o < 64; o <<= 1) {
-            a1[e] += __shfl_xor(a1[e], o, 64);
-            a2[e] += __shfl_xor(a2[e], o, 64);
+    for (int e = 0; e < S; ++e) unshift(a1[e], a2[e], piv[e], cnt, A1[e], A2[e]);
+    const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
+    reduce_stats_d<S>(A1, A2, s_redd, SL, sl, stats + ((size_t)g * RD_STAT_SLOTS + slot) * C * 2, C);
+}
+
+// sum / sum of squares of a plain NHWC tensor (standalone BatchNorm2d / DSBN forward); grid (blocks, N)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* x, double* stats, int HW, int C, GroupMap gm) {
+    extern __shared__ double s_redd[];                     // [C][2]
+    const int n = blockIdx.y, g = group_of(gm, n);
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_redd[i] = 0.0;
+    __syncthreads();
+    // generic channel counts (a standalone BN may have any C): one thread per (pixel, channel) element, channel fixed per
+    // thread when blockDim % C == 0, else recomputed -- keep it simple: thread t owns channel t % C of pixels t / C + k*P
+    const int tpb = blockDim.x / C * C;                    // threads that take part (multiple of C)
+    const int c = threadIdx.x % C;
+    float a1 = 0.f, a2 = 0.f, piv = 0.f;
+    int cnt = 0;
+    if ((int)threadIdx.x < tpb) {
+        const int ppb = tpb / C;                           // pixels per block per pass
+        for (int pix = blockIdx.x * ppb + threadIdx.x / C; pix < HW; pix += gridDim.x * ppb) {
+            const float v = to_f<T>(x[((size_t)n * HW + pix) * C + c]);
+            if (cnt == 0) piv = v;
+            ++cnt;
+            const float d = v - piv;
+            a1 += d;
+            a2 += d * d;
         }
     }
-    if (lane < SL) {
-#pragma unroll
-        for (int e = 0; e < S; ++e) {
-            atomicAdd(&s_red[(sl * S + e) * 2 + 0], a1[e]);
-            atomicAdd(&s_red[(sl * S + e) * 2 + 1], a2[e]);
-        }
-    }
+    double A1, A2;
+    unshift(a1, a2, piv, cnt, A1, A2);
+    atomicAdd(&s_redd[c * 2 + 0], A1);
+    atomicAdd(&s_redd[c * 2 + 1], A2);
     __syncthreads();
     const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&stats[((size_t)g * RD_STAT_SLOTS + slot) * C * 2 + i], s_red[i]);
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x)
+        atomicAdd(&stats[((size_t)g * RD_STAT_SLOTS + slot) * C * 2 + i], s_redd[i]);
+}
+
+// ------------------------------------------------------------------------------------ 2x2 max-pool, materialised
+// p = maxpool2(act(z*scale+shift)) stored once (1/4 of the pixels), so that the conv behind nn.MaxPool2d(2) (unet.py:45,56)
+// reads a plain tensor on the prefetching tile loaders in forward, dgrad and wgrad, instead of gathering 4 taps per element
+// in each of them.  grid (blocks, N); one item = one pooled pixel x one 16-byte channel slot.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const T* z, const float* scale, const float* shift, float slope, T* out,
+                                                       int Ho, int Wo, int C, GroupMap gm) {
+    constexpr int S = Slot<T>::N;
+    extern __shared__ float s_cf[];                        // [2][C]
+    const int n = blockIdx.y, g = group_of(gm, n);
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        s_cf[i] = scale ? scale[g * C + i] : 1.f;
+        s_cf[C + i] = shift ? shift[g * C + i] : 0.f;
+    }
+    __syncthreads();
+    const int SL = C / S, W = 2 * Wo;
+    const int items = Ho * Wo * SL;
+    const T* zb = z + (size_t)n * 4 * Ho * Wo * C;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < items; idx += gridDim.x * blockDim.x) {
+        const int sl = idx % SL, pix = idx / SL;
+        const int y = pix / Wo, x = pix - y * Wo;
+        float v[4][S], best[S];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ldv<T>(zb + ((size_t)(2 * y + (k >> 1)) * W + 2 * x + (k & 1)) * C + sl * S, v[k]);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const float sc = s_cf[sl * S + e], sh = s_cf[C + sl * S + e];
+            best[e] = act_fn(v[0][e] * sc + sh, slope);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) best[e] = fmaxf(best[e], act_fn(v[k][e] * sc + sh, slope));
+        }
+        *reinterpret_cast<uint4*>(out + ((size_t)n * Ho * Wo + pix) * C + sl * S) = Slot<T>::pack(best);
+    }
+}
+
+// backward: the gradient gp w.r.t. the pooled tensor goes to the FIRST maximum of each window (ATen max_pool2d), times the
+// activation's derivative there; the other three positions get 0 (or keep what a skip connection wrote: accumulate); the
+// BatchNorm-backward sums (sum g, sum g*z) of the scattered part are added to the producer's statistics slots.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* gp, const T* z, const float* scale, const float* shift, float slope,
+                                                       int act, T* gout, int accumulate, double* bstats, int Ho, int Wo, int C,
+                                                       GroupMap gm) {
+    constexpr int S = Slot<T>::N;
+    extern __shared__ double s_redd[];                     // [C][2], then [2][C] floats of coefficients
+    float* s_cf = reinterpret_cast<float*>(s_redd + 2 * C);
+    const int n = blockIdx.y, g = group_of(gm, n);
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_redd[i] = 0.0;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        s_cf[i] = scale ? scale[g * C + i] : 1.f;
+        s_cf[C + i] = shift ? shift[g * C + i] : 0.f;
+    }
+    __syncthreads();
+    const int SL = C / S, W = 2 * Wo;
+    const int items = Ho * Wo * SL;
+    const int sl = threadIdx.x % SL;                       // constant per thread (256 % SL == 0, stride % SL == 0)
+    const T* zb = z + (size_t)n * 4 * Ho * Wo * C + sl * S;
+    T* gb = gout + (size_t)n * 4 * Ho * Wo * C + sl * S;
+    float b1[S], b2[S], sc[S], sh[S];
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        b1[e] = b2[e] = 0.f;
+        sc[e] = s_cf[sl * S + e];
+        sh[e] = s_cf[C + sl * S + e];
+    }
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < items; idx += gridDim.x * blockDim.x) {
+        const int pix = idx / SL;
+        const int y = pix / Wo, x = pix - y * Wo;
+        float zz[4][S], gw[4][S], da[S];
+        ldv<T>(gp + ((size_t)n * Ho * Wo + pix) * C + sl * S, da);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t o = ((size_t)(2 * y + (k >> 1)) * W + 2 * x + (k & 1)) * C;
+            ldv<T>(zb + o, zz[k]);
+            if (accumulate) ldv<T>(gb + o, gw[k]);
+        }
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            float best = act_fn(zz[0][e] * sc[e] + sh[e], slope);
+            int arg = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float a = act_fn(zz[k][e] * sc[e] + sh[e], slope);
+                if (a > best) { best = a; arg = k; }      // first max wins
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float gn = 0.f;
+                if (arg == k) {
+                    gn = da[e] * (act ? act_grad(zz[k][e] * sc[e] + sh[e], slope) : 1.f);
+                    b1[e] += gn;
+                    b2[e] += gn * zz[k][e];
+                }
+                gw[k][e] = accumulate ? gw[k][e] + gn : gn;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<uint4*>(gb + ((size_t)(2 * y + (k >> 1)) * W + 2 * x + (k & 1)) * C) = Slot<T>::pack(gw[k]);
+    }
+    if (!bstats) return;
+    double A1[S], A2[S];
+#pragma unroll
+    for (int e = 0; e < S; ++e) { A1[e] = (double)b1[e]; A2[e] = (double)b2[e]; }
+    const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
+    reduce_stats_d<S>(A1, A2, s_redd, SL, sl, bstats + ((size_t)g * RD_STAT_SLOTS + slot) * C * 2, C);
 }
 
 // weights of the (up to 4) hi-res rows 2y-1..2y+2 on lo-res row y, and the 3 coefficients of row y of U^T U
@@ -319,7 +487,7 @@ __global__ void nhwc_to_nchw_kernel(const T* z, float* y, const float* scale, co
 // one block = 64 consecutive pixels of one image; per-channel partial sums through LDS
 template <typename T>
 __global__ __launch_bounds__(256) void grad_in_kernel(const float* dy, const T* z, T* gout, const float* scale,
-                                                      const float* shift, float* bstats, int act, float slope,
+                                                      const float* shift, double* bstats, int act, float slope,
                                                       int accumulate, int C, int H, int W, GroupMap gm) {
     extern __shared__ float s_red[];                       // [C][2]
     const int n = blockIdx.y, g = group_of(gm, n);
@@ -347,7 +515,7 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float* dy, const T* 
     __syncthreads();
     if (bstats) {
         const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
-        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&bstats[((size_t)g * RD_STAT_SLOTS + slot) * C * 2 + i], s_red[i]);
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&bstats[((size_t)g * RD_STAT_SLOTS + slot) * C * 2 + i], (double)s_red[i]);
     }
 }
 
@@ -443,21 +611,68 @@ int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
     return (int)hipGetLastError();
 }
 
-int rd_up_stats(const void* t, float* stats, void* y_out, int N, int h, int w, int C, int G, const int32_t* gstart_host, int dtype,
+int rd_up_stats(const void* t, double* stats, void* y_out, int N, int h, int w, int C, int G, const int32_t* gstart_host, int dtype,
                 void* stream) {
     const int S = dtype == RD_BF16 ? 8 : 4;
     if (C % S || 256 % (C / S)) return -2;
     const GroupMap gm = host_gm(G, gstart_host);
     const int items = 4 * h * w * (C / S);
-    static const int us_per = getenv("RD_UPS_PER") ? atoi(getenv("RD_UPS_PER")) : 8;
+    static const int us_per = rd_switch("RD_UPS_PER", 8);
     int bx = grid_for(items, 256 * us_per, 4096);
     dim3 grid(bx, N);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(up_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+        hipLaunchKernelGGL(up_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream,
                            (const bf16_t*)t, stats, (bf16_t*)y_out, h, w, C, gm);
     else
-        hipLaunchKernelGGL(up_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+        hipLaunchKernelGGL(up_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream,
                            (const float*)t, stats, (float*)y_out, h, w, C, gm);
+    return (int)hipGetLastError();
+}
+
+int rd_bn_stats(const void* x, double* stats, int N, int H, int W, int C, int G, const int32_t* gstart_host, int dtype, void* stream) {
+    if (!x || !stats || C < 1 || C > 256) return -2;
+    if (G < 1 || G > RD_MAX_GROUPS) return -1;
+    const GroupMap gm = host_gm(G, gstart_host);
+    const int ppb = 256 / C;                                   // pixels per block per pass
+    const int bx = grid_for(H * W, ppb * 16, 2048);
+    dim3 grid(bx, N);
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, (const bf16_t*)x, stats, H * W, C, gm);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, (const float*)x, stats, H * W, C, gm);
+    return (int)hipGetLastError();
+}
+
+int rd_pool_fwd(const void* z, const float* scale, const float* shift, float slope, void* out, int N, int Ho, int Wo, int C, int G,
+                const int32_t* gstart_host, int dtype, void* stream) {
+    const int S = dtype == RD_BF16 ? 8 : 4;
+    if (!z || !out || C % S || C > 1024) return -2;
+    if (G < 1 || G > RD_MAX_GROUPS) return -1;
+    const GroupMap gm = host_gm(G, gstart_host);
+    dim3 grid(grid_for((size_t)Ho * Wo * (C / S), 256 * 4, 2048), N);
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(pool_fwd_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const bf16_t*)z, scale, shift,
+                           slope, (bf16_t*)out, Ho, Wo, C, gm);
+    else
+        hipLaunchKernelGGL(pool_fwd_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const float*)z, scale, shift,
+                           slope, (float*)out, Ho, Wo, C, gm);
+    return (int)hipGetLastError();
+}
+
+int rd_pool_bwd(const void* gp, const void* z, const float* scale, const float* shift, float slope, int act, void* g, int accumulate,
+                double* bstats, int N, int Ho, int Wo, int C, int G, const int32_t* gstart_host, int dtype, void* stream) {
+    const int S = dtype == RD_BF16 ? 8 : 4;
+    if (!gp || !z || !g || C % S || C > 1024 || 256 % (C / S)) return -2;
+    if (G < 1 || G > RD_MAX_GROUPS) return -1;
+    const GroupMap gm = host_gm(G, gstart_host);
+    dim3 grid(grid_for((size_t)Ho * Wo * (C / S), 256 * 4, 2048), N);
+    const size_t lds = 2 * C * sizeof(double) + 2 * C * sizeof(float);
+    if (dtype == RD_BF16)
+        hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale, shift,
+                           slope, act, (bf16_t*)g, accumulate, bstats, Ho, Wo, C, gm);
+    else
+        hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
+                           slope, act, (float*)g, accumulate, bstats, Ho, Wo, C, gm);
     return (int)hipGetLastError();
 }
 
@@ -517,7 +732,7 @@ int rd_nhwc_to_nchw(const void* z, float* y, const float* scale, const float* sh
     return (int)hipGetLastError();
 }
 
-int rd_grad_in(const float* dy, const void* z, void* g, const float* scale, const float* shift, float* bstats, int act,
+int rd_grad_in(const float* dy, const void* z, void* g, const float* scale, const float* shift, double* bstats, int act,
                float slope, int accumulate, int N, int C, int H, int W, int G, const int32_t* gstart_host, int dtype,
                void* stream) {
     const GroupMap gm = host_gm(G, gstart_host);

@@ -99,6 +99,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Dispatch overrides (experiments, the forced-dispatch tests) exist only in the DEBUG build of the library
+// (`make debug` -> libramdsir_hip_dbg.so, -DRD_DEBUG_SWITCHES, loaded with RAMDSIR_DEBUG_LIB=1): there rd_switch reads the
+// environment variable; in the product library it IS the default -- no environment lookups, the branches fold away.
+#ifdef RD_DEBUG_SWITCHES
+#include <stdlib.h>
+inline int rd_switch(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#else
+constexpr int rd_switch(const char*, int dflt) { return dflt; }
+#endif
+
 // compute units of the current device (256 on MI355X), queried once
 inline int rd_num_cus() {
     static int n = 0;

@@ -111,21 +111,21 @@ int launch_conv(const rd_conv_t& p, hipStream_t st) {
         attr_set = true;
     }
     if constexpr (sizeof(T) == 2 && TAPS == 9 && NB == 2) {
-        static const bool pp_off = getenv("RD_CONV_PP_OFF") != nullptr;
+        static const bool pp_off = rd_switch("RD_CONV_PP_OFF", 0) != 0;
         if (!pp_off) {
             const int rc = rd_conv_pp_dispatch(p, st);
             if (rc != RD_CONV_PP_NA) return rc;
         }
     }
     if constexpr (sizeof(T) == 2) {
-        static const bool lean_off = getenv("RD_CONV_PF_LEAN_OFF") != nullptr;
-        if (!lean_off && getenv("RD_CONV_PF_OFF") == nullptr) {
+        static const bool lean_off = rd_switch("RD_CONV_PF_LEAN_OFF", 0) != 0;
+        if (!lean_off && rd_switch("RD_CONV_PF_OFF", 0) == 0) {
             const int rc = rd_conv_pf_lean_dispatch(p, NB == 2, st);      // register epilogues (conv_lean.hip)
             if (rc != RD_CONV_PP_NA) return rc;
         }
     }
     if constexpr (sizeof(T) == 2) {
-        static const bool pf_off = getenv("RD_CONV_PF_OFF") != nullptr;
+        static const bool pf_off = rd_switch("RD_CONV_PF_OFF", 0) != 0;
         const int nq = conv_pf_kind(p);
         if (!pf_off && nq && lds <= (size_t)72 * 1024) {
             static bool attr_pf = false;
@@ -152,7 +152,7 @@ int rd_conv_big_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
     bool nb2 = (p.CoutPad % 64) == 0;
     {
         // small grids (the 25x25 / 50x50 levels): 32-channel tiles double the number of workgroups
-        static const int nb1_below = getenv("RD_CONV_NB1_BELOW") ? atoi(getenv("RD_CONV_NB1_BELOW")) : 300;
+        static const int nb1_below = rd_switch("RD_CONV_NB1_BELOW", 300);
         const int wgs64 = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / 64);
         if (nb2 && dtype == RD_BF16 && wgs64 < nb1_below) nb2 = false;
     }

@@ -40,7 +40,8 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
                     const int col = (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float v = acc[mb][nb][r] + bsv;
                     s_out[((wave * 2 + mb) * TW + col) * 32 + li] = v;
-                    if (cok && y < H && x0 + col < W) { s1 += v; s2 += v * v; }
+                    // BatchNorm sums are those of the result WITHOUT the bias (ramdsir.h, RD_STAT_SLOTS): finalize adds it back
+                    if (cok && y < H && x0 + col < W) { const float a0 = acc[mb][nb][r]; s1 += a0; s2 += a0 * a0; }
                 }
             }
             __syncthreads();
@@ -95,8 +96,8 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
             if (p.emode == 0) {
                 if (p.stats) {
                     const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + cb + tid) * 2;
-                    atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
-                    atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
+                    atomicAdd(&p.stats[so + 0], (double)s_red[tid * 2 + 0]);
+                    atomicAdd(&p.stats[so + 1], (double)s_red[tid * 2 + 1]);
                 }
             } else {
                 const int cch = cb + tid;
@@ -106,8 +107,8 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
                     const int cdd = cch - (dj ? p.c_split : 0);
                     const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
                     const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
-                    atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
-                    atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
+                    atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
+                    atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
                 }
             }
         }
@@ -159,9 +160,9 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
                     if (!valid) continue;
 #pragma unroll
                     for (int e = 0; e < S; ++e) {
-                        o[e] += s_epi[cl + e];
-                        sa[nb][v][e] += o[e];
+                        sa[nb][v][e] += o[e];                     // sums exclude the bias (ramdsir.h, RD_STAT_SLOTS)
                         sb[nb][v][e] += o[e] * o[e];
+                        o[e] += s_epi[cl + e];
                     }
                     *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + ((size_t)(n * H + y) * W + x) * p.Cout + n0 + cl) = Slot<T>::pack(o);
                 } else {
@@ -214,8 +215,8 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
         if constexpr (EP == 1) {
             if (p.stats) {
                 const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + cch) * 2;
-                atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
-                atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
+                atomicAdd(&p.stats[so + 0], (double)s_red[tid * 2 + 0]);
+                atomicAdd(&p.stats[so + 1], (double)s_red[tid * 2 + 1]);
             }
         } else {
             const int dj = cch >= p.c_split ? 1 : 0;
@@ -223,8 +224,8 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
             if (dd.kind != RD_DST_NONE && dd.bstats) {
                 const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
                 const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cch - (dj ? p.c_split : 0)) * 2;
-                atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
-                atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
+                atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
             }
         }
     }

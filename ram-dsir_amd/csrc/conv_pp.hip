@@ -290,8 +290,8 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
                     if constexpr (MODE == 1) {
                         if (li == 0 && p.stats) {
                             const size_t so = (((size_t)cur_g * RD_STAT_SLOTS + slot) * p.Cout + cur_n0 + nb * 32 + 16 * v + 8 * h + e) * 2;
-                            atomicAdd(&p.stats[so + 0], a);
-                            atomicAdd(&p.stats[so + 1], b);
+                            atomicAdd(&p.stats[so + 0], (double)a);
+                            atomicAdd(&p.stats[so + 1], (double)b);
                         }
                     } else {
                         const int c = cur_n0 + nb * 32 + 16 * v;
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
                         if (li == 0 && d.kind != RD_DST_NONE && d.bstats) {
                             const int gd = d.g_fixed >= 0 ? d.g_fixed : cur_g;
                             const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * d.Cd + c - (di ? p.c_split : 0) + 8 * h + e) * 2;
-                            atomicAdd(&d.bstats[so + 0], a);
-                            atomicAdd(&d.bstats[so + 1], b);
+                            atomicAdd(&d.bstats[so + 0], (double)a);
+                            atomicAdd(&d.bstats[so + 1], (double)b);
                         }
                     }
                     sa[nb][v][e] = sb[nb][v][e] = 0.f;
@@ -432,14 +432,15 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
                                 const unsigned a = __float_as_uint(acc[mb][nb][8 * v + j]);
                                 const unsigned b = __float_as_uint(acc[mb][nb][8 * v + 4 + j]);
                                 const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-                                o[j] = __uint_as_float(r[0]) + bs[nb][v][j];
-                                o[4 + j] = __uint_as_float(r[1]) + bs[nb][v][4 + j];
+                                o[j] = __uint_as_float(r[0]);
+                                o[4 + j] = __uint_as_float(r[1]);
                             }
                             if (valid) {
 #pragma unroll
                                 for (int e = 0; e < S; ++e) {
-                                    sa[nb][v][e] += o[e];
+                                    sa[nb][v][e] += o[e];              // sums exclude the bias (ramdsir.h, RD_STAT_SLOTS)
                                     sb[nb][v][e] += o[e] * o[e];
+                                    o[e] += bs[nb][v][e];
                                 }
                                 *reinterpret_cast<uint4*>(orow + nb * 32 + 16 * v) = Slot<T>::pack(o);
                             }
@@ -542,7 +543,7 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     // Measured (gpurun_out/lb_pp*.txt): with at most one tile per CU -- the 25x25 level -- the pipelined K loop wins
     // 1.06-1.2x; on longer tile ranges the un-overlapped epilogue (2100 VALU per tile and wave, one workgroup per CU)
     // costs more than the K loop gains (0.7-0.9x), so those launches stay with conv_pf_kernel.  RD_CONV_PP_ALL=1 lifts the limit.
-    static const bool pp_all = getenv("RD_CONV_PP_ALL") != nullptr;
+    static const bool pp_all = rd_switch("RD_CONV_PP_ALL", 0) != 0;
     // forward launches whose output is whole 64-channel blocks take the register epilogue (LEAN) at any size
     // Which launches take this kernel (layer timings in gpurun_out/lb_lean*.txt, us, conv_pf_kernel -> this kernel):
     //   forward, >= 3 tiles per CU:  64->64 @200x200 121 -> 97, 128->128 @100x100 113 -> 98, 128->64 @100x100 67 -> 62,
@@ -551,7 +552,7 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     //   gradient (MODE 2):           slower almost everywhere (40 -> 57, 74 -> 87; only 64->64 @200x200 gains, 155 -> 142):
     //                                its sources are already-materialised dz tensors, which conv_pf_kernel streams with
     //                                two workgroups per CU -- opt-in only (RD_CONV_PP_LEAN2=1).
-    static const bool lean_off = getenv("RD_CONV_PP_LEAN_OFF") != nullptr, lean2_on = getenv("RD_CONV_PP_LEAN2") != nullptr;
+    static const bool lean_off = rd_switch("RD_CONV_PP_LEAN_OFF", 0) != 0, lean2_on = rd_switch("RD_CONV_PP_LEAN2", 0) != 0;
     int lean = lean_off ? 0 : rd_conv_lean_mode(p, PP_NT);               // 0 none, 1 forward, 2 plain gradient (conv_dispatch.h)
     if (lean == 1 && !(tiles >= 3 * n_cu || pp_all)) lean = 0;
     if (lean == 2 && !lean2_on) lean = 0;

@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
 #pragma unroll
                     for (int e = 0; e < S; ++e) {
                         o[e] = vec[v][e] + bs[v][e];
-                        sa[v][e] += o[e];
-                        sb[v][e] += o[e] * o[e];
+                        sa[v][e] += vec[v][e];                    // sums exclude the bias (ramdsir.h, RD_STAT_SLOTS)
+                        sb[v][e] += vec[v][e] * vec[v][e];
                     }
                     store_vec<T>(out + ((size_t)(n * H + y) * W + x) * p.Cout + cb, o, p.Cout - cb, (p.Cout % S) == 0);
                 } else {
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
         if constexpr (EPI == 0) {
             if (p.stats) {
                 const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + tid) * 2;
-                atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
-                atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
+                atomicAdd(&p.stats[so + 0], (double)s_red[tid * 2 + 0]);
+                atomicAdd(&p.stats[so + 1], (double)s_red[tid * 2 + 1]);
             }
         } else {
             const int dj = tid >= p.c_split ? 1 : 0;
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
                 const int cdd = tid - (dj ? p.c_split : 0);
                 const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
                 const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
-                atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
-                atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
+                atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
             }
         }
     }
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
                 const float v = acc[mb][r] + bsv;
                 s_out[((wave * 2 + mb) * TW + col) * 32 + li] = v;
                 if constexpr (EPI == 0) {
-                    if (interior || (y < H && x0 + col < W)) { s1 += v; s2 += v * v; }
+                    if (interior || (y < H && x0 + col < W)) { s1 += acc[mb][r]; s2 += acc[mb][r] * acc[mb][r]; }   // bias-free sums
                 }
             }
         }
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
         if (p.emode == 0) {
             if (p.stats) {
                 const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + tid) * 2;
-                atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
-                atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
+                atomicAdd(&p.stats[so + 0], (double)s_red[tid * 2 + 0]);
+                atomicAdd(&p.stats[so + 1], (double)s_red[tid * 2 + 1]);
             }
         } else {
             const int dj = tid >= p.c_split ? 1 : 0;
@@ -462,8 +462,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
                 const int cdd = tid - (dj ? p.c_split : 0);
                 const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
                 const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
-                atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
-                atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
+                atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
             }
         }
     }
@@ -478,7 +478,7 @@ int launch_conv_small(const rd_conv_t& p, hipStream_t st) {
                        (REG_EPI ? (size_t)(64 + 64) * sizeof(float) : (size_t)(TH * TW * 32 + 64) * sizeof(float));
     const int ntiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
     static int tpw_env = -1;
-    if (tpw_env < 0) { const char* e = getenv("RD_TPW"); tpw_env = e ? atoi(e) : 0; }
+    if (tpw_env < 0) tpw_env = rd_switch("RD_TPW", 0);
     // tiles per workgroup: the launch runs in rounds of `slots` resident workgroups (2 per CU); pick the
     // count whose last round is (nearly) full -- e.g. 16 images x 650 tiles: 4 tiles/workgroup is 6 rounds
     // x 4 tile-times, 21 tiles/workgroup is 1 round x 21 -- charging half a tile-time per workgroup prologue

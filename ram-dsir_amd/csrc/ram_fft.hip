@@ -8,13 +8,19 @@
 // centred (2b+1)^2 window and the identity elsewhere:   out = src + IFFT2( D ),
 //     D[k] = (1-lam) * (|F_trg[k]|/|F_src[k]| - 1) * F_src[k]      for |ky|<=b, |kx|<=b     (0 elsewhere)
 // (|F_src|==0: D = (1-lam)|F_trg|, the reference's angle()==0 case).  Only window bins are ever needed:
-//   A  row pass     one workgroup per image row: Stockham FFT (radix 4/2/3/5, LDS ping-pong) of the
-//                   3 channels, keep bins kx = 0..b                                  -> rowspec[img][c][kx][y]
-//   B  column pass  one workgroup per (sample, channel, kx): FFT of the src and trg columns, mix on the
-//                   2b+1 bins, inverse FFT of the zero-padded column                   -> colout[n][c][kx][y]
-//   C  row inverse  one workgroup per output row: Hermitian row spectrum (2b+1 bins) -> real row, + src,
-//                   clip, scale, store both network inputs (img, img_freq) as NHWC dtype.
-// All loads of image rows / spectrum columns are contiguous; butterflies run out of LDS.
+//   A  row pass     one workgroup per PAIR of image rows: Stockham FFTs (LDS ping-pong) of their 3 channels,
+//                   keep bins kx = 0..b                                             -> rowspec[img][c][y][kx]
+//   B  column pass  one workgroup per (sample, channel, 4 bins kx): FFT of the src and trg columns, mix on
+//                   the 2b+1 bins, inverse FFT of the zero-padded columns             -> colout[n][c][y][kx]
+//   C  row inverse  one workgroup per pair of output rows: Hermitian row spectrum (2b+1 bins) -> real row,
+//                   + src, clip, scale, store both network inputs (img, img_freq) as NHWC dtype.
+// The sides 256 / 384 / 400 / 512 (the reference's Fundus crop, Prostate slices, BASELINE.json's two synthetic
+// shapes) run compile-time radix plans (4,4,4,4 / 4,4,4,2,3 / 4,4,5,5 / 4,4,4,4,2): every quotient, stride and
+// twiddle step is a constant; any other side that factors into 2, 3, 5 runs the run-time plan.  Image rows are
+// read as 16-byte vectors (fp32, or uint8 as decoded PNGs are: 1 byte per value), spectrum panels with the bin
+// index fastest in both directions, the outputs as whole 16-byte channel slots.
+// Standalone entry points for the reference's free functions: rd_ram_amp (|fft2|, full spectrum), rd_ram_mutate (the
+// window lerp on two amplitude arrays), and rd_ram_mix with `trg_amp` (source_to_target_freq given an amplitude array).
 #include "common.h"
 #include "../../include/ramdsir.h"
 
@@ -32,10 +38,101 @@ __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2
 // s * i * a   (s = -1 forward, +1 inverse)
 __device__ __forceinline__ float2 imul(float2 a, float s) { return make_float2(-s * a.y, s * a.x); }
 
-// `batch` independent length-N Stockham autosort FFTs in LDS.  Transform t ping-pongs between
-// buf[(t*2+0)*N ..] and buf[(t*2+1)*N ..]; returns which half holds the result (same for every t).
-// tw[k] = (cos 2*pi*k/N, -sin 2*pi*k/N): the fp64-accurate table from the host, copied into LDS by the caller.
-__device__ int fft_stockham(float2* buf, int batch, const FftPlan& pl, const float2* tw, bool inverse, int tid, int nthreads) {
+// radix-R DFT of v[0..R) in place (v[m] <- X_m); sgn = -1 forward, +1 inverse
+template <int R>
+__device__ __forceinline__ void butterfly(float2* v, float sgn) {
+    if constexpr (R == 2) {
+        const float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    } else if constexpr (R == 4) {
+        const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = imul(csub(v[1], v[3]), sgn);
+        v[0] = cadd(t0, t2);
+        v[1] = cadd(t1, t3);
+        v[2] = csub(t0, t2);
+        v[3] = csub(t1, t3);
+    } else if constexpr (R == 3) {
+        const float2 t1 = cadd(v[1], v[2]);
+        const float2 t2 = csub(v[0], cscale(t1, 0.5f));
+        const float2 t3 = imul(cscale(csub(v[1], v[2]), 0.86602540378443864676f), sgn);
+        v[0] = cadd(v[0], t1);
+        v[1] = cadd(t2, t3);
+        v[2] = csub(t2, t3);
+    } else {  // R == 5
+        const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+        const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+        const float2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+        const float2 m1 = cadd(v[0], cadd(cscale(a1, c1), cscale(a2, c2)));
+        const float2 m2 = cadd(v[0], cadd(cscale(a1, c2), cscale(a2, c1)));
+        const float2 n1 = imul(cadd(cscale(b1, s1), cscale(b2, s2)), sgn);
+        const float2 n2 = imul(csub(cscale(b1, s2), cscale(b2, s1)), sgn);
+        v[0] = cadd(v[0], cadd(a1, a2));
+        v[1] = cadd(m1, n1);
+        v[4] = csub(m1, n1);
+        v[2] = cadd(m2, n2);
+        v[3] = csub(m2, n2);
+    }
+}
+
+// One Stockham autosort stage of `batch` independent length-N transforms in LDS, all constants known at compile time.
+// Transform t ping-pongs between buf[(t*2+0)*N ..] and buf[(t*2+1)*N ..].  tw[k] = (cos 2 pi k/N, -sin 2 pi k/N).
+template <int R, bool INV, int N, int NS>
+__device__ __forceinline__ void stage_fixed(float2* buf, int cur, int batch, const float2* tw, int tid, int nthreads) {
+    constexpr int nb = N / R, tstep = N / (NS * R);
+    constexpr float sgn = INV ? 1.f : -1.f;
+    for (int jj = tid; jj < batch * nb; jj += nthreads) {
+        const int t = jj / nb, j = jj - t * nb;
+        const int q = j / NS, k = j - q * NS;
+        const float2* a = buf + (t * 2 + cur) * N;
+        float2* o = buf + (t * 2 + (cur ^ 1)) * N + q * NS * R + k;
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = a[j + r * nb];
+        if constexpr (NS > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                float2 w = tw[r * k * tstep];
+                if (INV) w.y = -w.y;
+                v[r] = cmul(v[r], w);
+            }
+        }
+        butterfly<R>(v, sgn);
+#pragma unroll
+        for (int r = 0; r < R; ++r) o[r * NS] = v[r];
+    }
+    __syncthreads();
+}
+
+// compile-time plans; returns which half holds the result
+template <int N, bool INV>
+__device__ __forceinline__ int fft_fixed(float2* buf, int batch, const float2* tw, int tid, int nthreads) {
+    static_assert(N == 256 || N == 384 || N == 400 || N == 512, "compile-time plans: 256, 384, 400, 512");
+    stage_fixed<4, INV, N, 1>(buf, 0, batch, tw, tid, nthreads);
+    stage_fixed<4, INV, N, 4>(buf, 1, batch, tw, tid, nthreads);
+    if constexpr (N == 400) {
+        stage_fixed<5, INV, N, 16>(buf, 0, batch, tw, tid, nthreads);
+        stage_fixed<5, INV, N, 80>(buf, 1, batch, tw, tid, nthreads);
+        return 0;
+    } else {
+        stage_fixed<4, INV, N, 16>(buf, 0, batch, tw, tid, nthreads);
+        if constexpr (N == 256) {
+            stage_fixed<4, INV, N, 64>(buf, 1, batch, tw, tid, nthreads);
+            return 0;
+        } else if constexpr (N == 384) {
+            stage_fixed<2, INV, N, 64>(buf, 1, batch, tw, tid, nthreads);
+            stage_fixed<3, INV, N, 128>(buf, 0, batch, tw, tid, nthreads);
+            return 1;
+        } else {
+            stage_fixed<4, INV, N, 64>(buf, 1, batch, tw, tid, nthreads);
+            stage_fixed<2, INV, N, 256>(buf, 0, batch, tw, tid, nthreads);
+            return 1;
+        }
+    }
+}
+
+// run-time plan (any side that factors into 2, 3, 5): same stages, quotients by float reciprocals (exact for these
+// ranges: a < 2^12, divisor <= 1024)
+__device__ int fft_runtime(float2* buf, int batch, const FftPlan& pl, const float2* tw, bool inverse, int tid, int nthreads) {
     const int N = pl.N;
     const float sgn = inverse ? 1.f : -1.f;
     int Ns = 1, cur = 0;
@@ -43,16 +140,13 @@ __device__ int fft_stockham(float2* buf, int batch, const FftPlan& pl, const flo
         const int R = pl.radix[st];
         const int nb = N / R;
         const int tstep = N / (Ns * R);
-        // integer quotients by the run-time stage constants through float reciprocals: exact for these ranges
-        // (a < 2^12, divisor <= 1024: |rounding| ~ 1e-4 of the 0.5/divisor margin), a fraction of the cost of a division
         const float inv_nb = 1.0f / (float)nb, inv_Ns = 1.0f / (float)Ns;
         for (int jj = tid; jj < batch * nb; jj += nthreads) {
             const int t = (int)(((float)jj + 0.5f) * inv_nb), j = jj - t * nb;
             const float2* a = buf + (size_t)(t * 2 + cur) * N;
-            float2* o = buf + (size_t)(t * 2 + (cur ^ 1)) * N;
             const int q = (int)(((float)j + 0.5f) * inv_Ns);
             const int k = j - q * Ns;
-            const int j0 = q * Ns * R + k;
+            float2* o = buf + (size_t)(t * 2 + (cur ^ 1)) * N + q * Ns * R + k;
             float2 v[5];
 #pragma unroll
             for (int r = 0; r < 5; ++r)
@@ -64,36 +158,13 @@ __device__ int fft_stockham(float2* buf, int batch, const FftPlan& pl, const flo
                         v[r] = cmul(v[r], w);
                     }
                 }
-            if (R == 2) {
-                o[j0] = cadd(v[0], v[1]);
-                o[j0 + Ns] = csub(v[0], v[1]);
-            } else if (R == 4) {
-                const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = imul(csub(v[1], v[3]), sgn);
-                o[j0] = cadd(t0, t2);
-                o[j0 + Ns] = cadd(t1, t3);
-                o[j0 + 2 * Ns] = csub(t0, t2);
-                o[j0 + 3 * Ns] = csub(t1, t3);
-            } else if (R == 3) {
-                const float2 t1 = cadd(v[1], v[2]);
-                const float2 t2 = csub(v[0], cscale(t1, 0.5f));
-                const float2 t3 = imul(cscale(csub(v[1], v[2]), 0.86602540378443864676f), sgn);
-                o[j0] = cadd(v[0], t1);
-                o[j0 + Ns] = cadd(t2, t3);
-                o[j0 + 2 * Ns] = csub(t2, t3);
-            } else {  // R == 5
-                const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
-                const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-                const float2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
-                const float2 m1 = cadd(v[0], cadd(cscale(a1, c1), cscale(a2, c2)));
-                const float2 m2 = cadd(v[0], cadd(cscale(a1, c2), cscale(a2, c1)));
-                const float2 n1 = imul(cadd(cscale(b1, s1), cscale(b2, s2)), sgn);
-                const float2 n2 = imul(csub(cscale(b1, s2), cscale(b2, s1)), sgn);
-                o[j0] = cadd(v[0], cadd(a1, a2));
-                o[j0 + Ns] = cadd(m1, n1);
-                o[j0 + 4 * Ns] = csub(m1, n1);
-                o[j0 + 2 * Ns] = cadd(m2, n2);
-                o[j0 + 3 * Ns] = csub(m2, n2);
-            }
+            if (R == 2) butterfly<2>(v, sgn);
+            else if (R == 4) butterfly<4>(v, sgn);
+            else if (R == 3) butterfly<3>(v, sgn);
+            else butterfly<5>(v, sgn);
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+                if (r < R) o[r * Ns] = v[r];
         }
         __syncthreads();
         cur ^= 1;
@@ -102,122 +173,244 @@ __device__ int fft_stockham(float2* buf, int batch, const FftPlan& pl, const flo
     return cur;
 }
 
+template <int NFIX>
+__device__ __forceinline__ int fft_any(float2* buf, int batch, const FftPlan& pl, const float2* tw, bool inverse, int tid, int nthreads) {
+    if constexpr (NFIX == 0) return fft_runtime(buf, batch, pl, tw, inverse, tid, nthreads);
+    else return inverse ? fft_fixed<NFIX, true>(buf, batch, tw, tid, nthreads) : fft_fixed<NFIX, false>(buf, batch, tw, tid, nthreads);
+}
+
 struct RamArgs {
-    const float* src; const float* trg; const float* lam;
+    const void* src; const void* trg; const float* trg_amp; const float* lam;
     void* out_img; void* out_freq;
     float2* rowspec; float2* colout;
     const float2* tw_w; const float2* tw_h;
-    int B, H, W, b, cs;
-    float clip_lo, clip_hi, scale, offset;
+    float* amp_out;
+    int B, H, W, b, cs, KP, nkeep;       // nkeep bins kept per row (b+1, or W/2+1 for the amplitude entry point); KP = nkeep padded to 4
+    int nimg_rows, nch, src_u8, planar;  // row pass: images to transform, channels per image (3; 1 = planar planes)
+    float clip_lo, clip_hi, scale, div, offset;
     FftPlan pw, ph;
 };
 
-// A: grid (H, 2B)  images [0,B) = src batch, [B,2B) = trg batch.  One transform per channel (zero imaginary
-// part) rather than a packed pair: an all-zero channel must give an EXACTLY zero spectrum, because the mix
-// divides by |F_src| (the reference's angle()==0 branch, fundus.py:48 on a constant-zero plane).
+// value i (= x*3 + c) of an interleaved image row
+__device__ __forceinline__ void put3(float2* buf, int W, int i, float v) {
+    const int x = i / 3, c = i - 3 * x;
+    buf[c * 2 * W + x] = make_float2(v, 0.f);
+}
+
+// A: grid (ceil(H/ROWS), images).  One transform per channel (zero imaginary part) rather than a packed pair: an
+// all-zero channel must give an EXACTLY zero spectrum, because the mix divides by |F_src| (the reference's angle()==0
+// branch, fundus.py:48 on a constant-zero plane).
+template <int NW, int ROWS>
 __global__ __launch_bounds__(256) void ram_row_fwd_kernel(const RamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    float2* buf = reinterpret_cast<float2*>(smem_);        // [3 transforms][2][W], then the twiddle table [W]
-    const int y = blockIdx.x, n = blockIdx.y, W = a.W, H = a.H;
-    float2* s_tw = buf + 6 * W;                            // twiddles out of LDS: a butterfly no longer waits on L2 for them
+    float2* buf = reinterpret_cast<float2*>(smem_);        // [ROWS * nch transforms][2][W], then the twiddle table [W]
+    const int W = a.W, H = a.H, nch = a.nch;
+    const int y0 = blockIdx.x * ROWS, n = blockIdx.y;
+    float2* s_tw = buf + ROWS * nch * 2 * W;               // twiddles out of LDS: a butterfly does not wait on L2 for them
     for (int i = threadIdx.x; i < W; i += blockDim.x) s_tw[i] = a.tw_w[i];
-    const float* img = (n < a.B ? a.src + (size_t)n * H * W * 3 : a.trg + (size_t)(n - a.B) * H * W * 3) + (size_t)y * W * 3;
-    for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) {
-        const int x = i / 3, c = i - 3 * x;
-        buf[(size_t)c * 2 * W + x] = make_float2(img[i], 0.f);
-    }
-    __syncthreads();
-    const int cur = fft_stockham(buf, 3, a.pw, s_tw, false, threadIdx.x, blockDim.x);
-    const int nb1 = a.b + 1;
-    for (int i = threadIdx.x; i < 3 * nb1; i += blockDim.x) {
-        const int c = i / nb1, kx = i - c * nb1;
-        a.rowspec[((size_t)(n * 3 + c) * nb1 + kx) * H + y] = buf[(size_t)(c * 2 + cur) * W + kx];
-    }
-}
-
-// B: grid (b+1, 3, B)
-__global__ __launch_bounds__(256) void ram_col_kernel(const RamArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_[];
-    float2* buf = reinterpret_cast<float2*>(smem_);        // [2 transforms][2][H], then the twiddle table [H]
-    const int kx = blockIdx.x, c = blockIdx.y, n = blockIdx.z, H = a.H, nb1 = a.b + 1;
-    float2* s_tw = buf + 4 * H;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) s_tw[i] = a.tw_h[i];
-    const float2* cs = a.rowspec + ((size_t)(n * 3 + c) * nb1 + kx) * H;
-    const float2* ct = a.rowspec + ((size_t)((n + a.B) * 3 + c) * nb1 + kx) * H;
-    for (int y = threadIdx.x; y < H; y += blockDim.x) {
-        buf[y] = cs[y];
-        buf[2 * H + y] = ct[y];
-    }
-    __syncthreads();
-    const int cur = fft_stockham(buf, 2, a.ph, s_tw, false, threadIdx.x, blockDim.x);
-    const float2* fs = buf + cur * H;
-    const float2* ft = buf + (2 + cur) * H;
-    float2* din = buf + (cur ^ 1) * H;                      // free half of transform 0 becomes the inverse input
-    const float lam = a.lam[n];
-    for (int y = threadIdx.x; y < H; y += blockDim.x) din[y] = make_float2(0.f, 0.f);
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * a.b + 1; i += blockDim.x) {
-        const int ky = i - a.b;
-        const int idx = (ky + H) % H;
-        const float2 Fs = fs[idx], Ft = ft[idx];
-        const float As = sqrtf(Fs.x * Fs.x + Fs.y * Fs.y), At = sqrtf(Ft.x * Ft.x + Ft.y * Ft.y);
-        din[idx] = As > 0.f ? cscale(Fs, (1.f - lam) * (At / As - 1.f)) : make_float2((1.f - lam) * At, 0.f);
-    }
-    __syncthreads();
-    // inverse FFT of din (it sits in half cur^1 of transform 0: run a batch of 1 starting from that half)
-    float2* ibuf = buf;                                    // transform 0's two halves
-    // fft_stockham starts from half 0: if din is in half 1, swap roles by offsetting through a copy-free trick:
-    // copy din to half 0 when needed (H <= 1024 elements, one pass)
-    if ((cur ^ 1) == 1) {
-        for (int y = threadIdx.x; y < H; y += blockDim.x) ibuf[y] = din[y];
-        __syncthreads();
-    }
-    const int c2 = fft_stockham(ibuf, 1, a.ph, s_tw, true, threadIdx.x, blockDim.x);
-    const float2* yv = ibuf + c2 * H;
-    float2* out = a.colout + ((size_t)(n * 3 + c) * nb1 + kx) * H;
-    for (int y = threadIdx.x; y < H; y += blockDim.x) out[y] = yv[y];
-}
-
-// C: grid (H, B)
-template <typename T>
-__global__ __launch_bounds__(256) void ram_row_inv_kernel(const RamArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_[];
-    float2* buf = reinterpret_cast<float2*>(smem_);        // [2 transforms][2][W], then the twiddle table [W]
-    const int y = blockIdx.x, n = blockIdx.y, W = a.W, H = a.H, nb1 = a.b + 1;
-    float2* s_tw = buf + 4 * W;
-    for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        buf[x] = make_float2(0.f, 0.f);
-        buf[2 * W + x] = make_float2(0.f, 0.f);
-        s_tw[x] = a.tw_w[x];
-    }
-    __syncthreads();
-    for (int kx = threadIdx.x; kx < nb1; kx += blockDim.x) {
-        const float2 R0 = a.colout[((size_t)(n * 3 + 0) * nb1 + kx) * H + y];
-        const float2 R1 = a.colout[((size_t)(n * 3 + 1) * nb1 + kx) * H + y];
-        const float2 R2 = a.colout[((size_t)(n * 3 + 2) * nb1 + kx) * H + y];
-        buf[kx] = make_float2(R0.x - R1.y, R0.y + R1.x);                 // R0 + i R1
-        buf[2 * W + kx] = R2;
-        if (kx > 0) {
-            buf[W - kx] = make_float2(R0.x + R1.y, -R0.y + R1.x);        // conj(R0) + i conj(R1)
-            buf[2 * W + W - kx] = make_float2(R2.x, -R2.y);
+    const int rows = min(ROWS, H - y0);
+    for (int r = 0; r < rows; ++r) {
+        float2* rb = buf + (size_t)r * nch * 2 * W;
+        const int y = y0 + r;
+        if (a.planar) {
+            const float* p = reinterpret_cast<const float*>(a.src) + ((size_t)n * H + y) * W;
+            for (int x = threadIdx.x; x < W; x += blockDim.x) rb[x] = make_float2(p[x], 0.f);
+        } else if (a.src_u8) {
+            const uint8_t* p = reinterpret_cast<const uint8_t*>(n < a.B ? a.src : a.trg) + ((size_t)(n < a.B ? n : n - a.B) * H + y) * W * 3;
+            if ((3 * W) % 16 == 0) {
+                for (int i = threadIdx.x; i < 3 * W / 16; i += blockDim.x) {
+                    const uint4 u = reinterpret_cast<const uint4*>(p)[i];
+                    const unsigned wv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) put3(rb, W, i * 16 + e, (float)((wv[e >> 2] >> (8 * (e & 3))) & 0xffu));
+                }
+            } else {
+                for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) put3(rb, W, i, (float)p[i]);
+            }
+        } else {
+            const float* p = reinterpret_cast<const float*>(n < a.B ? a.src : a.trg) + ((size_t)(n < a.B ? n : n - a.B) * H + y) * W * 3;
+            if ((3 * W) % 4 == 0) {
+                for (int i = threadIdx.x; i < 3 * W / 4; i += blockDim.x) {
+                    const float4 f = reinterpret_cast<const float4*>(p)[i];
+                    put3(rb, W, i * 4 + 0, f.x);
+                    put3(rb, W, i * 4 + 1, f.y);
+                    put3(rb, W, i * 4 + 2, f.z);
+                    put3(rb, W, i * 4 + 3, f.w);
+                }
+            } else {
+                for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) put3(rb, W, i, p[i]);
+            }
         }
     }
     __syncthreads();
-    const int cur = fft_stockham(buf, 2, a.pw, s_tw, true, threadIdx.x, blockDim.x);
-    const float2* r01 = buf + cur * W;
-    const float2* r2 = buf + (2 + cur) * W;
+    const int cur = fft_any<NW>(buf, rows * nch, a.pw, s_tw, false, threadIdx.x, blockDim.x);
+    const int nk = a.nkeep, KP = a.KP;
+    for (int i = threadIdx.x; i < rows * nch * nk; i += blockDim.x) {
+        const int t = i / nk, kx = i - t * nk;              // t = r * nch + c
+        const int r = t / nch, c = t - r * nch;
+        a.rowspec[(((size_t)n * nch + c) * H + y0 + r) * KP + kx] = buf[(size_t)(t * 2 + cur) * W + kx];
+    }
+}
+
+// B: grid (ceil((b+1)/KT), 3, B): KT bins per workgroup.  LDS transforms: [0,KT) the src columns, [KT,2KT) the trg
+// columns (forward), then [KT,2KT) again as the inverse inputs.
+template <int NH, int KT>
+__global__ __launch_bounds__(256) void ram_col_mix_kernel(const RamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    float2* buf = reinterpret_cast<float2*>(smem_);        // [2*KT][2][H], then the twiddle table [H]
+    const int kx0 = blockIdx.x * KT, c = blockIdx.y, n = blockIdx.z, H = a.H, KP = a.KP, b = a.b;
+    const int nk = min(KT, a.nkeep - kx0);
+    float2* s_tw = buf + 2 * KT * 2 * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) s_tw[i] = a.tw_h[i];
+    const bool have_trg = a.trg_amp == nullptr;
+    const float2* cs = a.rowspec + ((size_t)(n * 3 + c) * H) * KP + kx0;
+    const float2* ct = a.rowspec + ((size_t)((n + a.B) * 3 + c) * H) * KP + kx0;
+    for (int i = threadIdx.x; i < H * KT; i += blockDim.x) {
+        const int y = i / KT, k = i - y * KT;               // bins fastest: KT*8 contiguous bytes per y
+        const bool ok = k < nk;
+        buf[(size_t)(k * 2) * H + y] = ok ? cs[(size_t)y * KP + k] : make_float2(0.f, 0.f);
+        if (have_trg) buf[(size_t)((KT + k) * 2) * H + y] = ok ? ct[(size_t)y * KP + k] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    const int cur = fft_any<NH>(buf, have_trg ? 2 * KT : KT, a.ph, s_tw, false, threadIdx.x, blockDim.x);
+    const float lam = a.lam[n];
+    const int nwin = 2 * b + 1;
+    constexpr int MAXI = (KT * 1025 + 255) / 256;            // window items per thread (H <= 1024)
+    float2 dv[MAXI];
+    int di[MAXI];
+#pragma unroll
+    for (int m = 0; m < MAXI; ++m) {
+        const int i = threadIdx.x + m * 256;
+        di[m] = -1;
+        if (i < KT * nwin) {
+            const int k = i / nwin, ky = i - k * nwin - b;
+            const int idx = (ky + H) % H;
+            if (k < nk) {
+                const float2 Fs = buf[(size_t)(k * 2 + cur) * H + idx];
+                float At;
+                if (have_trg) {
+                    const float2 Ft = buf[(size_t)((KT + k) * 2 + cur) * H + idx];
+                    At = sqrtf(Ft.x * Ft.x + Ft.y * Ft.y);
+                } else {
+                    At = a.trg_amp[(((size_t)n * 3 + c) * H + idx) * a.W + kx0 + k];
+                }
+                const float As = sqrtf(Fs.x * Fs.x + Fs.y * Fs.y);
+                dv[m] = As > 0.f ? cscale(Fs, (1.f - lam) * (At / As - 1.f)) : make_float2((1.f - lam) * At, 0.f);
+                di[m] = k * H + idx;
+            }
+        }
+    }
+    __syncthreads();
+    float2* ib = buf + (size_t)KT * 2 * H;                  // the trg block becomes the inverse transforms
+    for (int i = threadIdx.x; i < KT * H; i += blockDim.x) ib[(size_t)(i / H) * 2 * H + (i % H)] = make_float2(0.f, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MAXI; ++m)
+        if (di[m] >= 0) ib[(size_t)(di[m] / H) * 2 * H + (di[m] % H)] = dv[m];
+    __syncthreads();
+    const int c2 = fft_any<NH>(ib, KT, a.ph, s_tw, true, threadIdx.x, blockDim.x);
+    float2* out = a.colout + ((size_t)(n * 3 + c) * H) * KP + kx0;
+    for (int i = threadIdx.x; i < H * KT; i += blockDim.x) {
+        const int y = i / KT, k = i - y * KT;
+        if (k < nk) out[(size_t)y * KP + k] = ib[(size_t)(k * 2 + c2) * H + y];
+    }
+}
+
+// amplitude of the full spectrum (extract_amp_spectrum, fundus.py:13-19): grid (W/2+1, planes); column kx and its mirror
+__global__ __launch_bounds__(256) void ram_col_amp_kernel(const RamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    float2* buf = reinterpret_cast<float2*>(smem_);        // [1][2][H], then the twiddle table [H]
+    const int kx = blockIdx.x, pl = blockIdx.y, H = a.H, W = a.W, KP = a.KP;
+    float2* s_tw = buf + 2 * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        s_tw[i] = a.tw_h[i];
+        buf[i] = a.rowspec[((size_t)pl * H + i) * KP + kx];
+    }
+    __syncthreads();
+    const int cur = fft_runtime(buf, 1, a.ph, s_tw, false, threadIdx.x, blockDim.x);
+    const bool mirror = kx > 0 && kx != W - kx;             // F[-ky][-kx] = conj F[ky][kx]
+    for (int ky = threadIdx.x; ky < H; ky += blockDim.x) {
+        const float2 F = buf[cur * H + ky];
+        const float A = sqrtf(F.x * F.x + F.y * F.y);
+        a.amp_out[((size_t)pl * H + ky) * W + kx] = A;
+        if (mirror) a.amp_out[((size_t)pl * H + (H - ky) % H) * W + W - kx] = A;
+    }
+}
+
+// C: grid (ceil(H/ROWS), B)
+template <typename T, int NW, int ROWS>
+__global__ __launch_bounds__(256) void ram_row_inv_kernel(const RamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    float2* buf = reinterpret_cast<float2*>(smem_);        // [ROWS * 2 transforms][2][W], then the twiddle table [W]
+    const int y0 = blockIdx.x * ROWS, n = blockIdx.y, W = a.W, H = a.H, nb1 = a.b + 1, KP = a.KP;
+    const int rows = min(ROWS, H - y0);
+    float2* s_tw = buf + ROWS * 2 * 2 * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) s_tw[x] = a.tw_w[x];
+    for (int i = threadIdx.x; i < rows * 2 * W; i += blockDim.x) buf[(size_t)(i / W) * 2 * W + (i % W)] = make_float2(0.f, 0.f);
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * nb1; i += blockDim.x) {
+        const int r = i / nb1, kx = i - r * nb1;
+        const size_t o = ((size_t)(n * 3) * H + y0 + r) * KP + kx, cstep = (size_t)H * KP;
+        const float2 R0 = a.colout[o], R1 = a.colout[o + cstep], R2 = a.colout[o + 2 * cstep];
+        float2* z01 = buf + (size_t)(r * 2) * 2 * W;
+        float2* z2 = buf + (size_t)(r * 2 + 1) * 2 * W;
+        z01[kx] = make_float2(R0.x - R1.y, R0.y + R1.x);                 // R0 + i R1
+        z2[kx] = R2;
+        if (kx > 0) {
+            z01[W - kx] = make_float2(R0.x + R1.y, -R0.y + R1.x);        // conj(R0) + i conj(R1)
+            z2[W - kx] = make_float2(R2.x, -R2.y);
+        }
+    }
+    __syncthreads();
+    const int cur = fft_any<NW>(buf, rows * 2, a.pw, s_tw, true, threadIdx.x, blockDim.x);
     const float inv = 1.0f / ((float)H * (float)W);
-    const float* srow = a.src + ((size_t)n * H + y) * W * 3;
-    T* oi = reinterpret_cast<T*>(a.out_img) + ((size_t)n * H + y) * W * a.cs;
-    T* of = reinterpret_cast<T*>(a.out_freq) + ((size_t)n * H + y) * W * a.cs;
-    for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) {
-        const int x = i / 3, c = i - 3 * x;
-        const float corr = (c == 0 ? r01[x].x : (c == 1 ? r01[x].y : r2[x].x)) * inv;
-        const float s = srow[i];
-        float f = s + corr;
-        f = fminf(fmaxf(f, a.clip_lo), a.clip_hi);
-        oi[x * a.cs + c] = from_f<T>(s * a.scale + a.offset);
-        of[x * a.cs + c] = from_f<T>(f * a.scale + a.offset);
+    constexpr int SLOT = 16 / (int)sizeof(T);               // elements of one 16-byte channel slot
+    for (int i = threadIdx.x; i < rows * W; i += blockDim.x) {
+        const int r = i / W, x = i - r * W;
+        const float2 v01 = buf[(size_t)((r * 2) * 2 + cur) * W + x];
+        const float corr[3] = {v01.x * inv, v01.y * inv, buf[(size_t)((r * 2 + 1) * 2 + cur) * W + x].x * inv};
+        const size_t pix = ((size_t)n * H + y0 + r) * W + x;
+        float s[3];
+        if (a.src_u8) {
+            const uint8_t* sp = reinterpret_cast<const uint8_t*>(a.src) + pix * 3;
+            s[0] = (float)sp[0]; s[1] = (float)sp[1]; s[2] = (float)sp[2];
+        } else {
+            const float* sp = reinterpret_cast<const float*>(a.src) + pix * 3;
+            s[0] = sp[0]; s[1] = sp[1]; s[2] = sp[2];
+        }
+        float oi[SLOT], of[SLOT];
+#pragma unroll
+        for (int c = 0; c < SLOT; ++c) oi[c] = of[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float f = fminf(fmaxf(s[c] + corr[c], a.clip_lo), a.clip_hi);
+            // div != 0: x / div + offset, the reference's `img /= 127.5; img -= 1.0` bit for bit (fundus.py:217-218)
+            oi[c] = a.div != 0.f ? __fdiv_rn(s[c], a.div) + a.offset : s[c] * a.scale + a.offset;
+            of[c] = a.div != 0.f ? __fdiv_rn(f, a.div) + a.offset : f * a.scale + a.offset;
+        }
+        T* pi = reinterpret_cast<T*>(a.out_img) + pix * a.cs;
+        T* pf = reinterpret_cast<T*>(a.out_freq) + pix * a.cs;
+        if (a.cs == SLOT) {                                  // one 16-byte slot per pixel: channels 3.. are written as zeros
+            *reinterpret_cast<uint4*>(pi) = Slot<T>::pack(oi);
+            *reinterpret_cast<uint4*>(pf) = Slot<T>::pack(of);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pi[c] = from_f<T>(oi[c]);
+                pf[c] = from_f<T>(of[c]);
+            }
+        }
+    }
+}
+
+// low_freq_mutate_np (fundus.py:21-39) on two amplitude arrays [C][H][W]: lerp inside the centred window
+__global__ void ram_mutate_kernel(const float* as, const float* at, float* out, int C, int H, int W, int b, float lam) {
+    const size_t total = (size_t)C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int ky = y < (H + 1) / 2 ? y : y - H, kx = x < (W + 1) / 2 ? x : x - W;   // fftfreq order
+        const bool in = ky >= -b && ky <= b && kx >= -b && kx <= b;
+        out[i] = in ? as[i] * lam + at[i] * (1.f - lam) : as[i];
     }
 }
 
@@ -229,16 +422,56 @@ bool make_plan(int N, FftPlan& p) {
     while (n % 2 == 0) { p.radix[p.nst++] = 2; n /= 2; }
     while (n % 3 == 0) { p.radix[p.nst++] = 3; n /= 3; }
     while (n % 5 == 0) { p.radix[p.nst++] = 5; n /= 5; }
-    return n == 1 && p.nst <= 12;
+    return n == 1 && p.nst <= 12 && N <= 1024;
 }
+
+int pad4(int v) { return (v + 3) / 4 * 4; }
+
+template <int NW>
+void launch_row_fwd(const RamArgs& a, int nimg, hipStream_t st) {
+    constexpr int ROWS = NW == 0 ? 1 : 2;
+    const size_t lds = (size_t)(ROWS * a.nch * 2 + 1) * a.W * sizeof(float2);
+    hipLaunchKernelGGL((ram_row_fwd_kernel<NW, ROWS>), dim3((a.H + ROWS - 1) / ROWS, nimg), dim3(256), lds, st, a);
+}
+
+template <int NH>
+int launch_col_mix(const RamArgs& a, hipStream_t st) {
+    constexpr int KT = NH == 0 ? 1 : 4;
+    const size_t lds = (size_t)(2 * KT * 2 + 1) * a.H * sizeof(float2);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ram_col_mix_kernel<NH, KT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((ram_col_mix_kernel<NH, KT>), dim3((a.nkeep + KT - 1) / KT, 3, a.B), dim3(256), lds, st, a);
+    return 0;
+}
+
+template <typename T, int NW>
+void launch_row_inv(const RamArgs& a, hipStream_t st) {
+    constexpr int ROWS = NW == 0 ? 1 : 2;
+    const size_t lds = (size_t)(ROWS * 2 * 2 + 1) * a.W * sizeof(float2);
+    hipLaunchKernelGGL((ram_row_inv_kernel<T, NW, ROWS>), dim3((a.H + ROWS - 1) / ROWS, a.B), dim3(256), lds, st, a);
+}
+
+#define RD_BY_SIDE(side, CALL)            \
+    switch (side) {                       \
+        case 256: CALL(256); break;       \
+        case 384: CALL(384); break;       \
+        case 400: CALL(400); break;       \
+        case 512: CALL(512); break;       \
+        default: CALL(0); break;          \
+    }
 
 }  // namespace
 
 extern "C" {
 
 int64_t rd_ram_workspace(int B, int H, int W, int b) {
-    // rowspec [2B][3][b+1][H] + colout [B][3][b+1][H] complex64
-    return (int64_t)3 * B * 3 * (b + 1) * H * (int64_t)sizeof(float2);
+    // rowspec [2B][3][H][KP] + colout [B][3][H][KP] complex64, KP = (b+1) padded to 4
+    return (int64_t)3 * B * 3 * H * pad4(b + 1) * (int64_t)sizeof(float2);
 }
 
 int rd_ram_mix(const rd_ram_t* p, int dtype, void* stream) {
@@ -246,22 +479,71 @@ int rd_ram_mix(const rd_ram_t* p, int dtype, void* stream) {
     RamArgs a;
     if (!make_plan(p->W, a.pw) || !make_plan(p->H, a.ph)) return -2;   // sizes must factor into 2,3,5
     if (p->b < 0 || 2 * p->b + 1 > p->H || 2 * p->b + 1 > p->W) return -3;
-    a.src = p->src; a.trg = p->trg; a.lam = p->lam;
+    if (!p->src || (!p->trg && !p->trg_amp) || !p->lam || !p->out_img || !p->out_freq || !p->workspace) return -4;
+    a.src = p->src; a.trg = p->trg; a.trg_amp = p->trg_amp; a.lam = p->lam;
     a.out_img = p->out_img; a.out_freq = p->out_freq;
+    a.B = p->B; a.H = p->H; a.W = p->W; a.b = p->b;
+    a.nkeep = p->b + 1;
+    a.KP = pad4(a.nkeep);
     a.rowspec = reinterpret_cast<float2*>(p->workspace);
-    a.colout = a.rowspec + (size_t)2 * p->B * 3 * (p->b + 1) * p->H;
+    a.colout = a.rowspec + (size_t)2 * p->B * 3 * p->H * a.KP;
     a.tw_w = reinterpret_cast<const float2*>(p->tw_w);
     a.tw_h = reinterpret_cast<const float2*>(p->tw_h);
-    a.B = p->B; a.H = p->H; a.W = p->W; a.b = p->b;
+    a.amp_out = nullptr;
+    a.nch = 3; a.planar = 0; a.src_u8 = p->src_u8 ? 1 : 0;
     a.cs = p->out_cstride > 0 ? p->out_cstride : 3;
     if (a.cs < 3) return -1;
-    a.clip_lo = p->clip_lo; a.clip_hi = p->clip_hi; a.scale = p->scale; a.offset = p->offset;
+    a.clip_lo = p->clip_lo; a.clip_hi = p->clip_hi; a.scale = p->scale; a.div = p->div; a.offset = p->offset;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lw = (size_t)5 * p->W * sizeof(float2), lh = (size_t)5 * p->H * sizeof(float2);      // + twiddle table
-    hipLaunchKernelGGL(ram_row_fwd_kernel, dim3(p->H, 2 * p->B), dim3(256), (size_t)7 * p->W * sizeof(float2), st, a);
-    hipLaunchKernelGGL(ram_col_kernel, dim3(p->b + 1, 3, p->B), dim3(256), lh, st, a);
-    if (dtype == RD_BF16) hipLaunchKernelGGL(ram_row_inv_kernel<bf16_t>, dim3(p->H, p->B), dim3(256), lw, st, a);
-    else hipLaunchKernelGGL(ram_row_inv_kernel<float>, dim3(p->H, p->B), dim3(256), lw, st, a);
+    const int nimg = p->trg_amp ? p->B : 2 * p->B;          // the partner's spectrum is only needed when it is given as an image
+#define RD_ROWF(S_) launch_row_fwd<S_>(a, nimg, st)
+    RD_BY_SIDE(p->W, RD_ROWF)
+#undef RD_ROWF
+    int e = 0;
+#define RD_COLM(S_) e = launch_col_mix<S_>(a, st)
+    RD_BY_SIDE(p->H, RD_COLM)
+#undef RD_COLM
+    if (e) return e;
+    if (dtype == RD_BF16) {
+#define RD_ROWI(S_) launch_row_inv<bf16_t, S_>(a, st)
+        RD_BY_SIDE(p->W, RD_ROWI)
+#undef RD_ROWI
+    } else {
+#define RD_ROWI(S_) launch_row_inv<float, S_>(a, st)
+        RD_BY_SIDE(p->W, RD_ROWI)
+#undef RD_ROWI
+    }
+    return (int)hipGetLastError();
+}
+
+int64_t rd_ram_amp_workspace(int C, int H, int W) { return (int64_t)C * H * pad4(W / 2 + 1) * (int64_t)sizeof(float2); }
+
+int rd_ram_amp(const float* img_chw, float* amp_chw, int C, int H, int W, void* workspace, const float* tw_w, const float* tw_h,
+               void* stream) {
+    if (!img_chw || !amp_chw || !workspace || C < 1) return -1;
+    RamArgs a = {};
+    if (!make_plan(W, a.pw) || !make_plan(H, a.ph)) return -2;
+    a.src = img_chw;
+    a.B = C; a.H = H; a.W = W;
+    a.nkeep = W / 2 + 1;
+    a.KP = pad4(a.nkeep);
+    a.rowspec = reinterpret_cast<float2*>(workspace);
+    a.tw_w = reinterpret_cast<const float2*>(tw_w);
+    a.tw_h = reinterpret_cast<const float2*>(tw_h);
+    a.amp_out = amp_chw;
+    a.nch = 1; a.planar = 1;
+    hipStream_t st = (hipStream_t)stream;
+    launch_row_fwd<0>(a, C, st);
+    hipLaunchKernelGGL(ram_col_amp_kernel, dim3(a.nkeep, C), dim3(256), (size_t)3 * H * sizeof(float2), st, a);
+    return (int)hipGetLastError();
+}
+
+int rd_ram_mutate(const float* amp_src, const float* amp_trg, float* out, int C, int H, int W, int b, float lam, void* stream) {
+    if (!amp_src || !amp_trg || !out || b < 0 || 2 * b + 1 > H || 2 * b + 1 > W) return -1;
+    const size_t total = (size_t)C * H * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ram_mutate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, amp_src, amp_trg, out, C, H, W, b, lam);
     return (int)hipGetLastError();
 }
 

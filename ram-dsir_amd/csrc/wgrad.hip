@@ -688,7 +688,8 @@ __global__ __launch_bounds__(256, 3) void wgrad_c16_tr_kernel(const rd_wgrad_t p
         x0 = (trem % tiles_x) * TW;
     };
     const int sl = tid & 1;                                 // this thread's channel slot (of 2) in both tiles
-    const int ca_abs = sl * S, cz_abs = sl * S;
+    // grid (splits, Cout blocks of 16, Cin blocks of 16): this workgroup's 16 x 16 block of every tap
+    const int ca_abs = blockIdx.z * 16 + sl * S, cz_abs = blockIdx.y * 16 + sl * S;
     const int sia = (p.na == 1 || ca_abs < p.a[0].C) ? 0 : 1;
     const rd_src_t sda = select_src(p.a, sia);
     const int ca = ca_abs - (sia ? p.a[0].C : 0);
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_c16_tr_kernel(const rd_wgrad_t p
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[((size_t)tap * CoutPadW + 4 * kg + r) * CinPadW + li] = acc[tap][r];
+            for (int r = 0; r < 4; ++r) out[((size_t)tap * CoutPadW + blockIdx.y * 16 + 4 * kg + r) * CinPadW + blockIdx.z * 16 + li] = acc[tap][r];
     }
 }
 
@@ -1029,6 +1030,9 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void wgrad_c16_kernel(const rd_wgr
     }
 }
 
+// Split reduction.  (A float4-coalesced, chunked variant with atomics into a zeroed dW measured 320 us/step SLOWER over
+// the 40 launches -- the extra memset launch and fewer blocks in flight cost more than the strided reads, which are L2 hits
+// on partials written microseconds earlier: profiles/README.md round 2.)
 // block = 32 outputs x 8 split lanes: each thread sums every 8th split, LDS folds the 8 lanes in a fixed order
 template <int OB>                                         // outputs per block; 256/OB threads share one output's splits
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dW, int nsplit, int taps, int Cout,
@@ -1094,19 +1098,18 @@ template <typename T>
 WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     WgradGeom g;
     g.c16 = false;
-    // 16-channel blocks only where the kernel stays spill-free at 3 workgroups/CU (one block per workgroup)
-    if (sizeof(T) == 2 && p.Cout <= 16 && p.Cin <= 16) {
+    // 16 x 16 blocks (v_mfma_f32_16x16x32_bf16, 3 workgroups/CU): the 16-channel layers, and -- a grid of such blocks,
+    // transpose-read kernel only -- the layers with <= 16 output channels on 32 input channels (dec.out1 32->2,
+    // dec.convu1.conv2 32->16, rec.convu1.conv1 32->16), which would leave half of every 32 x 32 block's rows empty
+    if (sizeof(T) == 2 && p.Cout <= 16 && (p.Cin <= 16 || (p.Cin <= 32 && wgrad_pf_ok(p) && rd_switch("RD_WG_TR_OFF", 0) == 0 && rd_switch("RD_WG_C16_GRID", 1) != 0))) {
         g.c16 = true;
-        g.MB = p.Cout > 16 ? 2 : 1;
-        g.NB = p.Cin > 16 ? 2 : 1;
-        g.KS = 4 / (g.MB * g.NB);
-        g.CoutPadW = g.MB * 16;
-        g.CinPadW = g.NB * 16;
+        g.MB = g.NB = 1;                                   // blocks per WORKGROUP
+        g.KS = 4;
+        g.CoutPadW = 16;
+        g.CinPadW = (p.Cin + 15) / 16 * 16;
         g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
-        // exactly the resident set (no second, partially filled round): 4 workgroups/CU for the transpose-read kernel
-        // (plain sources), 3/CU for the generic one
-        static const bool tr_off = getenv("RD_WG_TR_OFF") != nullptr;
-        int gx = ((wgrad_pf_ok(p) && !tr_off) ? 3 : 3) * rd_num_cus();
+        // exactly the resident set (no second, partially filled round) at 3 workgroups/CU
+        int gx = 3 * rd_num_cus() / (g.CinPadW / 16);
         if (gx > g.total_tiles) gx = g.total_tiles;
         g.gx = gx < 1 ? 1 : gx;
         g.nsplit = g.gx;
@@ -1158,7 +1161,7 @@ int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * TAPS * 4 * 64 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
     dim3 grid(g.gx, g.CoutPadW / (MB * 16), g.CinPadW / (NB * 16));
-    static const bool tr_off = getenv("RD_WG_TR_OFF") != nullptr;
+    static const bool tr_off = rd_switch("RD_WG_TR_OFF", 0) != 0;
     if (wgrad_pf_ok(p) && !tr_off) {
         size_t l2 = (size_t)((TH + 2 * HALO) * (TW + 2 * HALO) + 4) * 48 + (size_t)TH * TW * 48;
         const size_t l2red = (size_t)3 * TAPS * 4 * 64 * sizeof(float);
@@ -1216,7 +1219,7 @@ int launch_wgrad_t_ts(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    static const bool tr_off = getenv("RD_WG_TR_OFF") != nullptr;
+    static const bool tr_off = rd_switch("RD_WG_TR_OFF", 0) != 0;
     // the transpose-read kernel needs whole 16-byte channel slots in every source (its generic fill covers pooled
     // / interpolated ones); ragged channel counts stay on the transposing-store kernel below
     if (!tr_off && wgrad_slots_ok(p)) return launch_wgrad_tr<TAPS, MB, NB>(p, g, st);
@@ -1259,8 +1262,7 @@ int dispatch_wgrad(const rd_wgrad_t& p, hipStream_t st) {
     const int total = p.taps * p.Cout * p.Cin;
     // many splits of a small filter (the 16/32-channel layers): 8 outputs x 32 split lanes per block
     if (g.nsplit >= 128 && total <= 16384) {
-        const int blocks = (total + 7) / 8;
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(blocks), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((total + 7) / 8), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
                            g.CoutPadW, g.CinPadW, p.beta);
     } else {
         int blocks = (total + 31) / 32;

@@ -4,7 +4,7 @@ Same constructors and on-disk format (``<base>/DomainK_{train,test}.list`` with 
 partner lists ``<base>/DomainK/train.list``, fundus.py:143,206).  One deliberate change: the
 reference runs the RAM FFTs on the CPU inside ``__getitem__`` in DataLoader workers; workers must not touch
 the GPU, so here ``Fundus_Multi.__getitem__`` returns the PIECES RAM needs --
-``(img_hwc float32 0..255, partner_hwc float32 0..255, lam, mask)`` with the reference's sampling semantics
+``(img_hwc uint8, partner_hwc uint8, lam, mask)`` (the decoded pixels; the GPU kernel reads 1 byte per value) with the reference's sampling semantics
 (partner domain != own domain if is_out_domain, never the test domain; partner resized to 256x256 BILINEAR;
 lam = random.randint(1,10)/10) -- and the FFTs run on the GPU for the whole batch (ramdsir.ram / the fused step).
 ``ram_collate`` turns a list of such samples into what the reference's loader yields: (img, img_freq, mask).
@@ -23,40 +23,25 @@ from ramdsir import ram as _ram
 DOMAINS = ['Domain1', 'Domain2', 'Domain3', 'Domain4']
 
 
-class _AmpHandle:
-    """What extract_amp_spectrum returns here: the target image itself (the GPU kernel needs only the window
-    bins of its spectrum and computes them on the fly)."""
-
-    def __init__(self, img_chw):
-        self.img_chw = np.asarray(img_chw, dtype=np.float32)
-
-
 def extract_amp_spectrum(img_np):
-    """fundus.py:13-19.  Returns a handle consumed by source_to_target_freq (the full amplitude array is never
-    materialised on the GPU path)."""
-    return _AmpHandle(img_np)
+    """fundus.py:13-19: amplitude of the 2-D FFT over the last two axes of a CHW array; numpy float32 array, computed by
+    the HIP kernels (rd_ram_amp).  Main process only: DataLoader workers must not touch the GPU (the training path
+    mixes whole batches with rd_ram_mix instead)."""
+    return _ram.extract_amp_spectrum_gpu(np.asarray(img_np, dtype=np.float32)).cpu().numpy()
 
 
 def low_freq_mutate_np(amp_src, amp_trg, L=0.1):
-    raise NotImplementedError('the amplitude window lerp is fused into the GPU RAM kernel (rd_ram_mix); '
-                              'use source_to_target_freq')
+    """fundus.py:21-39; like the reference the ratio is drawn HERE: random.randint(1, 10) / 10."""
+    ratio = random.randint(1, 10) / 10
+    return _ram.low_freq_mutate_gpu(amp_src, amp_trg, ratio, L).cpu().numpy()
 
 
 def source_to_target_freq(src_img, amp_trg, L=0.1, lam=None):
-    """fundus.py:41-61 on the GPU for one HWC image; draws the ratio like the reference when lam is None."""
+    """fundus.py:41-61 for one HWC image and the partner's amplitude spectrum (CHW array from extract_amp_spectrum); the
+    ratio is drawn like the reference does inside low_freq_mutate_np unless `lam` is given.  HWC numpy float32."""
     if lam is None:
         lam = random.randint(1, 10) / 10
-    dev = torch.device('cuda', torch.cuda.current_device())
-    src = torch.from_numpy(np.asarray(src_img, dtype=np.float32))[None].to(dev)
-    trg = torch.from_numpy(amp_trg.img_chw.transpose(1, 2, 0).copy())[None].to(dev)
-    H, W = src.shape[1:3]
-    m = _ram.RamMixer(1, H, W, torch.float32, dev, 'fundus', ratio=L)
-    m.p.clip_lo, m.p.clip_hi, m.p.scale, m.p.offset = -3.0e38, 3.0e38, 1.0, 0.0     # the trio itself does not clip
-    oi = torch.empty(1, H, W, 3, device=dev)
-    of = torch.empty(1, H, W, 3, device=dev)
-    m.bind(src, trg, torch.tensor([lam], dtype=torch.float32, device=dev), oi, of)
-    m.run()
-    return of[0].cpu().numpy()
+    return _ram.source_to_target_freq_gpu(np.asarray(src_img, dtype=np.float32), amp_trg, lam, L).cpu().numpy()
 
 
 def _read_list(path):
@@ -117,7 +102,7 @@ class Fundus_Multi(Dataset):
             self._partner_lists[other] = _read_list(os.path.join(self.base_dir, other, 'train.list'))
         other_id = np.random.choice(self._partner_lists[other]).split(' ')[0]          # fundus.py:208
         img = Image.open(os.path.join(self.base_dir, other, other_id)).resize((256, 256), Image.BILINEAR)
-        return np.array(img).astype(np.float32)
+        return np.array(img)                                              # uint8 HWC (the reference converts to float32: same values)
 
     def __getitem__(self, index):
         id = self.id_path[index]
@@ -127,13 +112,13 @@ class Fundus_Multi(Dataset):
         sample = {'img': img, 'mask': mask}
         if self.transform:
             sample = self.transform(sample)
-        img = np.array(sample['img']).astype(np.float32)                 # HWC, 0..255
+        img = np.array(sample['img'])                                     # HWC uint8, 0..255: 1 byte per value to the GPU
         mask = torch.from_numpy(fundus_mask(np.array(sample['mask']))).float()
         if not self.is_freq:
-            return torch.from_numpy(img.transpose(2, 0, 1) / 127.5 - 1.0).float(), mask
+            return torch.from_numpy(img.astype(np.float32).transpose(2, 0, 1) / 127.5 - 1.0).float(), mask
         other = self._partner(cur_domain_name)
         if other.shape != img.shape:                                      # reference assumes 256x256 crops (fundus.py:209)
-            other = np.array(Image.fromarray(other.astype(np.uint8)).resize((img.shape[1], img.shape[0]), Image.BILINEAR)).astype(np.float32)
+            other = np.array(Image.fromarray(other).resize((img.shape[1], img.shape[0]), Image.BILINEAR))
         lam = random.randint(1, 10) / 10                                  # fundus.py:35
         return torch.from_numpy(img), torch.from_numpy(other), torch.tensor(lam, dtype=torch.float32), mask
 

@@ -8,6 +8,8 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+from dataset.fundus import extract_amp_spectrum, low_freq_mutate_np, source_to_target_freq     # noqa: F401  (prostate.py:10-62 is the same trio)
+
 DOMAINS = ['Domain1', 'Domain2', 'Domain3', 'Domain4', 'Domain5', 'Domain6']
 
 

@@ -1,6 +1,8 @@
 """Drop-in for the reference's code/networks/dsbn.py: DomainSpecificBatchNorm2d keeps one BatchNorm2d per
-domain under ``bns`` (same state_dict keys ``bns.{d}.*``).  Inside Rec_Decoder the normalisation runs fused
-in the HIP conv kernels; called on its own it raises like any other fused holder would mislead."""
+domain under ``bns`` (same state_dict keys ``bns.{d}.*``).  Inside Rec_Decoder / ConvU_Rec the normalisation runs
+fused in the HIP conv kernels (one statistics group per domain); called on its own, ``forward(x, domain_label)``
+normalises with ``bns[domain_label[0]]`` on the standalone HIP BatchNorm and returns ``(y, domain_label)`` like
+dsbn.py:24-27."""
 from torch import nn
 
 from ramdsir.modules import FusedBatchNorm2d
@@ -27,8 +29,8 @@ class _DomainSpecificBatchNorm(nn.Module):
 
     def forward(self, x, domain_label):
         self._check_input_dim(x)                       # dsbn.py:25: ValueError on non-4D input
-        raise NotImplementedError('DomainSpecificBatchNorm2d is executed inside Rec_Decoder\'s fused HIP graph '
-                                  '(domain = domain_label[0], dsbn.py:26)')
+        bn = self.bns[domain_label[0]]                 # dsbn.py:26: the first label picks the BatchNorm for the whole batch
+        return bn(x), domain_label
 
 
 class DomainSpecificBatchNorm2d(_DomainSpecificBatchNorm):

@@ -34,8 +34,28 @@ def normalization(planes, norm='gn', num_domains=None):
     return m
 
 
-class ConvD(nn.Module):
-    """Parameter layout of unet.py:32-50 (conv1,bn1,conv2,bn2,conv3,bn3)."""
+def _plan_for(mod, key, N, training, build_graph, device):
+    """Acquire (or build) the launch plan of a module called on its own."""
+    def build():
+        pl = E.Plan(mod._bank, M.storage_dtype(), N, [0, N], slope=mod._slope, training=training)
+        build_graph(pl)
+        pl.build(mod._wpack)
+        pl.ws = E.workspace(pl.ws_bytes // 4, device)
+        pl.bind_workspace(pl.ws)
+        return pl
+    return mod._acquire_plan(key + (training, M.storage_dtype()), build)
+
+
+def _raw_input(pl, x, name):
+    a = E.Act(pl, x.shape[0], x.shape[2], x.shape[3], x.shape[1], name=name)
+    a.needs_grad = True
+    return a
+
+
+class ConvD(M.FusedModule):
+    """unet.py:32-72: [MaxPool2d(2)] conv1 bn1 / conv2 bn2 act / conv3 bn3 act.  Inside Encoder the five blocks run as one
+    launch list; called on its own the block builds its own (same kernels, the pool fused into conv1's read)."""
+    _mname = 'convd'
 
     def __init__(self, inplanes, planes, norm='bn', first=False, activation='relu'):
         super(ConvD, self).__init__()
@@ -46,10 +66,27 @@ class ConvD(nn.Module):
         self.bn2 = normalization(planes, norm)
         self.conv3 = M.FusedConv2d(planes, planes, 3, 1, 1, bias=True)
         self.bn3 = normalization(planes, norm)
+        self._planes = planes
+        self._finish_init(E.convd_specs(inplanes, planes), activation, init=False)
+
+    def forward(self, x):
+        _check_input(x, 'ConvD')
+        N, Cc, H, W = x.shape
+        if not self.first and (H % 2 or W % 2):
+            raise ValueError('ConvD: H and W must be even for the 2x2 max-pool, got %dx%d' % (H, W))
+        self._ensure_bound(x.device)
+
+        def graph(pl):
+            pl.x_in = _raw_input(pl, x, 'input')
+            pl.out = E.build_convd(pl, pl.x_in, L.SRC_RAW if self.first else L.SRC_POOL, self._planes, '', self._mname)
+            pl.out.g_written = True
+        pl = _plan_for(self, (N, Cc, H, W), N, self._bn_training(), graph, x.device)
+        return M.run_fused(self, pl, [pl.x_in], [pl.out], [x])[0]
 
 
-class ConvU(nn.Module):
-    """unet.py:75-94."""
+class ConvU(M.FusedModule):
+    """unet.py:75-117: [conv1 bn1 act] up2 conv2(1x1) bn2 act cat[prev, .] conv3 bn3 act."""
+    _mname = 'convu'
 
     def __init__(self, planes, norm='bn', first=False, activation='relu'):
         super(ConvU, self).__init__()
@@ -61,10 +98,26 @@ class ConvU(nn.Module):
         self.bn2 = normalization(planes // 2, norm)
         self.conv3 = M.FusedConv2d(planes, planes, 3, 1, 1, bias=True)
         self.bn3 = normalization(planes, norm)
+        self._planes = planes
+        self._finish_init(E.convu_specs(planes, first), activation, init=False)
+
+    def forward(self, x, prev):
+        _check_input(x, 'ConvU')
+        _check_input(prev, 'ConvU')
+        N = x.shape[0]
+        self._ensure_bound(x.device)
+
+        def graph(pl):
+            pl.x_in, pl.prev_in = _raw_input(pl, x, 'x'), _raw_input(pl, prev, 'prev')
+            pl.out = E.build_convu(pl, pl.x_in, pl.prev_in, self._planes, self.first, '', self._mname)
+            pl.out.g_written = True
+        pl = _plan_for(self, (tuple(x.shape), tuple(prev.shape)), N, self._bn_training(), graph, x.device)
+        return M.run_fused(self, pl, [pl.x_in, pl.prev_in], [pl.out], [x, prev])[0]
 
 
-class ConvU_Rec(nn.Module):
-    """unet.py:120-137."""
+class ConvU_Rec(M.FusedModule):
+    """unet.py:120-165: conv1 norm act up2 conv2(1x1) norm act conv3 norm act; norm='dsbn' picks bns[domain_label[0]]."""
+    _mname = 'convu_rec'
 
     def __init__(self, planes, norm='bn', activation='relu', num_domains=None):
         super(ConvU_Rec, self).__init__()
@@ -74,6 +127,23 @@ class ConvU_Rec(nn.Module):
         self.bn2 = normalization(planes // 2, norm, num_domains)
         self.conv3 = M.FusedConv2d(planes // 2, planes // 2, 3, 1, 1, bias=True)
         self.bn3 = normalization(planes // 2, norm, num_domains)
+        self._planes, self._dsbn = planes, norm == 'dsbn'
+        self._finish_init(E.convu_rec_specs(planes, num_domains if self._dsbn else None), activation, init=False)
+
+    def forward(self, x, domain_label=None):
+        _check_input(x, 'ConvU_Rec')
+        if self._dsbn and domain_label is None:
+            raise TypeError('ConvU_Rec(norm="dsbn") needs domain_label (unet.py:142-146)')
+        d = int(domain_label[0]) if domain_label is not None else None          # dsbn.py:26
+        N = x.shape[0]
+        self._ensure_bound(x.device)
+
+        def graph(pl):
+            pl.x_in = _raw_input(pl, x, 'x')
+            pl.out = E.build_convu_rec(pl, pl.x_in, L.SRC_RAW, 0, -1, self._planes, [d] if self._dsbn else None, '', self._mname)
+            pl.out.g_written = True
+        pl = _plan_for(self, (tuple(x.shape), d), N, self._bn_training(), graph, x.device)
+        return M.run_fused(self, pl, [pl.x_in], [pl.out], [x])[0]
 
 
 def _check_input(x, name):

@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libramdsir_hip.so')
+# RAMDSIR_DEBUG_LIB=1: the debug build (`make debug`), whose dispatch honours RD_* environment overrides (csrc/common.h
+# rd_switch); the product library has none
+LIB_PATH = os.path.join(_HERE, 'libramdsir_hip_dbg.so' if os.environ.get('RAMDSIR_DEBUG_LIB') == '1' else 'libramdsir_hip.so')
 
 RD_F32, RD_BF16 = 0, 1
 MAXG = 8
@@ -39,7 +41,7 @@ class RdWgrad(C.Structure):
 
 
 class RdBnFwd(C.Structure):
-    _fields_ = [('stats', fp), ('scale', fp), ('shift', fp), ('mean', fp), ('invstd', fp), ('gamma', fp * MAXG),
+    _fields_ = [('stats', fp), ('conv_bias', fp), ('scale', fp), ('shift', fp), ('mean', fp), ('invstd', fp), ('gamma', fp * MAXG),
                 ('beta', fp * MAXG), ('running_mean', fp * MAXG), ('running_var', fp * MAXG),
                 ('num_batches_tracked', vp * MAXG), ('count', f32 * MAXG), ('C', i32), ('G', i32), ('eps', f32),
                 ('momentum', f32), ('training', i32), ('pad_', i32)]
@@ -65,7 +67,8 @@ class RdAdam(C.Structure):
 class RdRam(C.Structure):
     _fields_ = [('src', fp), ('trg', fp), ('lam', fp), ('out_img', vp), ('out_freq', vp), ('workspace', vp),
                 ('tw_w', fp), ('tw_h', fp), ('B', i32), ('H', i32), ('W', i32), ('C', i32), ('b', i32),
-                ('clip_lo', f32), ('clip_hi', f32), ('scale', f32), ('offset', f32), ('out_cstride', i32)]
+                ('clip_lo', f32), ('clip_hi', f32), ('scale', f32), ('offset', f32), ('out_cstride', i32), ('src_u8', i32),
+                ('div', f32), ('pad_', i32), ('trg_amp', fp)]
 
 
 class RdPackEntry(C.Structure):
@@ -76,6 +79,9 @@ class RdPackEntry(C.Structure):
 _SIGS = {
     'rd_ram_workspace': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'rd_ram_mix': (C.c_int, [C.POINTER(RdRam), C.c_int, vp]),
+    'rd_ram_amp_workspace': (i64, [C.c_int, C.c_int, C.c_int]),
+    'rd_ram_amp': (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp, fp, fp, vp]),
+    'rd_ram_mutate': (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]),
     'rd_pack_weights_batched': (C.c_int, [fp, vp, vp, C.c_int, i64, C.c_int, vp]),
     'rd_conv': (C.c_int, [C.POINTER(RdConv), C.c_int, vp]),
     'rd_wgrad_workspace': (i64, [C.POINTER(RdWgrad), C.c_int]),
@@ -86,6 +92,9 @@ _SIGS = {
     'rd_bn_finalize_bwd': (C.c_int, [C.POINTER(RdBnBwd), vp]),
     'rd_bn_apply': (C.c_int, [vp, vp, vp, fp, fp, fp, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
     'rd_up_stats': (C.c_int, [vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
+    'rd_bn_stats': (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
+    'rd_pool_fwd': (C.c_int, [vp, fp, fp, f32, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
+    'rd_pool_bwd': (C.c_int, [vp, vp, fp, fp, f32, C.c_int, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
     'rd_up_bwd': (C.c_int, [vp, vp, vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32),
                             C.c_int, vp]),
     'rd_nchw_to_nhwc': (C.c_int, [fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -21,6 +21,7 @@ import os
 import torch
 
 from . import _lib as L
+from . import tuning as T
 
 EPS = 1e-5
 MOMENTUM = 0.1
@@ -56,14 +57,47 @@ def _norm_spec(out, name, c, num_domains):
             _bn_spec(out, '%s.bns.%d' % (name, d), c)
 
 
+def convd_specs(cin, cout, prefix='', out=None):
+    """networks.unet.ConvD (unet.py:32-50): conv1,bn1,conv2,bn2,conv3,bn3.  prefix '' = the block on its own."""
+    out = [] if out is None else out
+    for j, ci in ((1, cin), (2, cout), (3, cout)):
+        _conv_spec(out, '%sconv%d' % (prefix, j), ci, cout, 3)
+        _bn_spec(out, '%sbn%d' % (prefix, j), cout)
+    return out
+
+
+def convu_specs(planes, first, prefix='', out=None):
+    """networks.unet.ConvU (unet.py:75-94)."""
+    out = [] if out is None else out
+    if not first:
+        _conv_spec(out, prefix + 'conv1', 2 * planes, planes, 3)
+        _bn_spec(out, prefix + 'bn1', planes)
+    _conv_spec(out, prefix + 'conv2', planes, planes // 2, 1)
+    _bn_spec(out, prefix + 'bn2', planes // 2)
+    _conv_spec(out, prefix + 'conv3', planes, planes, 3)
+    _bn_spec(out, prefix + 'bn3', planes)
+    return out
+
+
+def convu_rec_specs(planes, num_domains, prefix='', out=None):
+    """networks.unet.ConvU_Rec (unet.py:120-137); DSBN when num_domains is given."""
+    out = [] if out is None else out
+    h = planes // 2
+    _conv_spec(out, prefix + 'conv1', planes, h, 3)
+    _norm_spec(out, prefix + 'bn1', h, num_domains)
+    _conv_spec(out, prefix + 'conv2', h, h, 1)
+    _norm_spec(out, prefix + 'bn2', h, num_domains)
+    _conv_spec(out, prefix + 'conv3', h, h, 3)
+    _norm_spec(out, prefix + 'bn3', h, num_domains)
+    return out
+
+
 def encoder_specs(c=3, n=16):
     """state_dict layout of networks.unet.Encoder (unet.py:248-255): 105 entries at n=16."""
     out = []
     ch = [c, n, 2 * n, 4 * n, 8 * n, 16 * n]
     for l in range(1, 6):
-        for j, ci in ((1, ch[l - 1]), (2, ch[l]), (3, ch[l])):
-            _conv_spec(out, 'convd%d.conv%d' % (l, j), ci, ch[l], 3)
-            _bn_spec(out, 'convd%d.bn%d' % (l, j), ch[l])
+        convd_specs(ch[l - 1], ch[l], 'convd%d.' % l, out)
     return out
 
 
@@ -71,14 +105,7 @@ def decoder_specs(n=16, num_classes=2):
     """networks.unet.Decoder (unet.py:273-281)."""
     out = []
     for l, planes, first in ((4, 16 * n, True), (3, 8 * n, False), (2, 4 * n, False), (1, 2 * n, False)):
-        p = 'convu%d' % l
-        if not first:
-            _conv_spec(out, p + '.conv1', 2 * planes, planes, 3)
-            _bn_spec(out, p + '.bn1', planes)
-        _conv_spec(out, p + '.conv2', planes, planes // 2, 1)
-        _bn_spec(out, p + '.bn2', planes // 2)
-        _conv_spec(out, p + '.conv3', planes, planes, 3)
-        _bn_spec(out, p + '.bn3', planes)
+        convu_specs(planes, first, 'convu%d.' % l, out)
     _conv_spec(out, 'out1', 2 * n, num_classes, 3)
     return out
 
@@ -87,13 +114,7 @@ def rec_decoder_specs(n=16, num_classes=3, num_domains=None):
     """networks.unet.Rec_Decoder (unet.py:299-307); norm='dsbn' when num_domains is given."""
     out = []
     for l, planes in ((4, 16 * n), (3, 8 * n), (2, 4 * n), (1, 2 * n)):
-        p, h = 'convu%d' % l, planes // 2
-        _conv_spec(out, p + '.conv1', planes, h, 3)
-        _norm_spec(out, p + '.bn1', h, num_domains)
-        _conv_spec(out, p + '.conv2', h, h, 1)
-        _norm_spec(out, p + '.bn2', h, num_domains)
-        _conv_spec(out, p + '.conv3', h, h, 3)
-        _norm_spec(out, p + '.bn3', h, num_domains)
+        convu_rec_specs(planes, num_domains, 'convu%d.' % l, out)
     _conv_spec(out, 'out1', n, num_classes, 3)
     return out
 
@@ -223,6 +244,12 @@ class ConvNode:
         self.has_bias_grad = has_bias_grad          # out1 convs: live bias (no BN behind it)
 
 
+class PoolNode:
+    """nn.MaxPool2d(2) in front of a ConvD (unet.py:56), materialised: `out` = maxpool2(act(bn(src))) stored once."""
+    def __init__(self, mname, name, src, out):
+        self.mname, self.name, self.src, self.out = mname, name, src, out
+
+
 class Plan:
     """Buffers + launch lists for one batch geometry (N images in G groups at H x W)."""
 
@@ -237,6 +264,11 @@ class Plan:
         # reads y as a plain BN+ReLU source instead of interpolating t four-taps-per-pixel in every loader:
         # +1 write / +3 reads of y against ~40% less time in those three kernels ('upsample')
         self.materialize_up = False
+        # True: the 2x2 max-pool in front of ConvD levels 2-5 is stored once (rd_pool_fwd, 1/4 of the pixels) and its
+        # gradient scattered by rd_pool_bwd, so the conv behind it runs the plain-source kernels in forward, dgrad and
+        # wgrad (level 2 at 400x400, 16 images: 576 -> ~230 us for the three launches; profiles/README.md round 2).
+        # False: RD_SRC_POOL / RD_DST_POOL fused into the conv's tile loader / gradient epilogue.
+        self.materialize_pool = T.options()['pool_mat']
         self.materialize_min_c = None   # channels from which BN+ReLU outputs are stored once (rd_bn_apply)
         self.materialize_dz_min_c = None  # ... and from which the BN-backward gradients dz are
         self._unit = {}
@@ -264,7 +296,8 @@ class Plan:
 
     def finalize_stats(self):
         total = sum(self._stat_chunks)
-        self.stat_arena = torch.zeros(max(total, 1), dtype=torch.float32, device=self.device)
+        # fp64: the slot atomics and everything the finalize kernels do across workgroups (include/ramdsir.h, RD_STAT_SLOTS)
+        self.stat_arena = torch.zeros(max(total, 1), dtype=torch.float64, device=self.device)
         offs, o = [], 0
         for n in self._stat_chunks:
             offs.append(o)
@@ -272,7 +305,7 @@ class Plan:
         self._stat_off = offs
 
     def stat_ptr(self, handle):
-        return self.stat_arena.data_ptr() + 4 * self._stat_off[handle[1]]
+        return self.stat_arena.data_ptr() + 8 * self._stat_off[handle[1]]
 
     def stat_view(self, handle, G, Cc):
         o = self._stat_off[handle[1]]
@@ -281,6 +314,17 @@ class Plan:
     # ---- graph construction
     def conv(self, mname, name, inputs, Cout, taps, norm=None, act=False, up_out=False, H=None, W=None, N=None):
         """inputs: list of (Act, mode, n_off, g_fixed).  Output dims: H x W of the conv itself."""
+        if self.materialize_pool:
+            pooled = []
+            for (a, mode, n_off, g_fixed) in inputs:
+                if mode == L.SRC_POOL and a.C % self.slot_channels() == 0:
+                    xp = Act(self, a.N, a.H // 2, a.W // 2, a.C, name='%s.%s.pool' % (mname, name))
+                    xp.needs_grad = True
+                    self.nodes.append(PoolNode(mname, name + '.pool', a, xp))
+                    pooled.append((xp, L.SRC_RAW, n_off, g_fixed))
+                else:
+                    pooled.append((a, mode, n_off, g_fixed))
+            inputs = pooled
         Cin = sum(a.C for a, _, _, _ in inputs)
         gcs = self.slot_channels() if (self.pad_narrow and norm is None and Cout < self.slot_channels()) else None
         out = Act(self, N if N is not None else self.N, H, W, Cout, norm=norm, act=act, up=up_out, name='%s.%s' % (mname, name),
@@ -311,6 +355,10 @@ class Plan:
                 g_fixed = 0
             else:
                 mode = L.SRC_RAW
+        elif a.norm is None and mode == L.SRC_POOL:
+            # 2x2 max-pool of a tensor that has no pending BatchNorm (ConvD called on its own): identity coefficients
+            one, zero = self.unit_coef(a.C)
+            s.ptr, s.scale, s.shift, slope, g_fixed = a.buf.data_ptr(), one.data_ptr(), zero.data_ptr(), 1.0, 0
         else:
             if mode == L.SRC_UP and a.y_buf is not None:
                 s.ptr, mode = a.y_buf.data_ptr(), L.SRC_AFFACT
@@ -347,6 +395,13 @@ class Plan:
             H, W, N = o.H, o.W, o.N
             if node.mname not in self.fwd_split:
                 self.fwd_split[node.mname] = len(self.fwd)
+            if isinstance(node, PoolNode):
+                a = node.src
+                has_bn = a.norm is not None
+                self.fwd.append((lib.rd_pool_fwd, (a.buf.data_ptr(), a.scale.data_ptr() if has_bn else None, a.shift.data_ptr() if has_bn else None,
+                                                   self.slope if (has_bn and a.act) else 1.0, o.buf.data_ptr(), N, H, W, o.C, self.G, self.gs_arr, dt),
+                                 dict(kernel='pool', what='fwd', layer='%s.%s' % (node.mname, node.name))))
+                continue
             # ---------------- forward conv
             p = L.RdConv()
             for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
@@ -367,6 +422,8 @@ class Plan:
                                                         N, H, W, o.C, self.G, self.gs_arr, dt)))
                 b = L.RdBnFwd()
                 b.stats = o.plan.stat_ptr(o.stats)
+                # the conv epilogues sum the result WITHOUT its bias; rd_up_stats sums y = up2(t) itself
+                b.conv_bias = None if o.up else self.bank.p(node.mname, node.name + '.bias').data_ptr()
                 b.scale, b.shift, b.mean, b.invstd = o.scale.data_ptr(), o.shift.data_ptr(), o.mean.data_ptr(), o.invstd.data_ptr()
                 hw = (4 if o.up else 1) * H * W
                 for g in range(self.G):
@@ -395,6 +452,17 @@ class Plan:
             self.bwd_node_start[(node.mname, node.name)] = len(self.bwd)
             o = node.out
             H, W, N = o.H, o.W, o.N
+            if isinstance(node, PoolNode):
+                a = node.src
+                has_bn = a.norm is not None
+                if has_bn or getattr(a, 'needs_grad', False):
+                    self.bwd.append((lib.rd_pool_bwd, (o.grad_buf().data_ptr(), a.buf.data_ptr(), a.scale.data_ptr() if has_bn else None,
+                                                       a.shift.data_ptr() if has_bn else None, self.slope if (has_bn and a.act) else 1.0,
+                                                       1 if (has_bn and a.act) else 0, a.grad_buf().data_ptr(), 1 if a.g_written else 0,
+                                                       a.plan.stat_ptr(a.bstats) if has_bn else None, N, H, W, o.C, self.G, self.gs_arr, dt),
+                                     dict(kernel='pool', what='bwd', layer='%s.%s' % (node.mname, node.name))))
+                    a.g_written = True
+                continue
             if o.norm is not None:
                 q = L.RdBnBwd()
                 q.bstats = o.plan.stat_ptr(o.bstats)
@@ -463,6 +531,10 @@ class Plan:
                     d.accumulate = 1 if a.g_written else 0
                     a.g_written = True
                     d.Cd, d.slope, d.n_off, d.g_fixed = a.C, self.slope, n_off, g_fixed
+                    if a.norm is None and d.kind == L.DST_POOL:
+                        # the arg-max of the scatter needs the pooled values: the raw tensor under identity coefficients
+                        one, zero = self.unit_coef(a.C)
+                        d.z, d.scale, d.shift, d.slope, d.g_fixed = a.buf.data_ptr(), one.data_ptr(), zero.data_ptr(), 1.0, 0
                 dsts.append(d)
             if all(d.kind == L.DST_NONE for d in dsts):
                 continue
@@ -494,7 +566,7 @@ class Plan:
         if nb == 2 and self.dtype == torch.bfloat16:
             # csrc/conv_big.hip rd_conv_big_dispatch: grids below RD_CONV_NB1_BELOW 64-wide workgroups run 32-wide tiles
             wgs64 = ((W + 31) // 32) * ((H + 7) // 8) * N * (((Cout + 31) // 32 * 32) // 64)
-            if wgs64 < int(os.environ.get('RD_CONV_NB1_BELOW', '300')):
+            if wgs64 < T.options()['conv_nb1_below']:
                 nb = 1
         tname = 'bf16' if self.dtype == torch.bfloat16 else 'f32'
         ck = 32 if self.dtype == torch.bfloat16 else 16
@@ -657,20 +729,22 @@ class WeightPack:
 
 
 # ------------------------------------------------------------------------------------------------ network builders
+def build_convd(plan, x, mode, cout, prefix, mname):
+    """ConvD.forward (unet.py:52-72): [maxpool] conv3-bn / conv3-bn-act / conv3-bn-act.  x: source Act read in `mode`
+    (RD_SRC_POOL = the 2x2 max-pool of levels 2-5 fused into the read).  Returns the Act of conv3 (BN3+act pending)."""
+    bank = plan.bank
+    H, W = (x.H // 2, x.W // 2) if mode == L.SRC_POOL else (x.H, x.W)
+    z1 = plan.conv(mname, prefix + 'conv1', [(x, mode, 0, -1)], cout, 9, Norm(bank, mname, prefix + 'bn1'), act=False, H=H, W=W)
+    z2 = plan.conv(mname, prefix + 'conv2', [(z1, L.SRC_AFF, 0, -1)], cout, 9, Norm(bank, mname, prefix + 'bn2'), act=True, H=H, W=W)
+    return plan.conv(mname, prefix + 'conv3', [(z2, L.SRC_AFFACT, 0, -1)], cout, 9, Norm(bank, mname, prefix + 'bn3'), act=True, H=H, W=W)
+
+
 def build_encoder(plan, x_act, n=16, mname='enc'):
     """Encoder.forward (unet.py:264-271).  x_act: Act of the image batch (no norm).  Returns [z3_1..z3_5]."""
-    bank = plan.bank
     feats = []
-    H, W = x_act.H, x_act.W
     prev, prev_mode = x_act, L.SRC_RAW
     for l in range(1, 6):
-        if l > 1:
-            H, W = H // 2, W // 2
-        p = 'convd%d' % l
-        co = n * (1 << (l - 1))
-        z1 = plan.conv(mname, p + '.conv1', [(prev, prev_mode, 0, -1)], co, 9, Norm(bank, mname, p + '.bn1'), act=False, H=H, W=W)
-        z2 = plan.conv(mname, p + '.conv2', [(z1, L.SRC_AFF, 0, -1)], co, 9, Norm(bank, mname, p + '.bn2'), act=True, H=H, W=W)
-        z3 = plan.conv(mname, p + '.conv3', [(z2, L.SRC_AFFACT, 0, -1)], co, 9, Norm(bank, mname, p + '.bn3'), act=True, H=H, W=W)
+        z3 = build_convd(plan, prev, prev_mode, n * (1 << (l - 1)), 'convd%d.' % l, mname)
         feats.append(z3)
         prev, prev_mode = z3, L.SRC_POOL
     return feats
@@ -680,38 +754,44 @@ def _feat_mode(a):
     return L.SRC_AFFACT if a.norm is not None else L.SRC_RAW
 
 
+def build_convu(plan, x, skip, planes, first, prefix, mname):
+    """ConvU.forward (unet.py:96-117): [conv3-bn-act] up2 conv1-bn-act cat[skip, .] conv3-bn-act."""
+    bank = plan.bank
+    if not first:
+        x = plan.conv(mname, prefix + 'conv1', [(x, _feat_mode(x), 0, -1)], planes, 9, Norm(bank, mname, prefix + 'bn1'), act=True,
+                      H=x.H, W=x.W)
+    # 1x1 conv below the upsample (commutes with bilinear interpolation); BN2 statistics on up(t)
+    t = plan.conv(mname, prefix + 'conv2', [(x, _feat_mode(x), 0, -1)], planes // 2, 1, Norm(bank, mname, prefix + 'bn2'), act=True,
+                  up_out=True, H=x.H, W=x.W)
+    return plan.conv(mname, prefix + 'conv3', [(skip, _feat_mode(skip), 0, -1), (t, L.SRC_UP, 0, -1)], planes, 9,
+                     Norm(bank, mname, prefix + 'bn3'), act=True, H=skip.H, W=skip.W)
+
+
 def build_decoder(plan, feats, n=16, num_classes=2, mname='dec'):
     """Decoder.forward (unet.py:290-296).  feats: 5 Acts (raw+pending BN, or materialised RAW inputs)."""
-    bank = plan.bank
     x = feats[4]
     for l, planes, first, skip in ((4, 16 * n, True, feats[3]), (3, 8 * n, False, feats[2]), (2, 4 * n, False, feats[1]),
                                    (1, 2 * n, False, feats[0])):
-        p = 'convu%d' % l
-        if not first:
-            x = plan.conv(mname, p + '.conv1', [(x, _feat_mode(x), 0, -1)], planes, 9, Norm(bank, mname, p + '.bn1'), act=True,
-                          H=x.H, W=x.W)
-        # 1x1 conv below the upsample (commutes with bilinear interpolation); BN2 statistics on up(t)
-        t = plan.conv(mname, p + '.conv2', [(x, _feat_mode(x), 0, -1)], planes // 2, 1, Norm(bank, mname, p + '.bn2'), act=True,
-                      up_out=True, H=x.H, W=x.W)
-        x = plan.conv(mname, p + '.conv3', [(skip, _feat_mode(skip), 0, -1), (t, L.SRC_UP, 0, -1)], planes, 9,
-                      Norm(bank, mname, p + '.bn3'), act=True, H=skip.H, W=skip.W)
+        x = build_convu(plan, x, skip, planes, first, 'convu%d.' % l, mname)
     return plan.conv(mname, 'out1', [(x, L.SRC_AFFACT, 0, -1)], num_classes, 9, None, H=x.H, W=x.W)
+
+
+def build_convu_rec(plan, x, mode, n_off, g_fixed, planes, domains, prefix, mname):
+    """ConvU_Rec.forward (unet.py:139-165): conv3-dsbn-act up2 conv1-dsbn-act conv3-dsbn-act; group g uses bns[domains[g]]."""
+    bank = plan.bank
+    h = planes // 2
+    nrm = (lambda nm: Norm(bank, mname, nm, domains)) if domains is not None else (lambda nm: Norm(bank, mname, nm))
+    z1 = plan.conv(mname, prefix + 'conv1', [(x, mode, n_off, g_fixed)], h, 9, nrm(prefix + 'bn1'), act=True, H=x.H, W=x.W)
+    t = plan.conv(mname, prefix + 'conv2', [(z1, L.SRC_AFFACT, 0, -1)], h, 1, nrm(prefix + 'bn2'), act=True, up_out=True, H=x.H, W=x.W)
+    return plan.conv(mname, prefix + 'conv3', [(t, L.SRC_UP, 0, -1)], h, 9, nrm(prefix + 'bn3'), act=True, H=2 * x.H, W=2 * x.W)
 
 
 def build_rec_decoder(plan, x5, n_off, g_fixed, domains, n=16, num_classes=3, mname='rec'):
     """Rec_Decoder.forward (unet.py:316-322) for all domain slices at once; plan.G groups, group g uses
     DomainSpecificBatchNorm2d.bns[domains[g]] (dsbn.py:26).  x5: bottleneck Act (of another plan when
     n_off/g_fixed address a slice of the encoder batch)."""
-    bank = plan.bank
     x, mode = x5, _feat_mode(x5)
-    H, W = x5.H, x5.W
     for l, planes in ((4, 16 * n), (3, 8 * n), (2, 4 * n), (1, 2 * n)):
-        p, h = 'convu%d' % l, planes // 2
-        nrm = (lambda nm: Norm(bank, mname, nm, domains)) if domains is not None else (lambda nm: Norm(bank, mname, nm))
-        z1 = plan.conv(mname, p + '.conv1', [(x, mode, n_off if x is x5 else 0, g_fixed if x is x5 else -1)], h, 9, nrm(p + '.bn1'),
-                       act=True, H=H, W=W)
-        t = plan.conv(mname, p + '.conv2', [(z1, L.SRC_AFFACT, 0, -1)], h, 1, nrm(p + '.bn2'), act=True, up_out=True, H=H, W=W)
-        H, W = 2 * H, 2 * W
-        x = plan.conv(mname, p + '.conv3', [(t, L.SRC_UP, 0, -1)], h, 9, nrm(p + '.bn3'), act=True, H=H, W=W)
+        x = build_convu_rec(plan, x, mode, n_off if x is x5 else 0, g_fixed if x is x5 else -1, planes, domains, 'convu%d.' % l, mname)
         mode = L.SRC_AFFACT
-    return plan.conv(mname, 'out1', [(x, L.SRC_AFFACT, 0, -1)], num_classes, 9, None, H=H, W=W)
+    return plan.conv(mname, 'out1', [(x, L.SRC_AFFACT, 0, -1)], num_classes, 9, None, H=x.H, W=x.W)

@@ -1,6 +1,7 @@
 """nn.Module machinery behind the drop-in ``networks.unet`` classes: parameters are nn.Parameters that alias
 a ParamBank arena, forward/backward of a whole Encoder / Decoder / Rec_Decoder are ONE autograd.Function
 each that runs the HIP launch lists of an engine.Plan (there is no ATen compute and no CPU fallback)."""
+import ctypes as C
 import os
 import weakref
 
@@ -26,11 +27,86 @@ class FusedConv2d(nn.Conv2d):
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):
-    """nn.BatchNorm2d as a parameter/buffer holder (``isinstance(m, nn.BatchNorm2d)`` and ``m.train()`` of
-    test_fundus_slice.py:75-83 work); statistics and the affine run inside the fused conv kernels."""
+    """nn.BatchNorm2d whose arithmetic is HIP (``isinstance(m, nn.BatchNorm2d)`` and ``m.train()`` of
+    test_fundus_slice.py:75-83 work).  Inside Encoder / Decoder / Rec_Decoder and their blocks the statistics and
+    the affine run fused in the conv kernels; called on its own (as DomainSpecificBatchNorm2d.forward does,
+    dsbn.py:24-27) it runs rd_bn_stats -> rd_bn_finalize_fwd -> rd_nhwc_to_nchw, and backward through rd_grad_in ->
+    rd_bn_finalize_bwd -> rd_bn_apply."""
 
     def forward(self, x):
-        raise NotImplementedError('this BatchNorm is executed inside the fused HIP graph of its parent module')
+        self._check_input_dim(x)
+        if not (x.is_cuda and self.affine and self.track_running_stats and self.momentum is not None):
+            raise RuntimeError('FusedBatchNorm2d: CUDA input, affine=True, track_running_stats=True, momentum set '
+                               '(the only configuration the reference builds, unet.py:19 / dsbn.py:10-11); no CPU fallback')
+        return BatchNormFn.apply(x, self.weight, self.bias, self)
+
+
+class BatchNormFn(torch.autograd.Function):
+    """Standalone BatchNorm2d forward/backward on the HIP kernels (one group: the whole batch shares the statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        lib = L.lib()
+        N, Cc, H, W = x.shape
+        dev, st = x.device, _stream()
+        dtype = storage_dtype()
+        dt = L.RD_BF16 if dtype == torch.bfloat16 else L.RD_F32
+        for t in (weight, bias, bn.running_mean, bn.running_var):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise RuntimeError('FusedBatchNorm2d: parameters and buffers must be contiguous fp32 CUDA tensors')
+        z = torch.empty(N, H, W, Cc, dtype=dtype, device=dev)
+        gs = L.gstart_array([0, N])
+        L.check(lib.rd_nchw_to_nhwc(x.contiguous().float().data_ptr(), z.data_ptr(), N, Cc, H, W, Cc, dt, st), 'bn: nchw_to_nhwc')
+        coef = torch.empty(4, Cc, dtype=torch.float32, device=dev)            # scale, shift, mean, invstd
+        b = L.RdBnFwd()
+        stats = None
+        if bn.training:
+            stats = torch.zeros(L.STAT_SLOTS * Cc * 2, dtype=torch.float64, device=dev)
+            L.check(lib.rd_bn_stats(z.data_ptr(), stats.data_ptr(), N, H, W, Cc, 1, gs, dt, st), 'bn_stats')
+            b.stats = stats.data_ptr()
+        b.conv_bias = None
+        b.scale, b.shift, b.mean, b.invstd = (coef[i].data_ptr() for i in range(4))
+        b.gamma[0], b.beta[0] = weight.data_ptr(), bias.data_ptr()
+        b.running_mean[0], b.running_var[0] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        b.num_batches_tracked[0] = bn.num_batches_tracked.data_ptr()
+        b.count[0] = float(N * H * W)
+        b.C, b.G, b.eps, b.momentum, b.training = Cc, 1, bn.eps, bn.momentum, 1 if bn.training else 0
+        L.check(lib.rd_bn_finalize_fwd(C.byref(b), st), 'bn_finalize_fwd')
+        y = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
+        L.check(lib.rd_nhwc_to_nchw(z.data_ptr(), y.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), 0, 0.0, N, Cc, H, W, 1, gs, dt, st),
+                'bn: nhwc_to_nchw')
+        ctx.save_for_backward(z, coef, weight)
+        ctx.training, ctx.dims, ctx.dt, ctx.keep = bn.training, (N, Cc, H, W), dt, (stats, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError('backward through BatchNorm in eval mode is not implemented in the HIP path')
+        lib = L.lib()
+        z, coef, weight = ctx.saved_tensors
+        N, Cc, H, W = ctx.dims
+        dev, st, dt = dy.device, _stream(), ctx.dt
+        gs = L.gstart_array([0, N])
+        g = torch.empty_like(z)
+        bst = torch.zeros(L.STAT_SLOTS * Cc * 2, dtype=torch.float64, device=dev)
+        L.check(lib.rd_grad_in(dy.contiguous().float().data_ptr(), z.data_ptr(), g.data_ptr(), None, None, bst.data_ptr(), 0, 0.0, 0,
+                               N, Cc, H, W, 1, gs, dt, st), 'bn: grad_in')
+        pqr = torch.empty(3, Cc, dtype=torch.float32, device=dev)
+        dgb = torch.zeros(2, Cc, dtype=torch.float32, device=dev)
+        q = L.RdBnBwd()
+        q.bstats, q.mean, q.invstd = bst.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr()
+        q.P, q.Q, q.R = (pqr[i].data_ptr() for i in range(3))
+        q.gamma[0], q.dgamma[0], q.dbeta[0] = weight.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr()
+        q.count[0] = float(N * H * W)
+        q.C, q.G = Cc, 1
+        L.check(lib.rd_bn_finalize_bwd(C.byref(q), st), 'bn_finalize_bwd')
+        dz = torch.empty_like(z)
+        L.check(lib.rd_bn_apply(g.data_ptr(), z.data_ptr(), dz.data_ptr(), pqr[0].data_ptr(), pqr[1].data_ptr(), pqr[2].data_ptr(), 1.0,
+                                N, H, W, Cc, 1, gs, dt, st), 'bn: apply bwd')
+        dx = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev)
+        L.check(lib.rd_nhwc_to_nchw(dz.data_ptr(), dx.data_ptr(), None, None, 0, 0.0, N, Cc, H, W, 1, gs, dt, st), 'bn: dx')
+        return dx, dgb[0], dgb[1], None
 
 
 def activation_slope(activation):
@@ -41,13 +117,17 @@ class FusedModule(nn.Module):
     """Common part of Encoder / Decoder / Rec_Decoder."""
     _mname = 'mod'
 
-    def _finish_init(self, specs, activation):
+    def _finish_init(self, specs, activation, init=True):
+        """init=False: a block (ConvD / ConvU / ConvU_Rec) -- the reference initialises only in the constructors of
+        Encoder / Decoder / Rec_Decoder (unet.py:257-262), so a block draws nothing beyond nn.Conv2d's own default."""
         self._specs = specs
         self._slope = activation_slope(activation)
         self._plans = {}
         self._bank = None
         self._wpack = None
         self._bound_device = None
+        if not init:
+            return
         # reference init (unet.py:257-262 and twins)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):

@@ -38,19 +38,26 @@ class RamMixer:
         p.workspace, p.tw_w, p.tw_h = self.ws.data_ptr(), self.tw_w.data_ptr(), self.tw_h.data_ptr()
         p.B, p.H, p.W, p.C, p.b = B, H, W, 3, self.b
         if dataset == 'fundus':
-            p.clip_lo, p.clip_hi, p.scale, p.offset = 0.0, 255.0, 1.0 / 127.5, -1.0
+            # x / 127.5 - 1 as a DIVISION: bit for bit numpy's `img /= 127.5; img -= 1.0` (fundus.py:217-218)
+            p.clip_lo, p.clip_hi, p.scale, p.div, p.offset = 0.0, 255.0, 1.0 / 127.5, 127.5, -1.0
         else:
-            p.clip_lo, p.clip_hi, p.scale, p.offset = -1.0, 1.0, 1.0, 0.0
+            p.clip_lo, p.clip_hi, p.scale, p.div, p.offset = -1.0, 1.0, 1.0, 0.0, 0.0
         self.p = p
 
-    def bind(self, src, trg, lam, out_img, out_freq):
-        """src/trg: fp32 NHWC [B,H,W,3]; lam: fp32 [B]; outputs: NHWC `dtype` [B,H,W,Cs] with Cs >= 3 (views are
-        fine; channels 3..Cs-1 are never written)."""
-        self.p.src, self.p.trg, self.p.lam = src.data_ptr(), trg.data_ptr(), lam.data_ptr()
+    def bind(self, src, trg, lam, out_img, out_freq, trg_amp=None):
+        """src/trg: NHWC [B,H,W,3], both fp32 or both uint8 (decoded PNG pixels); lam: fp32 [B]; outputs: NHWC `dtype`
+        [B,H,W,Cs] with Cs == 3 (dense) or one 16-byte slot (channels 3.. are then written as zeros).  trg_amp: fp32
+        [B,3,H,W] amplitude spectra of the partners instead of their images (trg may then be None)."""
+        assert src.is_contiguous() and lam.dtype == torch.float32 and src.dtype in (torch.float32, torch.uint8)
+        assert trg is None or (trg.is_contiguous() and trg.dtype == src.dtype)
+        self.p.src, self.p.lam = src.data_ptr(), lam.data_ptr()
+        self.p.trg = trg.data_ptr() if trg is not None else None
+        self.p.trg_amp = trg_amp.data_ptr() if trg_amp is not None else None
+        self.p.src_u8 = 1 if src.dtype == torch.uint8 else 0
         self.p.out_img, self.p.out_freq = out_img.data_ptr(), out_freq.data_ptr()
         assert out_img.shape[-1] == out_freq.shape[-1] >= 3
         self.p.out_cstride = out_img.shape[-1]
-        self._keep = (src, trg, lam, out_img, out_freq)
+        self._keep = (src, trg, lam, out_img, out_freq, trg_amp)
 
     def op(self):
         return (L.lib().rd_ram_mix, (C.byref(self.p), self.dt))
@@ -70,6 +77,63 @@ def source_to_target_freq_batch(src_nhwc, trg_nhwc, lam, dataset='fundus', dtype
     m = RamMixer(B, H, W, dtype, dev, dataset)
     oi = torch.empty(B, H, W, 3, dtype=dtype, device=dev)
     of = torch.empty(B, H, W, 3, dtype=dtype, device=dev)
-    m.bind(src_nhwc.float().contiguous(), trg_nhwc.float().contiguous(), lam.float().contiguous(), oi, of)
+    if not (src_nhwc.dtype == torch.uint8 and trg_nhwc.dtype == torch.uint8):
+        src_nhwc, trg_nhwc = src_nhwc.float(), trg_nhwc.float()
+    m.bind(src_nhwc.contiguous(), trg_nhwc.contiguous(), lam.float().contiguous(), oi, of)
     m.run()
     return oi.float().permute(0, 3, 1, 2).contiguous(), of.float().permute(0, 3, 1, 2).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's three free functions on the GPU, arrays in / arrays out (code/dataset/fundus.py:13-61).  The training
+# path never calls these (it runs rd_ram_mix per batch); they keep code written against the reference API working.
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError('the RAM kernels need a GPU: there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def extract_amp_spectrum_gpu(img_chw):
+    """|fft2(img)| over the last two axes (fundus.py:13-19); float32 [C,H,W] device tensor."""
+    dev = _dev()
+    x = torch.as_tensor(img_chw, dtype=torch.float32).to(dev).contiguous()
+    Cc, H, W = x.shape
+    lib = L.lib()
+    ws = E.workspace(lib.rd_ram_amp_workspace(Cc, H, W) // 4, dev)
+    tw_w, tw_h = _twiddle(W, dev), _twiddle(H, dev)
+    out = torch.empty(Cc, H, W, dtype=torch.float32, device=dev)
+    L.check(lib.rd_ram_amp(x.data_ptr(), out.data_ptr(), Cc, H, W, ws.data_ptr(), tw_w.data_ptr(), tw_h.data_ptr(), _stream()), 'rd_ram_amp')
+    return out
+
+
+def low_freq_mutate_gpu(amp_src, amp_trg, lam, ratio=0.1):
+    """The window lerp of fundus.py:21-39 with the mix ratio `lam` given; float32 [C,H,W] device tensor."""
+    dev = _dev()
+    a = torch.as_tensor(amp_src, dtype=torch.float32).to(dev).contiguous()
+    t = torch.as_tensor(amp_trg, dtype=torch.float32).to(dev).contiguous()
+    assert a.shape == t.shape and a.dim() == 3
+    Cc, H, W = a.shape
+    out = torch.empty_like(a)
+    L.check(L.lib().rd_ram_mutate(a.data_ptr(), t.data_ptr(), out.data_ptr(), Cc, H, W, window_half_width(H, W, ratio), float(lam), _stream()),
+            'rd_ram_mutate')
+    return out
+
+
+def source_to_target_freq_gpu(src_hwc, amp_trg_chw, lam, ratio=0.1):
+    """real(ifft2(A' e^{jP})) of fundus.py:41-61 for one HWC image and the partner's amplitude array; no clipping, no
+    scaling (the call sites do those); float32 [H,W,3] device tensor."""
+    dev = _dev()
+    src = torch.as_tensor(src_hwc, dtype=torch.float32).to(dev).contiguous()[None]
+    amp = torch.as_tensor(amp_trg_chw, dtype=torch.float32).to(dev).contiguous()[None]
+    _, H, W, _ = src.shape
+    m = RamMixer(1, H, W, torch.float32, dev, 'fundus', ratio=ratio)
+    m.p.clip_lo, m.p.clip_hi, m.p.scale, m.p.div, m.p.offset = -3.0e38, 3.0e38, 1.0, 0.0, 0.0
+    oi = torch.empty(1, H, W, 3, device=dev)
+    of = torch.empty(1, H, W, 3, device=dev)
+    m.bind(src, None, torch.tensor([float(lam)], dtype=torch.float32, device=dev), oi, of, trg_amp=amp)
+    m.run()
+    return of[0]

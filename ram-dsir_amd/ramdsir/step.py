@@ -17,11 +17,12 @@ import torch
 from . import _lib as L
 from . import engine as E
 from . import ram as R
+from . import tuning as T
 
 
 class TrainStep:
     def __init__(self, bank, mods, dtype, batch_sizes, H, W, dataset='fundus', consistency='kd', lambda_rec=0.1, lr=2e-3,
-                 total_iters=21200, in_channels=3, n=16, num_classes=2, slope=0.0, wpack=None, ram=False):
+                 total_iters=21200, in_channels=3, n=16, num_classes=2, slope=0.0, wpack=None, ram=False, options=None):
         self.bank, self.dtype = bank, dtype
         self.dt = L.RD_BF16 if dtype == torch.bfloat16 else L.RD_F32
         self.batch_sizes = list(batch_sizes)
@@ -32,12 +33,12 @@ class TrainStep:
         lib = L.lib()
         self.wpack = wpack if wpack is not None else E.WeightPack(bank, mods, dtype)
         # ---- graphs
+        self.opt = opt = T.options(options)
         self.seg = E.Plan(bank, dtype, 2 * B, [0, B, 2 * B], slope=slope)
         self.seg.pad_narrow = self.seg.materialize_up = True
-        min_c = int(os.environ.get('RD_MAT_MINC', '0'))
-        self.seg.materialize_min_c = min_c if min_c > 0 else None
-        min_dz = int(os.environ.get('RD_MAT_DZ_MINC', '64'))
-        self.seg.materialize_dz_min_c = min_dz if min_dz > 0 else None
+        self.seg.materialize_pool = bool(opt['pool_mat'])
+        self.seg.materialize_min_c = opt['mat_min_c'] if opt['mat_min_c'] > 0 else None
+        self.seg.materialize_dz_min_c = opt['mat_dz_min_c'] if opt['mat_dz_min_c'] > 0 else None
         slot = self.seg.slot_channels()
         self.x = E.Act(self.seg, 2 * B, H, W, in_channels, name='input', cstride=slot if in_channels < slot else None)
         self.feats = E.build_encoder(self.seg, self.x, n=n)
@@ -47,6 +48,7 @@ class TrainStep:
             gs.append(gs[-1] + b)
         self.rec = E.Plan(bank, dtype, B, gs, slope=slope)
         self.rec.pad_narrow = self.rec.materialize_up = True
+        self.rec.materialize_pool = self.seg.materialize_pool
         self.rec.materialize_min_c = self.seg.materialize_min_c
         self.rec.materialize_dz_min_c = self.seg.materialize_dz_min_c
         self.rec_logits = E.build_rec_decoder(self.rec, self.feats[4], n_off=B, g_fixed=1, domains=list(range(len(batch_sizes))),
@@ -55,7 +57,7 @@ class TrainStep:
         self.rec.build(self.wpack)
         # weight-gradient split workspaces: one per plan, because the restoration decoder's backward runs beside
         # the seg decoder's on its own stream
-        self.n_side = max(1, int(os.environ.get('RD_SIDE_STREAMS', '1')))
+        self.n_side = max(1, int(opt['side_streams']))
         self.ws = [E.workspace(max(self.seg.ws_bytes, 4) // 4 + 1, dev) for _ in range(self.n_side)]
         self.rec_wsp = E.workspace(max(self.rec.ws_bytes, 4) // 4 + 1, dev)
         self.seg.bind_workspace(self.ws)
@@ -92,10 +94,13 @@ class TrainStep:
         ad.base_lr, ad.total_iters, ad.beta1, ad.beta2, ad.eps = lr, total_iters, 0.9, 0.999, 1e-8
         self.ad = ad
         # ---- RAM (optional: raw images + partner images + lambda in, both network inputs out)
+        # ram = True: fp32 source / partner buffers; ram = 'u8': uint8 buffers (decoded PNG pixels of the Fundus pipeline:
+        # 1 byte per value over PCIe and out of HBM; the values are the same integers the reference holds as float32)
         self.ram = None
         if ram:
-            self.src = torch.zeros(B, H, W, in_channels, dtype=torch.float32, device=dev)
-            self.trg = torch.zeros(B, H, W, in_channels, dtype=torch.float32, device=dev)
+            idt = torch.uint8 if ram == 'u8' else torch.float32
+            self.src = torch.zeros(B, H, W, in_channels, dtype=idt, device=dev)
+            self.trg = torch.zeros(B, H, W, in_channels, dtype=idt, device=dev)
             self.lam = torch.ones(B, dtype=torch.float32, device=dev)
             self.ram = R.RamMixer(B, H, W, dtype, dev, dataset)
             self.ram.bind(self.src, self.trg, self.lam, self.x.buf[:B], self.x.buf[B:])
@@ -107,8 +112,8 @@ class TrainStep:
         # capture() records the one-stream order.
         self.side = [torch.cuda.Stream(device=dev) for _ in range(self.n_side)]
         self.rec_stream = torch.cuda.Stream(device=dev)
-        self.fork = os.environ.get('RD_FORK', '1') != '0'
-        self.rec_lane = os.environ.get('RD_REC_LANE', '1') != '0'
+        self.fork = bool(opt['fork'])
+        self.rec_lane = bool(opt['rec_lane'])
         self._ops = self._build_ops()
 
     def _build_ops(self):
@@ -167,7 +172,7 @@ class TrainStep:
 
     def load_raw(self, src_nhwc, trg_nhwc, lam):
         """RAM inputs: what Fundus_Multi.__getitem__ holds before the FFTs (fundus.py:209-212): the
-        transformed image and the partner image as HWC float32 arrays, and the mix ratio."""
+        transformed image and the partner image as HWC arrays (uint8 or float32), and the mix ratio."""
         self.src.copy_(src_nhwc)
         self.trg.copy_(trg_nhwc)
         self.lam.copy_(lam)
@@ -211,7 +216,7 @@ class TrainStep:
             st.synchronize()
             self._restore(saved)
             with torch.cuda.graph(g, stream=st):
-                self.run_eager(lanes=self.lanes() if os.environ.get('RD_GRAPH_FORK') == '1' else {})
+                self.run_eager(lanes=self.lanes() if self.opt['graph_fork'] else {})
         torch.cuda.current_stream().wait_stream(st)
         self.graph = g
         return g

@@ -23,7 +23,7 @@ class FusedTrainer:
         slope = encoder._slope
         self.ts = S.TrainStep(self.bank, mods, dtype, batch_sizes, H, W, dataset=dataset, consistency=consistency,
                               lambda_rec=lambda_rec, lr=lr, total_iters=total_iters, in_channels=encoder._c, n=encoder._n,
-                              num_classes=seg_decoder._k, slope=slope, ram=True)
+                              num_classes=seg_decoder._k, slope=slope, ram='u8' if dataset == 'fundus' else True)
         self.ts.wpack.refresh()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         if self.world > 1:
@@ -49,6 +49,19 @@ class FusedTrainer:
         self._step()
 
     def losses(self):
+        """The five loss terms + per-domain rec losses (names of the tensorboard scalars, train.py:298-304).  Data parallel:
+        the MEAN over the ranks (every rank must call this; one small all-reduce at logging time)."""
+        if self.world > 1:
+            buf = torch.cat([self.ts.losses, self.ts.rec_mse])
+            dist.all_reduce(buf)
+            buf /= self.world
+            keep = self.ts.losses.clone(), self.ts.rec_mse.clone()
+            self.ts.losses.copy_(buf[:self.ts.losses.numel()])
+            self.ts.rec_mse.copy_(buf[self.ts.losses.numel():])
+            out = self.ts.loss_dict()
+            self.ts.losses.copy_(keep[0])
+            self.ts.rec_mse.copy_(keep[1])
+            return out
         return self.ts.loss_dict()
 
     def lr(self):

@@ -1,0 +1,32 @@
+"""Schedule / materialisation knobs of the host side, in ONE place.  The defaults are the measured best (DESIGN.md section 2
+'what was tried'); TrainStep(options={...}) overrides them per instance.  Environment overrides (RD_*) are honoured only in
+debug mode (RAMDSIR_DEBUG_LIB=1, the library build whose kernels' dispatch switches are live too): a production run reads
+no tuning environment."""
+import os
+
+DEFAULTS = dict(
+    mat_min_c=0,          # >0: store relu(bn(z)) once for layers with at least this many channels (measured a net loss: off)
+    mat_dz_min_c=64,      # store the BN-backward gradient dz once for layers with at least this many channels
+    pool_mat=True,        # store the 2x2 max-pool in front of ConvD levels 2-5 once (rd_pool_fwd / rd_pool_bwd)
+    side_streams=1,       # HIP streams for the weight-gradient launches
+    fork=True,            # eager launch over main / side / rec streams (False: one stream)
+    rec_lane=True,        # the restoration decoder branch on its own stream
+    graph_fork=False,     # capture(): keep the forks as graph branches (slower on ROCm 7: DESIGN.md section 3)
+    conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
+)
+_ENV = dict(mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS',
+            fork='RD_FORK', rec_lane='RD_REC_LANE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
+
+
+def options(over=None):
+    o = dict(DEFAULTS)
+    if os.environ.get('RAMDSIR_DEBUG_LIB') == '1':
+        for k, name in _ENV.items():
+            if name in os.environ:
+                o[k] = type(DEFAULTS[k])(int(os.environ[name]))
+    if over:
+        unknown = set(over) - set(DEFAULTS)
+        if unknown:
+            raise KeyError('unknown tuning option(s): %s' % sorted(unknown))
+        o.update(over)
+    return o

@@ -27,6 +27,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
 
 import dataset.transform as trans
 from dataset.fundus import Fundus_Multi, Fundus
@@ -149,13 +150,19 @@ def main(args):
     bsl = fundus_batch_list[args.test_domain_idx] if args.dataset == 'fundus' else prostate_batch_list[args.test_domain_idx]
     domain_idx_list = [int(i) for i in args.domain_idxs.split(',')]
     loaders, max_len, max_id = [], -1, 0
-    raw = []
+    raw, samplers = [], []
     for idx, i in enumerate(domain_idx_list):
         ds = zoo[args.dataset](base_dir=data_root, split='train', domain_idx_list=[i], transform=transform[args.dataset],
                                is_out_domain=args.is_out_domain, test_domain_idx=args.test_domain_idx)
-        dl = DataLoader(ds, batch_size=bsl[idx], num_workers=args.num_workers, shuffle=True, drop_last=True, pin_memory=True,
-                        worker_init_fn=seed_worker)
+        # Data parallel (one process per GPU): every domain's list is SHARDED over the ranks (DistributedSampler, reshuffled
+        # per epoch with seed + epoch), each rank draws the reference's per-domain batch sizes from its shard, so one step
+        # consumes world x the reference's batch and an epoch is 1/world as many iterations; RAM partners / lambda / crops
+        # are drawn rank-locally (workers are seeded from seed + rank).  Single process: exactly the reference's loaders.
+        sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=args.seed, drop_last=True) if world > 1 else None
+        dl = DataLoader(ds, batch_size=bsl[idx], num_workers=args.num_workers, shuffle=sampler is None, sampler=sampler, drop_last=True,
+                        pin_memory=True, worker_init_fn=seed_worker)
         raw.append(dl)
+        samplers.append(sampler)
         loaders.append(cycle(dl))                       # train.py:560: replays the first pass of the shorter loaders
         if max_len < len(dl):
             max_len, max_id = len(dl), idx
@@ -185,14 +192,18 @@ def main(args):
             print('\n==> Epoch %i, learning rate = %.6f' % (epoch, args.lr if iter_num == 0 else trainer.lr()))
         for m in (encoder, seg_decoder, rec_decoder):
             m.train()
+        for sp in samplers:
+            if sp is not None:
+                sp.set_epoch(epoch)
         for i, batches in enumerate(zip(*loaders)):
             src = torch.cat([b[0] for b in batches], 0).cuda(non_blocking=True)
             trg = torch.cat([b[1] for b in batches], 0).cuda(non_blocking=True)
             lam = torch.cat([b[2] for b in batches], 0).cuda(non_blocking=True)
             mask = torch.cat([b[3] for b in batches], 0).cuda(non_blocking=True)
             trainer.step(src, trg, lam, mask)
+            if iter_num % args.log_every == 0:
+                l = trainer.losses()                    # collective when world > 1: the mean over the ranks
             if rank == 0 and iter_num % args.log_every == 0:
-                l = trainer.losses()
                 print('iter %d lr %.6f ' % (iter_num, trainer.lr()) + ' '.join('%s %.4f' % (k, v) for k, v in l.items() if k != 'rec')
                       + ' loss_rec %.4f' % (sum(l['rec']) / 4))               # train.py:304 logs avg/4
             iter_num += 1
@@ -230,9 +241,10 @@ if __name__ == '__main__':
     if 'LOCAL_RANK' not in os.environ:
         os.environ['CUDA_VISIBLE_DEVICES'] = args.gpu                  # train.py:606
     if args.deterministic:
-        random.seed(args.seed)
-        np.random.seed(args.seed)
-        torch.manual_seed(args.seed)
+        r = int(os.environ.get('RANK', '0'))               # rank-local RAM partners / crops; weights are broadcast from rank 0
+        random.seed(args.seed + r)
+        np.random.seed(args.seed + r)
+        torch.manual_seed(args.seed + r)
     if args.epochs is None:
         args.epochs = {'fundus': 400, 'prostate': 200}[args.dataset]
     if args.lr is None:

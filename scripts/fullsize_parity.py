@@ -68,6 +68,18 @@ def run(name, out):
         res['bf16_' + k] = FU.rel_l2(got3[k], got[k])
         print('  bf16 %s rel_l2 vs fp32 %.3e' % (k, res['bf16_' + k]))
     res['grads_bf16_vs_fp32'] = show(FU.grad_table(got3['grads'], got['grads']), 'bf16 HIP vs fp32 HIP grads')
+    # bf16 HIP vs the oracle with the SAME rounding points (oracle.unet.rounding)
+    from oracle import unet as OU
+    with OU.rounding(torch.bfloat16):
+        refb = FU.oracle_step(cfg, states, img, frq, mask)
+    lrel = [abs(a - b) / abs(b) for a, b in zip(got3['losses'], refb['losses'])]
+    print('  bf16 HIP vs bf16-rounding oracle: loss rel %s' % ['%.2e' % v for v in lrel])
+    res['bf16m_loss_rel'] = max(lrel)
+    for k in ('logit1', 'logit2'):
+        res['bf16m_' + k] = FU.rel_l2(got3[k], refb[k])
+        print('  bf16 HIP %s rel_l2 vs bf16-rounding oracle %.3e   (that oracle vs fp32 oracle: %.3e)' % (k, res['bf16m_' + k], FU.rel_l2(refb[k], ref[k])))
+    res['grads_bf16_vs_model'] = show(FU.grad_table(got3['grads'], refb['grads']), 'bf16 HIP vs bf16-rounding oracle grads')
+    res['grads_model_vs_fp32'] = show(FU.grad_table(refb['grads'], ref['grads']), 'bf16-rounding oracle vs fp32 oracle grads')
     out[name] = res
     del ts, bank, ts3, bank3
     torch.cuda.empty_cache()

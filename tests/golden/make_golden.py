@@ -208,6 +208,41 @@ def gen_blocks(RU):
     print('blocks.npz', len(out), 'arrays')
 
 
+# ------------------------------------------------------------------------------------------ standalone DSBN
+def gen_dsbn(ref_root):
+    """networks/dsbn.py:24-27 on its own: forward(x, domain_label) -> (y, domain_label), train (batch statistics of
+    bns[domain_label[0]], running statistics of that domain only) + backward, then eval.  Channel 2 has |mean| = 1e3 sigma."""
+    import networks.dsbn as RD
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    m = RD.DomainSpecificBatchNorm2d(12, num_domains=3)
+    for d, bn in enumerate(m.bns):
+        bn.weight.data = 1.0 + 0.3 * torch.randn(12, generator=g)
+        bn.bias.data = 0.2 * torch.randn(12, generator=g)
+    for k, v in m.state_dict().items():
+        out['sd.' + k] = v.numpy().copy()
+    x = torch.randn(5, 12, 10, 14, generator=g)
+    x[:, 2] = x[:, 2] * 1e-2 + 10.0
+    lab = torch.tensor([1, 0, 2, 1, 1])                     # only lab[0] matters (dsbn.py:26)
+    m.train()
+    xi = x.clone().requires_grad_(True)
+    y, lab_out = m(xi, lab)
+    w = torch.randn(y.shape, generator=g)
+    (y * w).sum().backward()
+    out['x'], out['lab'], out['y'], out['w'], out['dx'] = x.numpy(), lab.numpy(), y.detach().numpy(), w.numpy(), xi.grad.numpy()
+    out['lab_is_same_object'] = np.array(lab_out is lab)
+    for k, p in m.named_parameters():
+        out['g.' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    for k, v in m.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            out['after.' + k] = v.numpy().copy()
+    m.eval()
+    y2, _ = m(x, lab)
+    out['y_eval'] = y2.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, 'dsbn.npz'), **out)
+    print('dsbn.npz', len(out), 'arrays')
+
+
 # ------------------------------------------------------------------------------------------ losses
 def gen_losses(ref_losses):
     from torch.nn import BCELoss, KLDivLoss, MSELoss, CrossEntropyLoss
@@ -502,7 +537,7 @@ def gen_metrics(ref_root):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
-    ap.add_argument('--only', default='', help='comma list of fixture groups (ram,masks,losses,blocks,modules,steps,sampling,metrics)')
+    ap.add_argument('--only', default='', help='comma list of fixture groups (ram,masks,losses,blocks,modules,steps,sampling,metrics,dsbn)')
     args = ap.parse_args()
     only = set(filter(None, args.only.split(',')))
     sys.path.insert(0, os.path.join(args.ref, 'code'))
@@ -529,6 +564,8 @@ def main():
         gen_sampling(ref_fundus, ref_prostate, ref_transform)
     if want('metrics'):
         gen_metrics(args.ref)
+    if want('dsbn'):
+        gen_dsbn(args.ref)
     with open(os.path.join(HERE, 'VERSIONS.json'), 'w') as f:
         json.dump(dict(torch=torch.__version__, numpy=np.__version__, python=sys.version.split()[0]), f)
 

@@ -38,7 +38,7 @@ def test_fundus_multi_returns_ram_pieces_with_reference_sampling(tmp_path):
     seen = set()
     for k in range(40):
         img, other, lam, mask = ds[k % 5]
-        assert img.shape == (48, 48, 3) and img.dtype == torch.float32 and other.shape == (48, 48, 3)
+        assert img.shape == (48, 48, 3) and img.dtype == torch.uint8 and other.shape == (48, 48, 3) and other.dtype == torch.uint8
         assert mask.shape == (2, 48, 48)
         assert round(float(lam) * 10) in range(1, 11)
         dom = int(round(float(other[0, 0, 0]))) // 10

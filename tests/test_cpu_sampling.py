@@ -46,15 +46,18 @@ def test_fundus_multi_sampling_matches_reference(trees, tag, dom, ood, tdi):
         with SD.DrawLog() as dl:
             img, other, lam, mask = ds[i]
         assert dl.log == list(G['%s.%d.draws' % (tag, i)]), i                            # same draws, same order
-        assert img.shape == (256, 256, 3) and other.shape == (256, 256, 3)
-        x = (img.numpy() / np.float32(127.5) - np.float32(1.0)).transpose(2, 0, 1)
+        assert img.shape == (256, 256, 3) and other.shape == (256, 256, 3) and img.dtype == torch.uint8 and other.dtype == torch.uint8
+        x = img.numpy().astype(np.float32)                                                # fundus.py:211,217-218
+        x /= 127.5
+        x -= 1.0
+        x = x.transpose(2, 0, 1)
         np.testing.assert_array_equal(x[:, ::8, ::8], G['%s.%d.img' % (tag, i)])         # bit-exact source image
         np.testing.assert_array_equal(mask.numpy()[:, ::4, ::4].astype(np.uint8), G['%s.%d.mask' % (tag, i)])
         s = G['%s.%d.sig' % (tag, i)]
         np.testing.assert_allclose(sig(torch.from_numpy(x))[:4], s[0][:4], rtol=1e-12)
         np.testing.assert_allclose(sig(mask)[:4], s[2][:4], rtol=0)
         # RAM on the returned pieces (oracle, float32 like numpy >= 2 computes it) == the reference's img_freq
-        _, frq = OR.ram_fundus(img.numpy(), other.numpy(), float(lam), dtype=np.float32)
+        _, frq = OR.ram_fundus(img.numpy().astype(np.float32), other.numpy().astype(np.float32), float(lam), dtype=np.float32)
         assert np.abs(frq[:, ::8, ::8] - G['%s.%d.frq' % (tag, i)]).max() < 2e-3 / 127.5
         np.testing.assert_allclose(sig(torch.from_numpy(frq))[2], s[1][2], rtol=1e-5)
 

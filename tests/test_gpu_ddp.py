@@ -1,0 +1,58 @@
+"""-m gpu: world_size = 2 data parallelism on ONE MI355X: two processes share cuda:0, gloo process group on device tensors
+(tests/ddp_worker.py).  ramdsir.ddp.DataParallelStep runs its real choreography -- segment A, bucket 2 (decoders), segment
+B1, bucket 1 (encoder levels 3-5), segment B2, bucket 0, join, Adam -- eagerly (weight gradients on the side stream, the
+restoration decoder on its own) and as four captured hipGraphs.  Asserted: the arena holds the MEAN of the two ranks'
+single-process gradients (each rank has its own batch), bit-identical on both ranks; after two steps both ranks hold
+bit-identical parameters; BatchNorm statistics stay rank-local (nn.DataParallel replicas, train.py:205-208)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('graph', [0, 1])
+def test_two_ranks_on_one_gpu_average_gradients_and_stay_in_sync(graph):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ddp_worker.py'), '--rank', str(r), '--world', '2',
+                               '--port', str(port), '--graph', str(graph)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode())
+    res = []
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+        line = [l for l in o.splitlines() if l.startswith('DDPRESULT ')]
+        assert line, o[-3000:]
+        res.append(json.loads(line[-1][len('DDPRESULT '):]))
+    for r in res:
+        # two plain runs of one batch already differ by ~6e-3 relative L2 at this size (atomics order x ReLU flips, DESIGN.md
+        # 'Numerics'); a missing or doubled exchange would show as ~0.7 (independent batches) or a factor 2
+        assert r['rel_avg_vs_mean'] < 3e-2, r
+        assert r['rel_avg_vs_local'] > 0.2, r             # the exchange really mixed two different batches
+        assert r['same_grad'] and r['same_params'], r
+        assert r['iters'] == 2 and r['moved'] > 0, r
+        assert r['bn_tracked'] == 4, r                    # 2 steps x 2 passes, rank-local
+    assert res[0]['loss_local'] != res[1]['loss_local']   # different batches ...
+    assert res[0]['loss_mean'] == res[1]['loss_mean']     # ... one logged value

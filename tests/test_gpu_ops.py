@@ -24,7 +24,7 @@ def _slotted(t_gc2):
     G, Cc, _ = t_gc2.shape
     w = torch.rand(L.STAT_SLOTS)
     w = w / w.sum()
-    return t_gc2[:, None] * w[None, :, None, None]
+    return (t_gc2[:, None].double() * w[None, :, None, None].double())
 
 
 def _params(G, Cc, gen):
@@ -92,16 +92,17 @@ def test_conv_forward(case, dtype):
     ref = F.conv2d(a, w, bias, padding=k // 2)
     p = _conv_desc(keep, srcs, w, bias, N, H, W, gstart, dtype, taps)
     out = torch.full((N, H, W, Cout), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
-    stats = torch.zeros(G, L.STAT_SLOTS, Cout, 2, device=U.dev())
+    stats = torch.zeros(G, L.STAT_SLOTS, Cout, 2, dtype=torch.float64, device=U.dev())
     p.emode, p.out, p.stats = 0, out.data_ptr(), stats.data_ptr()
     L.check(L.lib().rd_conv(C.byref(p), U.DT[dtype][0], None), name)
     torch.cuda.synchronize()
     U.assert_close(U.from_nhwc(out), ref, dtype, name)
-    ref_stats = torch.stack([torch.stack([ref[gstart[g]:gstart[g + 1]].sum((0, 2, 3)),
-                                          ref[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1) for g in range(G)])
+    nb_ = ref - bias[None, :, None, None]                 # the sums are those of the result WITHOUT the bias (ramdsir.h, RD_STAT_SLOTS)
+    ref_stats = torch.stack([torch.stack([nb_[gstart[g]:gstart[g + 1]].sum((0, 2, 3)),
+                                          nb_[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1) for g in range(G)])
     npx = H * W * max(gstart[g + 1] - gstart[g] for g in range(G))
     # sums of npx values: compare relative to sqrt(npx)*rms (stats are taken from the fp32 accumulators)
-    assert float((stats.sum(1).cpu() - ref_stats).abs().max()) <= (1e-3 if dtype == 'bf16' else 1e-4) * npx * float(ref.abs().max() + 1) ** 2
+    assert float((stats.sum(1).cpu().float() - ref_stats).abs().max()) <= (1e-3 if dtype == 'bf16' else 1e-4) * npx * float(ref.abs().max() + 1) ** 2
 
 
 # ------------------------------------------------------------------------------------ conv gradient (dgrad + epilogues)
@@ -158,7 +159,7 @@ def test_conv_gradient_epilogues(case, dtype):
         d = L.RdDst()
         old = U.rnd(torch.randn(ys[i].shape, generator=gen), dtype) if accumulate else torch.zeros(ys[i].shape)
         gbuf = keep(U.nhwc(old if accumulate else torch.full(ys[i].shape, float('nan')), dtype))
-        bst = keep(torch.zeros(G, L.STAT_SLOTS, Cd, 2, device=U.dev()))
+        bst = keep(torch.zeros(G, L.STAT_SLOTS, Cd, 2, dtype=torch.float64, device=U.dev()))
         d.g, d.z = gbuf.data_ptr(), keep(U.nhwc(z, dtype)).data_ptr()
         d.scale, d.shift = keep(U.fdev(sc)).data_ptr(), keep(U.fdev(sh)).data_ptr()
         d.bstats, d.kind, d.act, d.accumulate, d.Cd, d.slope, d.n_off, d.g_fixed = bst.data_ptr(), kind, act, accumulate, Cd, slope, 0, -1
@@ -176,7 +177,7 @@ def test_conv_gradient_epilogues(case, dtype):
         rs = torch.stack([torch.stack([gref[gstart[g]:gstart[g + 1]].sum((0, 2, 3)),
                                        (gref * zz)[gstart[g]:gstart[g + 1]].sum((0, 2, 3))], -1) for g in range(G)])
         tol = (3e-2 if dtype == 'bf16' else 2e-4) * float(rs.abs().max() + gref.abs().sum() / Cd / G * 0.05 + 1e-3)
-        assert float((bst.sum(1).cpu() - rs).abs().max()) <= tol, '%s bstats' % name
+        assert float((bst.sum(1).cpu().float() - rs).abs().max()) <= tol, '%s bstats' % name
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -202,7 +203,7 @@ def test_conv_bnbwd_loader_and_image_offsets(dtype):
     p.emode, p.c_split = 1, Ca
     old = U.rnd(torch.randn(4, Ca, H, W, generator=gen), dtype)
     gbuf = U.nhwc(old, dtype)
-    bst = torch.zeros(2, L.STAT_SLOTS, Ca, 2, device=U.dev())
+    bst = torch.zeros(2, L.STAT_SLOTS, Ca, 2, dtype=torch.float64, device=U.dev())
     d = L.RdDst()
     d.g, d.z = gbuf.data_ptr(), keep(U.nhwc(zprod, dtype)).data_ptr()
     d.scale, d.shift = keep(U.fdev(sc)).data_ptr(), keep(U.fdev(sh)).data_ptr()
@@ -452,6 +453,128 @@ def test_bn_finalize_forward_and_backward():
     np.testing.assert_allclose(dbet.cpu(), gb.grad, rtol=1e-4, atol=1e-4)
 
 
+def _bn_standalone(x_nchw, gstart, dtype='f32'):
+    """rd_bn_stats + rd_bn_finalize_fwd on a plain tensor -> (mean, invstd) [G][C] (what a standalone BatchNorm2d does)."""
+    N, Cc, H, W = x_nchw.shape
+    G = len(gstart) - 1
+    xd = U.nhwc(x_nchw, dtype)
+    stats = torch.zeros(G, L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=U.dev())
+    L.check(L.lib().rd_bn_stats(L.ptr(xd), L.ptr(stats), N, H, W, Cc, G, L.gstart_array(gstart), U.DT[dtype][0], None), 'bn_stats')
+    bufs = {k: torch.zeros(G, Cc, device=U.dev()) for k in ('scale', 'shift', 'mean', 'invstd')}
+    one, zero = torch.ones(Cc, device=U.dev()), torch.zeros(Cc, device=U.dev())
+    p = L.RdBnFwd()
+    p.stats = stats.data_ptr()
+    for k, t in bufs.items():
+        setattr(p, k, t.data_ptr())
+    for g in range(G):
+        p.gamma[g], p.beta[g] = one.data_ptr(), zero.data_ptr()
+        p.count[g] = (gstart[g + 1] - gstart[g]) * H * W
+    p.C, p.G, p.eps, p.momentum, p.training = Cc, G, 1e-5, 0.1, 1
+    L.check(L.lib().rd_bn_finalize_fwd(C.byref(p), None), 'bnf')
+    torch.cuda.synchronize()
+    return bufs['mean'].cpu(), bufs['invstd'].cpu(), stats
+
+
+def test_bn_stats_standalone_and_large_mean_over_sigma():
+    """ATen's batch_norm never forms E[x^2]-E[x]^2 in fp32 (mean first, then deviations / Welford).  A channel with
+    |mean| = 1e3 sigma (and one with 3e4 sigma) must still get the right variance: rd_bn_stats sums deviations from a
+    per-thread pivot and everything across threads is fp64."""
+    gen = torch.Generator().manual_seed(11)
+    N, Cc, H, W = 4, 16, 40, 56
+    gstart = [0, 1, 4]
+    x = torch.randn(N, Cc, H, W, generator=gen)
+    x[:, 3] = x[:, 3] * 1e-3 + 1.0                    # mean / sigma = 1e3
+    x[:, 5] = x[:, 5] + 3e4                           # mean / sigma = 3e4 (fp32 resolution of x itself: 2e-3)
+    x[:, 7] = 2.5                                     # constant channel: variance exactly 0
+    mean, invstd, _ = _bn_standalone(x, gstart)
+    for g in range(2):
+        xs = x[gstart[g]:gstart[g + 1]].double()
+        m = xs.mean((0, 2, 3))
+        v = xs.var((0, 2, 3), unbiased=False)
+        sd = torch.sqrt(v)
+        assert bool(((mean[g].double() - m).abs() <= 1e-6 * torch.maximum(m.abs(), sd)).all())   # fp32 output: 1e-6 of max(|mean|, sigma)
+        np.testing.assert_allclose(invstd[g], 1 / torch.sqrt(v + 1e-5), rtol=2e-5)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_bn_statistics_with_a_large_bias(dtype):
+    """A conv bias 1e3 x the spread of the conv result (the one structural way a BatchNorm input gets |mean| >> sigma):
+    the epilogue's sums exclude the bias and rd_bn_finalize_fwd adds it back -> mean and invstd as torch computes them."""
+    gen = torch.Generator().manual_seed(12)
+    keep = U.Keep()
+    N, H, W, Cin, Cout, gstart = 2, 24, 40, 16, 32, [0, 1, 2]
+    a = U.rnd(torch.randn(N, Cin, H, W, generator=gen), dtype)
+    w = U.rnd(torch.randn(Cout, Cin, 3, 3, generator=gen) / np.sqrt(Cin * 9), dtype)
+    bias = 1e3 * (1 + torch.rand(Cout, generator=gen))
+    srcs = [U.make_src(keep, a, L.SRC_RAW, dtype)]
+    p = _conv_desc(keep, srcs, w, bias, N, H, W, gstart, dtype, 9)
+    out = torch.empty((N, H, W, Cout), dtype=U.DT[dtype][1], device=U.dev())
+    stats = torch.zeros(2, L.STAT_SLOTS, Cout, 2, dtype=torch.float64, device=U.dev())
+    p.emode, p.out, p.stats = 0, out.data_ptr(), stats.data_ptr()
+    L.check(L.lib().rd_conv(C.byref(p), U.DT[dtype][0], None), 'conv')
+    bufs = {k: torch.zeros(2, Cout, device=U.dev()) for k in ('scale', 'shift', 'mean', 'invstd')}
+    one, zero, bd = torch.ones(Cout, device=U.dev()), torch.zeros(Cout, device=U.dev()), bias.to(U.dev())
+    q = L.RdBnFwd()
+    q.stats, q.conv_bias = stats.data_ptr(), bd.data_ptr()
+    for k, t in bufs.items():
+        setattr(q, k, t.data_ptr())
+    for g in range(2):
+        q.gamma[g], q.beta[g] = one.data_ptr(), zero.data_ptr()
+        q.count[g] = H * W
+    q.C, q.G, q.eps, q.momentum, q.training = Cout, 2, 1e-5, 0.1, 1
+    L.check(L.lib().rd_bn_finalize_fwd(C.byref(q), None), 'bnf')
+    torch.cuda.synchronize()
+    ref = F.conv2d(a.double(), w.double(), None, padding=1)
+    for g in range(2):
+        m = ref[g:g + 1].mean((0, 2, 3)) + bias.double()
+        v = ref[g:g + 1].var((0, 2, 3), unbiased=False)
+        np.testing.assert_allclose(bufs['mean'][g].cpu(), m, rtol=1e-6)
+        np.testing.assert_allclose(bufs['invstd'][g].cpu(), 1 / torch.sqrt(v + 1e-5), rtol=1e-4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('with_bn', [True, False])
+def test_pool_materialised_forward_and_backward(dtype, with_bn):
+    """rd_pool_fwd / rd_pool_bwd == F.max_pool2d(act(bn(z)), 2) and its autograd backward (nn.MaxPool2d(2), unet.py:45,56):
+    first maximum on ties (a ReLU'd window of non-positive values is a 4-way tie at 0), activation mask, accumulation onto an
+    existing gradient, BatchNorm-backward sums of the scattered values."""
+    gen = torch.Generator().manual_seed(21)
+    N, Cc, Ho, Wo = 3, 16, 7, 9
+    gstart, slope = [0, 1, 3], 0.0
+    z = U.rnd(torch.randn(N, Cc, 2 * Ho, 2 * Wo, generator=gen), dtype)
+    z[0, :, 0:2, 0:2] = -1.0                                            # all four activations 0: tie -> position (0, 0)
+    z[1, 3, 2:4, 2:4] = 0.75                                            # exact tie of positive values
+    sc, sh = _params(2, Cc, gen)
+    zd = U.nhwc(z, dtype)
+    scd, shd = (U.fdev(sc), U.fdev(sh)) if with_bn else (None, None)
+    gs = L.gstart_array(gstart)
+    out = torch.full((N, Ho, Wo, Cc), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
+    L.check(L.lib().rd_pool_fwd(L.ptr(zd), L.ptr(scd), L.ptr(shd), slope if with_bn else 1.0, L.ptr(out), N, Ho, Wo, Cc, 2, gs,
+                                U.DT[dtype][0], None), 'pool_fwd')
+    torch.cuda.synchronize()
+    zz = z.clone().requires_grad_(True)
+    pre = (zz * U.group_rows(sc, gstart, N) + U.group_rows(sh, gstart, N)) if with_bn else zz
+    a = F.relu(pre) if with_bn else pre
+    ref = F.max_pool2d(a, 2)
+    U.assert_close(U.from_nhwc(out), ref.detach(), dtype, 'pool_fwd')
+    gp = U.rnd(torch.randn(N, Cc, Ho, Wo, generator=gen), dtype)
+    old = U.rnd(torch.randn(N, Cc, 2 * Ho, 2 * Wo, generator=gen), dtype)
+    pre.retain_grad()
+    ref.backward(gp)
+    gref = pre.grad if with_bn else zz.grad                             # gradient w.r.t. the BN output (what g holds)
+    for accumulate in (0, 1):
+        gbuf = U.nhwc(old, dtype)
+        bst = torch.zeros(2, L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=U.dev())
+        L.check(L.lib().rd_pool_bwd(L.ptr(U.nhwc(gp, dtype)), L.ptr(zd), L.ptr(scd), L.ptr(shd), slope if with_bn else 1.0, 1 if with_bn else 0,
+                                    L.ptr(gbuf), accumulate, L.ptr(bst) if with_bn else None, N, Ho, Wo, Cc, 2, gs, U.DT[dtype][0], None), 'pool_bwd')
+        torch.cuda.synchronize()
+        U.assert_close(U.from_nhwc(gbuf), gref + (old if accumulate else 0), dtype, 'pool_bwd acc=%d' % accumulate)
+        if with_bn:
+            rs = torch.stack([torch.stack([gref[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), (gref * z)[gstart[g]:gstart[g + 1]].sum((0, 2, 3))], -1)
+                              for g in range(2)])
+            np.testing.assert_allclose(bst.sum(1).cpu().float(), rs, rtol=1e-3, atol=1e-3)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_upsample_stats_and_backward(dtype):
     gen = torch.Generator().manual_seed(5)
@@ -460,13 +583,13 @@ def test_upsample_stats_and_backward(dtype):
     t = U.rnd(torch.randn(N, Cc, h, w, generator=gen), dtype).requires_grad_(True)
     y = F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False)
     td = U.nhwc(t.detach(), dtype)
-    stats = torch.zeros(2, L.STAT_SLOTS, Cc, 2, device=U.dev())
+    stats = torch.zeros(2, L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=U.dev())
     gs = L.gstart_array(gstart)
     L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats), None, N, h, w, Cc, 2, gs, U.DT[dtype][0], None), 'upstats')
     torch.cuda.synchronize()
     ref = torch.stack([torch.stack([y[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), y[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
                        for g in range(2)]).detach()
-    np.testing.assert_allclose(stats.sum(1).cpu(), ref, rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(stats.sum(1).cpu().float(), ref, rtol=1e-3, atol=1e-2)
     # materialising variant: y is stored, and the statistics are those of the stored (rounded) values
     stats2 = torch.zeros_like(stats)
     yd = torch.full((N, 2 * h, 2 * w, Cc), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
@@ -476,7 +599,7 @@ def test_upsample_stats_and_backward(dtype):
     ys = U.from_nhwc(yd)
     ref2 = torch.stack([torch.stack([ys[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), ys[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
                         for g in range(2)])
-    np.testing.assert_allclose(stats2.sum(1).cpu(), ref2, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(stats2.sum(1).cpu().float(), ref2, rtol=1e-4, atol=1e-3)
     P, R = _params(2, Cc, gen)
     Q = 0.1 * torch.randn(2, Cc, generator=gen)
     g2 = U.rnd(torch.randn(N, Cc, 2 * h, 2 * w, generator=gen), dtype)
@@ -624,7 +747,7 @@ def test_layout_boundary_kernels(dtype):
     dy = torch.randn(N, Cc, H, W, generator=gen)
     old = U.rnd(torch.randn(N, Cc, H, W, generator=gen), dtype)
     gbuf = U.nhwc(old, dtype)
-    bst = torch.zeros(2, L.STAT_SLOTS, Cc, 2, device=U.dev())
+    bst = torch.zeros(2, L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=U.dev())
     dyd = dy.to(U.dev())
     L.check(L.lib().rd_grad_in(L.ptr(dyd), L.ptr(y), L.ptr(gbuf), L.ptr(scd), L.ptr(shd), L.ptr(bst), 1, 0.0, 1, N, Cc, H, W, 2, gs,
                                U.DT[dtype][0], None), 'grad_in')
@@ -633,7 +756,7 @@ def test_layout_boundary_kernels(dtype):
     U.assert_close(U.from_nhwc(gbuf), old + gnew, dtype, 'grad_in')
     rs = torch.stack([torch.stack([gnew[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), (gnew * x)[gstart[g]:gstart[g + 1]].sum((0, 2, 3))], -1)
                       for g in range(2)])
-    np.testing.assert_allclose(bst.sum(1).cpu(), rs, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(bst.sum(1).cpu().float(), rs, rtol=1e-3, atol=1e-3)
     # column sums (bias gradient of out1)
     t3 = U.rnd(torch.randn(2, 3, 20, 30, generator=gen), dtype)
     t3d = U.nhwc(t3, dtype)
@@ -657,11 +780,11 @@ def test_layout_boundary_kernels(dtype):
 ], ids=['pp_lean_fwd', 'pp_lean_fwd_bwd', 'pp_staged', 'nb1_everywhere'])
 def test_conv_kernels_under_forced_dispatch(env):
     """The persistent pipelined kernel only takes large forward launches by default (the cases above are small), and the
-    dispatch switches are read once per process: re-run the conv parity tests in a child process with every eligible
+    dispatch switches (debug build of the library only) are read once per process: re-run the conv parity tests in a child process with every eligible
     launch forced through conv_pp_kernel (each epilogue mode) / through the 32-wide tiles."""
     import subprocess
     import sys
-    e = dict(os.environ)
+    e = dict(os.environ, RAMDSIR_DEBUG_LIB='1')        # the RD_* overrides exist only in the debug build (csrc/common.h rd_switch)
     e.update(env)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
                         'test_conv_forward or test_conv_gradient_epilogues or test_conv_bnbwd'], env=e,
