@@ -75,8 +75,9 @@ __device__ __forceinline__ void butterfly(float2* v, float sgn) {
 }
 
 // One Stockham autosort stage of `batch` independent length-N transforms in LDS, all constants known at compile time.
-// Transform t ping-pongs between buf[(t*2+0)*N ..] and buf[(t*2+1)*N ..].  tw[k] = (cos 2 pi k/N, -sin 2 pi k/N).
-template <int R, bool INV, int N, int NS>
+// Transform t ping-pongs between buf[(t*2+0)*N ..] and buf[(t*2+1)*N ..].  tw[TWS*k] = (cos 2 pi k/N, -sin 2 pi k/N)
+// (TWS = 2: the table of the twice-as-long transform, shared with the real-input post-pass).
+template <int R, bool INV, int N, int NS, int TWS>
 __device__ __forceinline__ void stage_fixed(float2* buf, int cur, int batch, const float2* tw, int tid, int nthreads) {
     constexpr int nb = N / R, tstep = N / (NS * R);
     constexpr float sgn = INV ? 1.f : -1.f;
@@ -91,7 +92,7 @@ __device__ __forceinline__ void stage_fixed(float2* buf, int cur, int batch, con
         if constexpr (NS > 1) {
 #pragma unroll
             for (int r = 1; r < R; ++r) {
-                float2 w = tw[r * k * tstep];
+                float2 w = tw[TWS * r * k * tstep];
                 if (INV) w.y = -w.y;
                 v[r] = cmul(v[r], w);
             }
@@ -103,30 +104,29 @@ __device__ __forceinline__ void stage_fixed(float2* buf, int cur, int batch, con
     __syncthreads();
 }
 
-// compile-time plans; returns which half holds the result
-template <int N, bool INV>
+// compile-time plan = the radix list; returns which half holds the result
+template <int N, bool INV, int TWS, int NS, int CUR>
+__device__ __forceinline__ int fft_chain(float2*, int, const float2*, int, int) {
+    static_assert(NS == N, "the radices must multiply to N");
+    return CUR;
+}
+template <int N, bool INV, int TWS, int NS, int CUR, int R, int... Rest>
+__device__ __forceinline__ int fft_chain(float2* buf, int batch, const float2* tw, int tid, int nthreads) {
+    stage_fixed<R, INV, N, NS, TWS>(buf, CUR, batch, tw, tid, nthreads);
+    return fft_chain<N, INV, TWS, NS * R, CUR ^ 1, Rest...>(buf, batch, tw, tid, nthreads);
+}
+
+template <int N, bool INV, int TWS = 1>
 __device__ __forceinline__ int fft_fixed(float2* buf, int batch, const float2* tw, int tid, int nthreads) {
-    static_assert(N == 256 || N == 384 || N == 400 || N == 512, "compile-time plans: 256, 384, 400, 512");
-    stage_fixed<4, INV, N, 1>(buf, 0, batch, tw, tid, nthreads);
-    stage_fixed<4, INV, N, 4>(buf, 1, batch, tw, tid, nthreads);
-    if constexpr (N == 400) {
-        stage_fixed<5, INV, N, 16>(buf, 0, batch, tw, tid, nthreads);
-        stage_fixed<5, INV, N, 80>(buf, 1, batch, tw, tid, nthreads);
-        return 0;
-    } else {
-        stage_fixed<4, INV, N, 16>(buf, 0, batch, tw, tid, nthreads);
-        if constexpr (N == 256) {
-            stage_fixed<4, INV, N, 64>(buf, 1, batch, tw, tid, nthreads);
-            return 0;
-        } else if constexpr (N == 384) {
-            stage_fixed<2, INV, N, 64>(buf, 1, batch, tw, tid, nthreads);
-            stage_fixed<3, INV, N, 128>(buf, 0, batch, tw, tid, nthreads);
-            return 1;
-        } else {
-            stage_fixed<4, INV, N, 64>(buf, 1, batch, tw, tid, nthreads);
-            stage_fixed<2, INV, N, 256>(buf, 0, batch, tw, tid, nthreads);
-            return 1;
-        }
+    if constexpr (N == 128) return fft_chain<N, INV, TWS, 1, 0, 4, 4, 4, 2>(buf, batch, tw, tid, nthreads);
+    else if constexpr (N == 192) return fft_chain<N, INV, TWS, 1, 0, 4, 4, 4, 3>(buf, batch, tw, tid, nthreads);
+    else if constexpr (N == 200) return fft_chain<N, INV, TWS, 1, 0, 4, 2, 5, 5>(buf, batch, tw, tid, nthreads);
+    else if constexpr (N == 256) return fft_chain<N, INV, TWS, 1, 0, 4, 4, 4, 4>(buf, batch, tw, tid, nthreads);
+    else if constexpr (N == 384) return fft_chain<N, INV, TWS, 1, 0, 4, 4, 4, 2, 3>(buf, batch, tw, tid, nthreads);
+    else if constexpr (N == 400) return fft_chain<N, INV, TWS, 1, 0, 4, 4, 5, 5>(buf, batch, tw, tid, nthreads);
+    else {
+        static_assert(N == 512, "compile-time plans: 128, 192, 200, 256, 384, 400, 512");
+        return fft_chain<N, INV, TWS, 1, 0, 4, 4, 4, 4, 2>(buf, batch, tw, tid, nthreads);
     }
 }
 
@@ -196,59 +196,89 @@ __device__ __forceinline__ void put3(float2* buf, int W, int i, float v) {
     const int x = i / 3, c = i - 3 * x;
     buf[c * 2 * W + x] = make_float2(v, 0.f);
 }
-
-// A: grid (ceil(H/ROWS), images).  One transform per channel (zero imaginary part) rather than a packed pair: an
-// all-zero channel must give an EXACTLY zero spectrum, because the mix divides by |F_src| (the reference's angle()==0
-// branch, fundus.py:48 on a constant-zero plane).
+// A: grid (ceil(H/ROWS), images).  An all-zero channel must give an EXACTLY zero spectrum, because the mix divides by
+// |F_src| (the reference's angle()==0 branch, fundus.py:48 on a constant-zero plane): never pack two different signals into
+// one complex transform.  Compile-time sides use the real-input form -- the W reals of ONE channel as the W/2 complex points
+// z[n] = x[2n] + i x[2n+1] (transform c spans 2 halves x W/2 float2 = 2 W floats: channel c's pixel x is float c*2W + x), a
+// W/2-point transform, then X[k] = E[k] + W_N^k O[k] with E, O = (Z[k] +- conj Z[W/2-k]) / 2 (/ i) for the kept bins only --
+// which is zero for zero input and halves the butterflies and LDS traffic; the run-time plan transforms (x, 0).
 template <int NW, int ROWS>
 __global__ __launch_bounds__(256) void ram_row_fwd_kernel(const RamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    float2* buf = reinterpret_cast<float2*>(smem_);        // [ROWS * nch transforms][2][W], then the twiddle table [W]
+    constexpr bool REAL = NW != 0;
     const int W = a.W, H = a.H, nch = a.nch;
+    const int M = REAL ? W / 2 : W;                         // points per transform
+    float2* buf = reinterpret_cast<float2*>(smem_);        // [ROWS * nch transforms][2][M], then the twiddle table [W]
     const int y0 = blockIdx.x * ROWS, n = blockIdx.y;
-    float2* s_tw = buf + ROWS * nch * 2 * W;               // twiddles out of LDS: a butterfly does not wait on L2 for them
+    float2* s_tw = buf + ROWS * nch * 2 * M;               // twiddles out of LDS: a butterfly does not wait on L2 for them
     for (int i = threadIdx.x; i < W; i += blockDim.x) s_tw[i] = a.tw_w[i];
     const int rows = min(ROWS, H - y0);
     for (int r = 0; r < rows; ++r) {
-        float2* rb = buf + (size_t)r * nch * 2 * W;
+        float2* rb = buf + (size_t)r * nch * 2 * M;
+        float* rf = reinterpret_cast<float*>(rb);
         const int y = y0 + r;
         if (a.planar) {
             const float* p = reinterpret_cast<const float*>(a.src) + ((size_t)n * H + y) * W;
-            for (int x = threadIdx.x; x < W; x += blockDim.x) rb[x] = make_float2(p[x], 0.f);
-        } else if (a.src_u8) {
-            const uint8_t* p = reinterpret_cast<const uint8_t*>(n < a.B ? a.src : a.trg) + ((size_t)(n < a.B ? n : n - a.B) * H + y) * W * 3;
-            if ((3 * W) % 16 == 0) {
-                for (int i = threadIdx.x; i < 3 * W / 16; i += blockDim.x) {
-                    const uint4 u = reinterpret_cast<const uint4*>(p)[i];
-                    const unsigned wv[4] = {u.x, u.y, u.z, u.w};
+            for (int x = threadIdx.x; x < W; x += blockDim.x) {
+                if constexpr (REAL) rf[x] = p[x];
+                else rb[x] = make_float2(p[x], 0.f);
+            }
+            continue;
+        }
+        const size_t row = ((size_t)(n < a.B ? n : n - a.B) * H + y) * W * 3;
+        const void* base = n < a.B ? a.src : a.trg;
+        if constexpr (REAL) {
+            // 4 pixels per thread (W % 4 == 0 for every compile-time side): 12 bytes / three float4 in, one 16-byte LDS
+            // store per channel out -- no per-value index arithmetic
+            for (int q = threadIdx.x; q < W / 4; q += blockDim.x) {
+                float v[12];
+                if (a.src_u8) {
+                    const unsigned* p32 = reinterpret_cast<const unsigned*>(reinterpret_cast<const uint8_t*>(base) + row) + 3 * q;
+                    const unsigned w0 = p32[0], w1 = p32[1], w2 = p32[2];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) put3(rb, W, i * 16 + e, (float)((wv[e >> 2] >> (8 * (e & 3))) & 0xffu));
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (float)((w0 >> (8 * e)) & 0xffu);
+                        v[4 + e] = (float)((w1 >> (8 * e)) & 0xffu);
+                        v[8 + e] = (float)((w2 >> (8 * e)) & 0xffu);
+                    }
+                } else {
+                    const float4* p4 = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + row) + 3 * q;
+                    const float4 f0 = p4[0], f1 = p4[1], f2 = p4[2];
+                    v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
+                    v[8] = f2.x; v[9] = f2.y; v[10] = f2.z; v[11] = f2.w;
                 }
-            } else {
-                for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) put3(rb, W, i, (float)p[i]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)                  // v[3*j + c] = pixel 4q+j, channel c
+                    *reinterpret_cast<float4*>(rf + c * 2 * W + 4 * q) = make_float4(v[c], v[3 + c], v[6 + c], v[9 + c]);
             }
+        } else if (a.src_u8) {
+            const uint8_t* p = reinterpret_cast<const uint8_t*>(base) + row;
+            for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) put3(rb, W, i, (float)p[i]);
         } else {
-            const float* p = reinterpret_cast<const float*>(n < a.B ? a.src : a.trg) + ((size_t)(n < a.B ? n : n - a.B) * H + y) * W * 3;
-            if ((3 * W) % 4 == 0) {
-                for (int i = threadIdx.x; i < 3 * W / 4; i += blockDim.x) {
-                    const float4 f = reinterpret_cast<const float4*>(p)[i];
-                    put3(rb, W, i * 4 + 0, f.x);
-                    put3(rb, W, i * 4 + 1, f.y);
-                    put3(rb, W, i * 4 + 2, f.z);
-                    put3(rb, W, i * 4 + 3, f.w);
-                }
-            } else {
-                for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) put3(rb, W, i, p[i]);
-            }
+            const float* p = reinterpret_cast<const float*>(base) + row;
+            for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) put3(rb, W, i, p[i]);
         }
     }
     __syncthreads();
-    const int cur = fft_any<NW>(buf, rows * nch, a.pw, s_tw, false, threadIdx.x, blockDim.x);
     const int nk = a.nkeep, KP = a.KP;
-    for (int i = threadIdx.x; i < rows * nch * nk; i += blockDim.x) {
-        const int t = i / nk, kx = i - t * nk;              // t = r * nch + c
-        const int r = t / nch, c = t - r * nch;
-        a.rowspec[(((size_t)n * nch + c) * H + y0 + r) * KP + kx] = buf[(size_t)(t * 2 + cur) * W + kx];
+    if constexpr (REAL) {
+        const int cur = fft_fixed<NW / 2, false, 2>(buf, rows * nch, s_tw, threadIdx.x, blockDim.x);
+        for (int i = threadIdx.x; i < rows * nch * nk; i += blockDim.x) {
+            const int t = i / nk, kx = i - t * nk;          // t = r * nch + c;  kx <= b < M
+            const int r = t / nch, c = t - r * nch;
+            const float2* Z = buf + (size_t)(t * 2 + cur) * M;
+            const float2 zk = Z[kx], zm = Z[kx == 0 ? 0 : M - kx];
+            const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));        // (Z[k] + conj Z[M-k]) / 2
+            const float2 O = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));       // (Z[k] - conj Z[M-k]) / (2i)
+            a.rowspec[(((size_t)n * nch + c) * H + y0 + r) * KP + kx] = cadd(E, cmul(s_tw[kx], O));
+        }
+    } else {
+        const int cur = fft_runtime(buf, rows * nch, a.pw, s_tw, false, threadIdx.x, blockDim.x);
+        for (int i = threadIdx.x; i < rows * nch * nk; i += blockDim.x) {
+            const int t = i / nk, kx = i - t * nk;          // t = r * nch + c
+            const int r = t / nch, c = t - r * nch;
+            a.rowspec[(((size_t)n * nch + c) * H + y0 + r) * KP + kx] = buf[(size_t)(t * 2 + cur) * W + kx];
+        }
     }
 }
 
@@ -427,16 +457,19 @@ bool make_plan(int N, FftPlan& p) {
 
 int pad4(int v) { return (v + 3) / 4 * 4; }
 
-template <int NW>
-void launch_row_fwd(const RamArgs& a, int nimg, hipStream_t st) {
-    constexpr int ROWS = NW == 0 ? 1 : 2;
-    const size_t lds = (size_t)(ROWS * a.nch * 2 + 1) * a.W * sizeof(float2);
+template <int NW, int ROWS>
+void launch_row_fwd_r(const RamArgs& a, int nimg, hipStream_t st) {
+    const size_t lds = (size_t)(ROWS * a.nch * 2 * (NW ? a.W / 2 : a.W) + a.W) * sizeof(float2);
     hipLaunchKernelGGL((ram_row_fwd_kernel<NW, ROWS>), dim3((a.H + ROWS - 1) / ROWS, nimg), dim3(256), lds, st, a);
 }
+template <int NW>
+void launch_row_fwd(const RamArgs& a, int nimg, hipStream_t st) {
+    if (NW == 0 || rd_switch("RD_RAM_ROWS_FWD", 1) == 1) launch_row_fwd_r<NW, 1>(a, nimg, st);
+    else launch_row_fwd_r<NW, 2>(a, nimg, st);
+}
 
-template <int NH>
-int launch_col_mix(const RamArgs& a, hipStream_t st) {
-    constexpr int KT = NH == 0 ? 1 : 4;
+template <int NH, int KT>
+int launch_col_mix_k(const RamArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(2 * KT * 2 + 1) * a.H * sizeof(float2);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
@@ -448,12 +481,25 @@ int launch_col_mix(const RamArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((ram_col_mix_kernel<NH, KT>), dim3((a.nkeep + KT - 1) / KT, 3, a.B), dim3(256), lds, st, a);
     return 0;
 }
+template <int NH>
+int launch_col_mix(const RamArgs& a, hipStream_t st) {
+    const int kt = NH == 0 ? 1 : rd_switch("RD_RAM_KT", 2);
+    if (kt == 1) return launch_col_mix_k<NH, 1>(a, st);
+    if (kt == 2) return launch_col_mix_k<NH, 2>(a, st);
+    return launch_col_mix_k<NH, 4>(a, st);
+}
 
-template <typename T, int NW>
-void launch_row_inv(const RamArgs& a, hipStream_t st) {
-    constexpr int ROWS = NW == 0 ? 1 : 2;
+template <typename T, int NW, int ROWS>
+void launch_row_inv_r(const RamArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(ROWS * 2 * 2 + 1) * a.W * sizeof(float2);
     hipLaunchKernelGGL((ram_row_inv_kernel<T, NW, ROWS>), dim3((a.H + ROWS - 1) / ROWS, a.B), dim3(256), lds, st, a);
+}
+template <typename T, int NW>
+void launch_row_inv(const RamArgs& a, hipStream_t st) {
+    const int rows = NW == 0 ? 1 : rd_switch("RD_RAM_ROWS_INV", 2);
+    if (rows == 1) launch_row_inv_r<T, NW, 1>(a, st);
+    else if (rows == 4) launch_row_inv_r<T, NW, 4>(a, st);
+    else launch_row_inv_r<T, NW, 2>(a, st);
 }
 
 #define RD_BY_SIDE(side, CALL)            \

@@ -1,5 +1,6 @@
-// wgrad.hip -- weight-gradient kernels (K = pixels): generic fp32/bf16, bf16 with transposed LDS tiles, and the
-// 16x16x32-MFMA kernel for 16-channel layers; deterministic two-stage split reduction.
+// wgrad.hip -- weight-gradient kernels (K = pixels): the generic one (fp32; bf16 with ragged channel counts), the bf16 kernels
+// on [pixel][channel] LDS tiles read through ds_read_b64_tr_b16 (32x32x16 MFMA blocks, and 16x16x32 blocks for <= 16 output
+// channels); deterministic two-stage split reduction.
 #include "conv_device.h"
 #include "conv_dispatch.h"
 
@@ -176,274 +177,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int Cout
                 const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int ccol = cbase + nb * 32 + li;
                 out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------ bf16 wgrad, transposed LDS tiles
-// Same decomposition as wgrad_kernel, but the tiles are stored [channel][pixel] so that the K (pixel) run of
-// both MFMA operands is contiguous: the dz fragment is one ds_read_b128, the three horizontal taps of a row
-// come from ONE 10-pixel window (ds_read_b128 + ds_read_b32; the odd tap is 4 v_alignbit), instead of
-// 38 ds_read_u16 + packing per k-step.  Channel rows are padded to 16*odd bytes mod 256 so the 16-lane
-// groups of a b128 read hit 64 distinct banks.  Each wave fills whole channel slots (lanes run over
-// pixels), so the transposing ds_write_b16 of a wave land on consecutive pixels of one row.
-template <int TAPS, int MB, int NB, bool PF, int TS>
-__global__ __launch_bounds__(256 * TS) void wgrad_t_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
-    typedef bf16_t T;
-    constexpr int S = 8;
-    constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
-    constexpr int PWL = (TAPS == 9) ? 40 : 32;             // LDS row pitch in pixels (16-byte aligned windows)
-    constexpr int AP = PH * PWL + 8;                        // elements per channel row: 816 B (3x3) / 528 B (1x1)
-    constexpr int ZP = TH * TW + 8;                         // 528 B
-    constexpr int CA = NB * 32, CZ = MB * 32;
-    constexpr int KS = 4 / (MB * NB);
-    constexpr int ROWS = TH / KS;
-    constexpr int NSA = CA / S, NSZ = CZ / S;               // channel slots per tile
-    // TS = 3: the three kernel rows of a 3x3 go to three groups of 4 waves (12 waves share one LDS tile):
-    // 48 accumulator registers per wave instead of 144, so 3 waves per SIMD overlap their LDS->MFMA chains
-    constexpr int NW = 4 * TS, NTH = 256 * TS;
-    constexpr int KHN = (TAPS == 9 ? 3 : 1) / TS, NTAP = TAPS / TS;   // kernel rows / taps per wave
-    constexpr int SPA = (NSA + NW - 1) / NW, SPZ = (NSZ + NW - 1) / NW; // slots per wave (a: low waves, dz: high waves)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned short* s_a = reinterpret_cast<unsigned short*>(smem);     // [CA][AP]
-    unsigned short* s_z = s_a + CA * AP;                                // [CZ][ZP]
-
-    // the wave index in an SGPR: everything derived from it (slot, BN coefficients, source pointers) is scalar
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, h = lane >> 5;
-    const int khs = wave >> 2, w4 = wave & 3;
-    const int kq = w4 / (MB * NB), blk = w4 % (MB * NB);
-    const int mb = blk / NB, nb = blk % NB;
-    const int nbase = blockIdx.y * CZ, cbase = blockIdx.z * CA;
-    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
-    const int H = p.H, W = p.W;
-    const GroupMap gm = make_gm(p.gstart, p.G);
-
-    f32x16 acc[NTAP];
-#pragma unroll
-    for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    auto coords = [&](int tile, int& n, int& y0, int& x0) {
-        n = tile / (tiles_x * tiles_y);
-        const int trem = tile - n * tiles_x * tiles_y;
-        y0 = (trem / tiles_x) * TH;
-        x0 = (trem % tiles_x) * TW;
-    };
-    SlotCtx<T> ctx_a[SPA], ctx_z[SPZ];
-    PlainSrc<T> psa[SPA], psz[SPZ];
-    rd_src_t sa[SPA];
-    bool live_a[SPA], live_z[SPZ];
-    int ca[SPA], cz[SPZ];                                   // channel of the slot inside its source
-    auto make_ctx = [&](int g) {
-        if constexpr (PF) {
-#pragma unroll
-            for (int q = 0; q < SPA; ++q)
-                if (live_a[q]) plain_src_coef<T>(psa[q], sa[q], g, ca[q]);
-#pragma unroll
-            for (int q = 0; q < SPZ; ++q)
-                if (live_z[q]) plain_src_coef<T>(psz[q], p.dz, g, cz[q]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < SPA; ++q) slot_ctx<T>(ctx_a[q], p.a, p.na, p.Cin, g, cbase + (wave + NW * q) * S);
-#pragma unroll
-            for (int q = 0; q < SPZ; ++q) slot_ctx<T>(ctx_z[q], &p.dz, 1, p.Cout, g, nbase + (NW - 1 - wave + NW * q) * S);
-        }
-    };
-    if constexpr (PF) {
-#pragma unroll
-        for (int q = 0; q < SPA; ++q) {
-            const int c = cbase + (wave + NW * q) * S;
-            const int si = (p.na == 1 || c < p.a[0].C) ? 0 : 1;
-            sa[q] = select_src(p.a, si);
-            ca[q] = c - (si ? p.a[0].C : 0);
-            live_a[q] = wave + NW * q < NSA && c < p.Cin;
-            plain_src_init<T>(psa[q], sa[q], ca[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < SPZ; ++q) {
-            cz[q] = nbase + (NW - 1 - wave + NW * q) * S;
-            live_z[q] = NW - 1 - wave + NW * q < NSZ && cz[q] < p.Cout;
-            plain_src_init<T>(psz[q], p.dz, cz[q]);
-        }
-    }
-    int g_ctx = 0;
-    make_ctx(0);
-    // PF (every source is a plain per-pixel read with whole 16-byte channel slots -- the host checks): the
-    // raw 16-byte vectors of the NEXT tile are fetched into registers right after this tile's LDS fill, so
-    // their HBM latency is hidden behind the MFMA phase; channel slots beyond Cin / Cout are zeroed once.
-    constexpr int NITA = (PH * PW + 63) / 64, NITZ = (TH * TW) / 64;
-    ItemGeom<NITA> iga;
-    ItemGeom<NITZ> igz;
-    uint4 raw_a[SPA][NITA][1], raw_z[SPZ][NITZ][2];
-    auto issue = [&](int tile) {
-        int n, y0, x0;
-        coords(tile, n, y0, x0);
-#pragma unroll
-        for (int q = 0; q < SPA; ++q)
-            if (live_a[q]) pfu_issue<T, NITA>(raw_a[q], psa[q], iga, n, H, W, y0 - HALO, x0 - HALO);
-#pragma unroll
-        for (int q = 0; q < SPZ; ++q)
-            if (live_z[q]) pfu_issue<T, NITZ>(raw_z[q], psz[q], igz, n, H, W, y0, x0);
-    };
-    if constexpr (PF) {
-#pragma unroll
-        for (int b = 0; b < NITA; ++b) {
-            const int pix = lane + 64 * b, py = pix / PW, px = pix - py * PW;
-            iga.py[b] = (short)py;
-            iga.px[b] = (short)px;
-            iga.lds[b] = pix < PH * PW ? py * PWL + px : -1;
-        }
-#pragma unroll
-        for (int b = 0; b < NITZ; ++b) {
-            const int pix = lane + 64 * b;
-            igz.py[b] = (short)(pix / TW);
-            igz.px[b] = (short)(pix % TW);
-            igz.lds[b] = pix;
-        }
-        unsigned* z32 = reinterpret_cast<unsigned*>(smem);
-        for (int i = tid; i < (CA * AP + CZ * ZP) / 2; i += NTH) z32[i] = 0u;
-        if ((int)blockIdx.x < total_tiles) issue(blockIdx.x);
-    }
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        int n, y0, x0;
-        coords(tile, n, y0, x0);
-        const int g = group_of(gm, n);
-        if (g != g_ctx) {
-            make_ctx(g);
-            g_ctx = g;
-        }
-        __syncthreads();
-        if constexpr (PF) {
-#pragma unroll
-            for (int q = 0; q < SPA; ++q) {
-                const int sl = wave + NW * q;
-                if (live_a[q])
-                    pfu_consume<T, NITA, 1>(raw_a[q], psa[q], iga, H, W, y0 - HALO, x0 - HALO, [&](int l, const uint4& u) {
-                        unsigned short* d = s_a + (sl * S) * AP + l;
-                        d[0 * AP] = (unsigned short)(u.x & 0xffff); d[1 * AP] = (unsigned short)(u.x >> 16);
-                        d[2 * AP] = (unsigned short)(u.y & 0xffff); d[3 * AP] = (unsigned short)(u.y >> 16);
-                        d[4 * AP] = (unsigned short)(u.z & 0xffff); d[5 * AP] = (unsigned short)(u.z >> 16);
-                        d[6 * AP] = (unsigned short)(u.w & 0xffff); d[7 * AP] = (unsigned short)(u.w >> 16);
-                    });
-            }
-#pragma unroll
-            for (int q = 0; q < SPZ; ++q) {
-                const int sl = NW - 1 - wave + NW * q;
-                if (live_z[q])
-                    pfu_consume<T, NITZ, 2>(raw_z[q], psz[q], igz, H, W, y0, x0, [&](int l, const uint4& u) {
-                        unsigned short* d = s_z + (sl * S) * ZP + l;
-                        d[0 * ZP] = (unsigned short)(u.x & 0xffff); d[1 * ZP] = (unsigned short)(u.x >> 16);
-                        d[2 * ZP] = (unsigned short)(u.y & 0xffff); d[3 * ZP] = (unsigned short)(u.y >> 16);
-                        d[4 * ZP] = (unsigned short)(u.z & 0xffff); d[5 * ZP] = (unsigned short)(u.z >> 16);
-                        d[6 * ZP] = (unsigned short)(u.w & 0xffff); d[7 * ZP] = (unsigned short)(u.w >> 16);
-                    });
-            }
-        } else {
-#pragma unroll
-        for (int q = 0; q < SPA; ++q) {
-            const int sl = wave + NW * q;
-            if (sl < NSA) {
-                auto map = [&](int pix, int& y, int& x) -> bool {
-                    const int py = pix / PW, px = pix - py * PW;
-                    y = y0 - HALO + py;
-                    x = x0 - HALO + px;
-                    return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                };
-                auto store = [&](int pix, const uint4& u) {
-                    const int py = pix / PW, px = pix - py * PW;
-                    unsigned short* d = s_a + (sl * S) * AP + py * PWL + px;
-                    d[0 * AP] = (unsigned short)(u.x & 0xffff); d[1 * AP] = (unsigned short)(u.x >> 16);
-                    d[2 * AP] = (unsigned short)(u.y & 0xffff); d[3 * AP] = (unsigned short)(u.y >> 16);
-                    d[4 * AP] = (unsigned short)(u.z & 0xffff); d[5 * AP] = (unsigned short)(u.z >> 16);
-                    d[6 * AP] = (unsigned short)(u.w & 0xffff); d[7 * AP] = (unsigned short)(u.w >> 16);
-                };
-                tile_fill<T, 64>(p.a, ctx_a[q], n, H, W, lane, PH * PW, map, store);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < SPZ; ++q) {
-            const int sl = NW - 1 - wave + NW * q;
-            if (sl < NSZ) {
-                auto map = [&](int pix, int& y, int& x) -> bool {
-                    const int py = pix / TW, px = pix - py * TW;
-                    y = y0 + py;
-                    x = x0 + px;
-                    return y < H && x < W;
-                };
-                auto store = [&](int pix, const uint4& u) {
-                    unsigned short* d = s_z + (sl * S) * ZP + pix;
-                    d[0 * ZP] = (unsigned short)(u.x & 0xffff); d[1 * ZP] = (unsigned short)(u.x >> 16);
-                    d[2 * ZP] = (unsigned short)(u.y & 0xffff); d[3 * ZP] = (unsigned short)(u.y >> 16);
-                    d[4 * ZP] = (unsigned short)(u.z & 0xffff); d[5 * ZP] = (unsigned short)(u.z >> 16);
-                    d[6 * ZP] = (unsigned short)(u.w & 0xffff); d[7 * ZP] = (unsigned short)(u.w >> 16);
-                };
-                tile_fill<T, 64>(&p.dz, ctx_z[q], n, H, W, lane, TH * TW, map, store);
-            }
-        }
-        }
-        __syncthreads();
-        if constexpr (PF) {
-            if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
-        }
-        const unsigned short* zr = s_z + (mb * 32 + li) * ZP;
-        const unsigned short* ar = s_a + (nb * 32 + li) * AP;
-#pragma unroll 1
-        for (int rr = 0; rr < ROWS; ++rr) {
-            const int row = kq + rr * KS;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int px0 = ks * 16 + 8 * h;                  // this lane-half's 8 pixels (k = 8h+e)
-                const bf16x8 afrag = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(zr + row * TW + px0));
-#pragma unroll
-                for (int kj = 0; kj < KHN; ++kj) {
-                    const int kh = khs * KHN + kj;
-                    const unsigned short* wp = ar + (row + kh) * PWL + px0;     // halo coords: input = output + tap
-                    const uint4 dq = *reinterpret_cast<const uint4*>(wp);
-                    if constexpr (TAPS == 9) {
-                        const unsigned d4 = *reinterpret_cast<const unsigned*>(wp + 8);
-                        const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(dq.y, dq.x, 16), __builtin_amdgcn_alignbit(dq.z, dq.y, 16),
-                                                    __builtin_amdgcn_alignbit(dq.w, dq.z, 16), __builtin_amdgcn_alignbit(d4, dq.w, 16));
-                        const uint4 m2 = make_uint4(dq.y, dq.z, dq.w, d4);
-                        acc[kj * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kj * 3 + 0], 0, 0, 0);
-                        acc[kj * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kj * 3 + 1], 0, 0, 0);
-                        acc[kj * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kj * 3 + 2], 0, 0, 0);
-                    } else {
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[0], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-    if constexpr (KS > 1) {
-        float* s_acc = reinterpret_cast<float*>(smem) + khs * ((KS - 1) * (MB * NB) * 16 * 64);     // [TS][(KS-1)][MB*NB][16][64]
-#pragma unroll
-        for (int tap = 0; tap < NTAP; ++tap) {
-            __syncthreads();
-            if (kq > 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s_acc[(((kq - 1) * (MB * NB) + blk) * 16 + r) * 64 + lane] = acc[tap][r];
-            }
-            __syncthreads();
-            if (kq == 0) {
-#pragma unroll
-                for (int k2 = 0; k2 < KS - 1; ++k2)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tap][r] += s_acc[((k2 * (MB * NB) + blk) * 16 + r) * 64 + lane];
-            }
-        }
-    }
-    if (kq == 0) {
-        float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
-#pragma unroll
-        for (int tap = 0; tap < NTAP; ++tap)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int ccol = cbase + nb * 32 + li;
-                out[((size_t)(khs * NTAP + tap) * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
             }
     }
 }
@@ -802,234 +535,6 @@ __global__ __launch_bounds__(256, 3) void wgrad_c16_tr_kernel(const rd_wgrad_t p
     }
 }
 
-// ------------------------------------------------------------------------------------ bf16 wgrad, <= 32 channels
-// The HBM-bound layers (16/32 channels at 400x400 / 200x200): v_mfma_f32_16x16x32_bf16 with K = the 32 pixels
-// of one tile row, 16x16 channel blocks (no padding of 16-channel layers to 32), 4 accumulator VGPRs per tap
-// (36 for a 3x3) instead of 144 -> 4 workgroups per CU keep enough loads in flight.  MB x NB 16-channel
-// blocks per workgroup; the 4 waves are MB*NB blocks x KS = 4/(MB*NB) row splits.
-template <int TAPS, int MB, int NB, bool PF>
-__global__ __launch_bounds__(256, PF ? 2 : 3) void wgrad_c16_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
-    typedef bf16_t T;
-    typedef __attribute__((ext_vector_type(4))) float f32x4v;
-    constexpr int S = 8;
-    constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
-    constexpr int PWL = (TAPS == 9) ? 40 : 32;
-    constexpr int AP = PH * PWL + 8, ZP = TH * TW + 8;
-    constexpr int CA = NB * 16, CZ = MB * 16;
-    constexpr int KS = 4 / (MB * NB);
-    constexpr int ROWS = TH / KS;
-    constexpr int NSA = CA / S, NSZ = CZ / S, NJOB = NSA + NSZ;      // fill jobs: one 8-channel slot each
-    constexpr int JPW = (NJOB + 3) / 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned short* s_a = reinterpret_cast<unsigned short*>(smem);     // [CA][AP]
-    unsigned short* s_z = s_a + CA * AP;                                // [CZ][ZP]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kg = lane >> 4;
-    const int kq = wave / (MB * NB), blk = wave % (MB * NB);
-    const int mb = blk / NB, nb = blk % NB;
-    const int nbase = blockIdx.y * CZ, cbase = blockIdx.z * CA;
-    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
-    const int H = p.H, W = p.W;
-    const GroupMap gm = make_gm(p.gstart, p.G);
-
-    f32x4v acc[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-
-    auto coords = [&](int tile, int& n, int& y0, int& x0) {
-        n = tile / (tiles_x * tiles_y);
-        const int trem = tile - n * tiles_x * tiles_y;
-        y0 = (trem / tiles_x) * TH;
-        x0 = (trem % tiles_x) * TW;
-    };
-    SlotCtx<T> ctx[JPW];
-    auto make_ctx = [&](int g) {
-#pragma unroll
-        for (int q = 0; q < JPW; ++q) {
-            const int job = wave + 4 * q;
-            if (job < NSA) slot_ctx<T>(ctx[q], p.a, p.na, p.Cin, g, cbase + job * S);
-            else if (job < NJOB) slot_ctx<T>(ctx[q], &p.dz, 1, p.Cout, g, nbase + (job - NSA) * S);
-            else ctx[q].si = -1;
-        }
-    };
-    int g_ctx = 0;
-    make_ctx(0);
-    // PF: see wgrad_t_kernel -- next tile's raw vectors are in flight during this tile's MFMA phase
-    constexpr int NITA = (PH * PW + 63) / 64, NITZ = (TH * TW) / 64;
-    ItemGeom<NITA> iga;
-    ItemGeom<NITZ> igz;
-    rd_src_t sj[JPW];
-    bool live[JPW];
-    uint4 raw_a[JPW][NITA][1], raw_z[JPW][NITZ][2];
-    auto issue = [&](int tile) {
-        int n, y0, x0;
-        coords(tile, n, y0, x0);
-#pragma unroll
-        for (int q = 0; q < JPW; ++q) {
-            if (!live[q]) continue;
-            if (wave + 4 * q < NSA) pf_issue<T, NITA>(raw_a[q], sj[q], ctx[q], iga, n, H, W, y0 - HALO, x0 - HALO);
-            else pf_issue<T, NITZ>(raw_z[q], sj[q], ctx[q], igz, n, H, W, y0, x0);
-        }
-    };
-    if constexpr (PF) {
-#pragma unroll
-        for (int b = 0; b < NITA; ++b) {
-            const int pix = lane + 64 * b, py = pix / PW, px = pix - py * PW;
-            iga.py[b] = (short)py;
-            iga.px[b] = (short)px;
-            iga.lds[b] = pix < PH * PW ? py * PWL + px : -1;
-        }
-#pragma unroll
-        for (int b = 0; b < NITZ; ++b) {
-            const int pix = lane + 64 * b;
-            igz.py[b] = (short)(pix / TW);
-            igz.px[b] = (short)(pix % TW);
-            igz.lds[b] = pix;
-        }
-#pragma unroll
-        for (int q = 0; q < JPW; ++q) {
-            const int job = wave + 4 * q;
-            sj[q] = job < NSA ? select_src(p.a, ctx[q].si > 0 ? 1 : 0) : p.dz;
-            live[q] = job < NJOB && ctx[q].si >= 0;
-        }
-        unsigned* z32 = reinterpret_cast<unsigned*>(smem);
-        for (int i = tid; i < (CA * AP + CZ * ZP) / 2; i += 256) z32[i] = 0u;
-        if ((int)blockIdx.x < total_tiles) issue(blockIdx.x);
-    }
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        int n, y0, x0;
-        coords(tile, n, y0, x0);
-        const int g = group_of(gm, n);
-        if (g != g_ctx) {
-            make_ctx(g);
-            g_ctx = g;
-        }
-        __syncthreads();
-        if constexpr (PF) {
-#pragma unroll
-            for (int q = 0; q < JPW; ++q) {
-                const int job = wave + 4 * q;
-                if (!live[q]) continue;
-                if (job < NSA) {
-                    pf_consume_fn<T, NITA, 1>(raw_a[q], sj[q], ctx[q], iga, H, W, y0 - HALO, x0 - HALO, [&](int l, const uint4& u) {
-                        unsigned short* d = s_a + (job * S) * AP + l;
-                        d[0 * AP] = (unsigned short)(u.x & 0xffff); d[1 * AP] = (unsigned short)(u.x >> 16);
-                        d[2 * AP] = (unsigned short)(u.y & 0xffff); d[3 * AP] = (unsigned short)(u.y >> 16);
-                        d[4 * AP] = (unsigned short)(u.z & 0xffff); d[5 * AP] = (unsigned short)(u.z >> 16);
-                        d[6 * AP] = (unsigned short)(u.w & 0xffff); d[7 * AP] = (unsigned short)(u.w >> 16);
-                    });
-                } else {
-                    pf_consume_fn<T, NITZ, 2>(raw_z[q], sj[q], ctx[q], igz, H, W, y0, x0, [&](int l, const uint4& u) {
-                        unsigned short* d = s_z + ((job - NSA) * S) * ZP + l;
-                        d[0 * ZP] = (unsigned short)(u.x & 0xffff); d[1 * ZP] = (unsigned short)(u.x >> 16);
-                        d[2 * ZP] = (unsigned short)(u.y & 0xffff); d[3 * ZP] = (unsigned short)(u.y >> 16);
-                        d[4 * ZP] = (unsigned short)(u.z & 0xffff); d[5 * ZP] = (unsigned short)(u.z >> 16);
-                        d[6 * ZP] = (unsigned short)(u.w & 0xffff); d[7 * ZP] = (unsigned short)(u.w >> 16);
-                    });
-                }
-            }
-        } else {
-#pragma unroll
-        for (int q = 0; q < JPW; ++q) {
-            const int job = wave + 4 * q;
-            if (job < NSA) {
-                auto map = [&](int pix, int& y, int& x) -> bool {
-                    const int py = pix / PW, px = pix - py * PW;
-                    y = y0 - HALO + py;
-                    x = x0 - HALO + px;
-                    return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                };
-                auto store = [&](int pix, const uint4& u) {
-                    const int py = pix / PW, px = pix - py * PW;
-                    unsigned short* d = s_a + (job * S) * AP + py * PWL + px;
-                    d[0 * AP] = (unsigned short)(u.x & 0xffff); d[1 * AP] = (unsigned short)(u.x >> 16);
-                    d[2 * AP] = (unsigned short)(u.y & 0xffff); d[3 * AP] = (unsigned short)(u.y >> 16);
-                    d[4 * AP] = (unsigned short)(u.z & 0xffff); d[5 * AP] = (unsigned short)(u.z >> 16);
-                    d[6 * AP] = (unsigned short)(u.w & 0xffff); d[7 * AP] = (unsigned short)(u.w >> 16);
-                };
-                tile_fill<T, 64>(p.a, ctx[q], n, H, W, lane, PH * PW, map, store);
-            } else if (job < NJOB) {
-                const int sl = job - NSA;
-                auto map = [&](int pix, int& y, int& x) -> bool {
-                    const int py = pix / TW, px = pix - py * TW;
-                    y = y0 + py;
-                    x = x0 + px;
-                    return y < H && x < W;
-                };
-                auto store = [&](int pix, const uint4& u) {
-                    unsigned short* d = s_z + (sl * S) * ZP + pix;
-                    d[0 * ZP] = (unsigned short)(u.x & 0xffff); d[1 * ZP] = (unsigned short)(u.x >> 16);
-                    d[2 * ZP] = (unsigned short)(u.y & 0xffff); d[3 * ZP] = (unsigned short)(u.y >> 16);
-                    d[4 * ZP] = (unsigned short)(u.z & 0xffff); d[5 * ZP] = (unsigned short)(u.z >> 16);
-                    d[6 * ZP] = (unsigned short)(u.w & 0xffff); d[7 * ZP] = (unsigned short)(u.w >> 16);
-                };
-                tile_fill<T, 64>(&p.dz, ctx[q], n, H, W, lane, TH * TW, map, store);
-            }
-        }
-        }
-        __syncthreads();
-        if constexpr (PF) {
-            if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
-        }
-        const unsigned short* zr = s_z + (mb * 16 + li) * ZP + kg * 8;
-        const unsigned short* ar = s_a + (nb * 16 + li) * AP + kg * 8;
-#pragma unroll 1
-        for (int rr = 0; rr < ROWS; ++rr) {
-            const int row = kq + rr * KS;
-            const bf16x8 afrag = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(zr + row * TW));
-#pragma unroll
-            for (int kh = 0; kh < (TAPS == 9 ? 3 : 1); ++kh) {
-                const unsigned short* wp = ar + (row + kh) * PWL;
-                const uint4 dq = *reinterpret_cast<const uint4*>(wp);
-                if constexpr (TAPS == 9) {
-                    const unsigned d4 = *reinterpret_cast<const unsigned*>(wp + 8);
-                    const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(dq.y, dq.x, 16), __builtin_amdgcn_alignbit(dq.z, dq.y, 16),
-                                                __builtin_amdgcn_alignbit(dq.w, dq.z, 16), __builtin_amdgcn_alignbit(d4, dq.w, 16));
-                    const uint4 m2 = make_uint4(dq.y, dq.z, dq.w, d4);
-                    acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kh * 3 + 0], 0, 0, 0);
-                    acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kh * 3 + 1], 0, 0, 0);
-                    acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kh * 3 + 2], 0, 0, 0);
-                } else {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[0], 0, 0, 0);
-                }
-            }
-        }
-    }
-    if constexpr (KS > 1) {
-        float* s_acc = reinterpret_cast<float*>(smem);     // [(KS-1)][MB*NB][TAPS][4][64]
-        __syncthreads();
-        if (kq > 0) {
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s_acc[((((kq - 1) * (MB * NB) + blk) * TAPS + tap) * 4 + r) * 64 + lane] = acc[tap][r];
-        }
-        __syncthreads();
-        if (kq == 0) {
-#pragma unroll
-            for (int k2 = 0; k2 < KS - 1; ++k2)
-#pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tap][r] += s_acc[(((k2 * (MB * NB) + blk) * TAPS + tap) * 4 + r) * 64 + lane];
-        }
-    }
-    if (kq == 0) {
-        // D layout of the 16x16 MFMA: column (N, cin) = lane&15, row (M, cout) = 4*(lane>>4) + r
-        float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int nrow = nbase + mb * 16 + 4 * kg + r;
-                const int ccol = cbase + nb * 16 + li;
-                out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
-            }
-    }
-}
-
 // Split reduction.  (A float4-coalesced, chunked variant with atomics into a zeroed dW measured 320 us/step SLOWER over
 // the 40 launches -- the extra memset launch and fewer blocks in flight cost more than the strided reads, which are L2 hits
 // on partials written microseconds earlier: profiles/README.md round 2.)
@@ -1101,7 +606,7 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     // 16 x 16 blocks (v_mfma_f32_16x16x32_bf16, 3 workgroups/CU): the 16-channel layers, and -- a grid of such blocks,
     // transpose-read kernel only -- the layers with <= 16 output channels on 32 input channels (dec.out1 32->2,
     // dec.convu1.conv2 32->16, rec.convu1.conv1 32->16), which would leave half of every 32 x 32 block's rows empty
-    if (sizeof(T) == 2 && p.Cout <= 16 && (p.Cin <= 16 || (p.Cin <= 32 && wgrad_pf_ok(p) && rd_switch("RD_WG_TR_OFF", 0) == 0 && rd_switch("RD_WG_C16_GRID", 1) != 0))) {
+    if (sizeof(T) == 2 && p.Cout <= 16 && p.Cin <= (rd_switch("RD_WG_C16_GRID", 1) ? 32 : 16) && wgrad_pf_ok(p) && rd_switch("RD_WG_TR_OFF", 0) == 0) {
         g.c16 = true;
         g.MB = g.NB = 1;                                   // blocks per WORKGROUP
         g.KS = 4;
@@ -1152,28 +657,17 @@ int launch_wgrad(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int TAPS, int MB, int NB>
+template <int TAPS>
 int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    constexpr int PH = TH + 2 * HALO;
-    constexpr int PWL = (TAPS == 9) ? 40 : 32;
-    size_t lds = (size_t)(NB * 16 * (PH * PWL + 8) + MB * 16 * (TH * TW + 8)) * 2;
-    const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * TAPS * 4 * 64 * sizeof(float);
+    dim3 grid(g.gx, g.CoutPadW / 16, g.CinPadW / 16);
+    size_t lds = (size_t)((TH + 2 * HALO) * (TW + 2 * HALO) + 4) * 48 + (size_t)TH * TW * 48;
+    const size_t lds_red = (size_t)3 * TAPS * 4 * 64 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
-    dim3 grid(g.gx, g.CoutPadW / (MB * 16), g.CinPadW / (NB * 16));
-    static const bool tr_off = rd_switch("RD_WG_TR_OFF", 0) != 0;
-    if (wgrad_pf_ok(p) && !tr_off) {
-        size_t l2 = (size_t)((TH + 2 * HALO) * (TW + 2 * HALO) + 4) * 48 + (size_t)TH * TW * 48;
-        const size_t l2red = (size_t)3 * TAPS * 4 * 64 * sizeof(float);
-        if (l2 < l2red) l2 = l2red;
-        if (p.dz.mode == RD_SRC_BNBWD)
-            hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 2>), grid, dim3(256), l2, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
-        else
-            hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 1>), grid, dim3(256), l2, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
-        return (int)hipGetLastError();
-    }
-    // (a tile-ahead prefetch variant of this kernel, PF = true, measured slower: 2 workgroups/CU worth of registers)
-    hipLaunchKernelGGL((wgrad_c16_kernel<TAPS, MB, NB, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    if (p.dz.mode == RD_SRC_BNBWD)
+        hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 2>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    else
+        hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 1>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
     return (int)hipGetLastError();
 }
 
@@ -1204,52 +698,23 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int TAPS, int MB, int NB, int TS>
-int launch_wgrad_t_ts(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
-    constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    constexpr int PH = TH + 2 * HALO;
-    constexpr int PWL = (TAPS == 9) ? 40 : 32;
-    size_t lds = (size_t)(NB * 32 * (PH * PWL + 8) + MB * 32 * (TH * TW + 8)) * 2;
-    const size_t lds_red = (size_t)TS * (4 / (MB * NB) - 1) * (MB * NB) * 16 * 64 * sizeof(float);
-    if (lds < lds_red) lds = lds_red;
-    dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_t_kernel<TAPS, MB, NB, false, TS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    static const bool tr_off = rd_switch("RD_WG_TR_OFF", 0) != 0;
-    // the transpose-read kernel needs whole 16-byte channel slots in every source (its generic fill covers pooled
-    // / interpolated ones); ragged channel counts stay on the transposing-store kernel below
-    if (!tr_off && wgrad_slots_ok(p)) return launch_wgrad_tr<TAPS, MB, NB>(p, g, st);
-    // (its tile-ahead prefetch form, PF = true, and the 12-wave form, TS = 3, are superseded by wgrad_tr_kernel: not instantiated)
-    hipLaunchKernelGGL((wgrad_t_kernel<TAPS, MB, NB, false, TS>), grid, dim3(256 * TS), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
-    return (int)hipGetLastError();
-}
-
-// TS = 3 (12 waves, one kernel row per group of 4) measured slower than TS = 1 on every layer of the U-Net at
-// 400x400 (the 170-register cap spills, and the fill is still one lock-step phase): kept in the kernel, not instantiated
-template <int TAPS, int MB, int NB>
-int launch_wgrad_t(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
-    return launch_wgrad_t_ts<TAPS, MB, NB, 1>(p, g, st);
-}
-
 template <typename T>
 int dispatch_wgrad(const rd_wgrad_t& p, hipStream_t st) {
     const WgradGeom g = wgrad_geom<T>(p);
     int e;
     if (g.c16) {
-        e = p.taps == 9 ? launch_wgrad_c16<9, 1, 1>(p, g, st) : launch_wgrad_c16<1, 1, 1>(p, g, st);
-    } else if constexpr (sizeof(T) == 2) {
+        e = p.taps == 9 ? launch_wgrad_c16<9>(p, g, st) : launch_wgrad_c16<1>(p, g, st);
+    } else if (sizeof(T) == 2 && wgrad_slots_ok(p) && rd_switch("RD_WG_TR_OFF", 0) == 0) {
+        // bf16, every source made of whole 16-byte channel slots: [pixel][channel] LDS tiles + ds_read_b64_tr_b16
 #define RD_WGT(TAPS_)                                                                \
-    if (g.MB == 2 && g.NB == 2) e = launch_wgrad_t<TAPS_, 2, 2>(p, g, st);           \
-    else if (g.MB == 2) e = launch_wgrad_t<TAPS_, 2, 1>(p, g, st);                   \
-    else if (g.NB == 2) e = launch_wgrad_t<TAPS_, 1, 2>(p, g, st);                   \
-    else e = launch_wgrad_t<TAPS_, 1, 1>(p, g, st);
+    if (g.MB == 2 && g.NB == 2) e = launch_wgrad_tr<TAPS_, 2, 2>(p, g, st);          \
+    else if (g.MB == 2) e = launch_wgrad_tr<TAPS_, 2, 1>(p, g, st);                  \
+    else if (g.NB == 2) e = launch_wgrad_tr<TAPS_, 1, 2>(p, g, st);                  \
+    else e = launch_wgrad_tr<TAPS_, 1, 1>(p, g, st);
         if (p.taps == 9) { RD_WGT(9) } else { RD_WGT(1) }
 #undef RD_WGT
     } else {
+        // fp32, and bf16 with ragged channel counts (e.g. a 3-channel image that is not padded to a slot)
 #define RD_WG(TAPS_)                                                                 \
     if (g.MB == 2 && g.NB == 2) e = launch_wgrad<T, TAPS_, 2, 2>(p, g, st);          \
     else if (g.MB == 2) e = launch_wgrad<T, TAPS_, 2, 1>(p, g, st);                  \

@@ -16,6 +16,7 @@ import argparse
 import os
 import os.path as osp
 import random
+import time
 import sys
 from itertools import cycle
 
@@ -187,6 +188,7 @@ def main(args):
                            dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
 
     previous_best, iter_num = 0.0, 0
+    t_mark, it_mark, imgs_per_iter = None, 0, world * sum(bsl[:len(domain_idx_list)])
     for epoch in range(args.epochs):
         if rank == 0:
             print('\n==> Epoch %i, learning rate = %.6f' % (epoch, args.lr if iter_num == 0 else trainer.lr()))
@@ -207,8 +209,16 @@ def main(args):
                 print('iter %d lr %.6f ' % (iter_num, trainer.lr()) + ' '.join('%s %.4f' % (k, v) for k, v in l.items() if k != 'rec')
                       + ' loss_rec %.4f' % (sum(l['rec']) / 4))               # train.py:304 logs avg/4
             iter_num += 1
+            if iter_num == 5:                           # end-to-end throughput (files -> DataLoader -> H2D -> step), start-up excluded
+                torch.cuda.synchronize()
+                t_mark, it_mark = time.time(), iter_num
             if args.max_iters and iter_num >= args.max_iters:
                 break
+        if t_mark is not None and iter_num > it_mark:
+            torch.cuda.synchronize()
+            if rank == 0:
+                print('train throughput: %.1f images/s end to end (%d iterations of %d images, %d DataLoader workers per domain)'
+                      % ((iter_num - it_mark) * imgs_per_iter / (time.time() - t_mark), iter_num - it_mark, imgs_per_iter, args.num_workers))
         # validation on the held-out domain + keep-best checkpoint rotation (train.py:331-350); skipped when the
         # evaluation data is not on disk (synthetic / smoke runs)
         avg_dice = None

@@ -293,7 +293,7 @@ def gen_losses(ref_losses):
 
 
 # ------------------------------------------------------------------------------------------ full steps
-def gen_steps(RU, ref_losses):
+def gen_steps(RU, ref_losses, only64=False):
     from torch.nn import BCELoss, KLDivLoss, MSELoss, CrossEntropyLoss
     from torch.optim import Adam
 
@@ -303,7 +303,10 @@ def gen_steps(RU, ref_losses):
 
     for dataset, bsl, S, ncls, cons in (('fundus', [2, 3, 3], 32, 2, 'kd'),
                                         ('fundus_mse', [1, 2, 1], 32, 2, 'mse'),
-                                        ('prostate', [2, 2, 2, 2, 2], 32, 2, 'kd')):
+                                        ('prostate', [2, 2, 2, 2, 2], 32, 2, 'kd'),
+                                        ('fundus64', [2, 3, 3], 64, 2, 'kd')):       # 4x4-pixel bottleneck: tighter gradient checks
+        if only64 and dataset != 'fundus64':
+            continue
         out = {}
         nd = len(bsl)
         B = sum(bsl)
@@ -537,7 +540,7 @@ def gen_metrics(ref_root):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
-    ap.add_argument('--only', default='', help='comma list of fixture groups (ram,masks,losses,blocks,modules,steps,sampling,metrics,dsbn)')
+    ap.add_argument('--only', default='', help='comma list of fixture groups (ram,masks,losses,blocks,modules,steps,steps64,sampling,metrics,dsbn)')
     args = ap.parse_args()
     only = set(filter(None, args.only.split(',')))
     sys.path.insert(0, os.path.join(args.ref, 'code'))
@@ -558,8 +561,8 @@ def main():
         gen_blocks(RU)
     if want('modules'):
         gen_modules(RU)
-    if want('steps'):
-        gen_steps(RU, ref_losses)
+    if want('steps') or want('steps64'):
+        gen_steps(RU, ref_losses, only64=not want('steps'))
     if want('sampling'):
         gen_sampling(ref_fundus, ref_prostate, ref_transform)
     if want('metrics'):

@@ -23,6 +23,9 @@ DEV = 'cuda:0'
 # Full-step checks therefore use relative L2 <= 4e-2; the smooth-activation test below (slope=1, no ReLU
 # kinks) holds the same composition to 2e-3, and tests/test_gpu_ops.py holds every kernel to 2e-5.
 REL_L2_STEP = 4e-2
+# ... and the 64x64 fixture (4x4-pixel bottleneck, BatchNorm batches of >= 32 values) to 2.5e-2 (runs give 1.2e-2 .. 1.7e-2); at the benchmark sizes
+# tests/test_gpu_fullsize.py holds every gradient to the reference's own noise floor (<= 2e-2 worst, 6e-3 median).
+REL_L2_BY_FIXTURE = {'fundus64': 2.5e-2}
 
 
 def rel_l2(got, ref):
@@ -49,9 +52,10 @@ def _feed(ts, G, it):
     ts.load_target(T(G['s%d.mask' % it]).to(DEV))
 
 
-@pytest.mark.parametrize('name', ['fundus', 'fundus_mse', 'prostate'])
+@pytest.mark.parametrize('name', ['fundus', 'fundus_mse', 'prostate', 'fundus64'])
 def test_step_fp32_matches_reference_fixture(golden_dir, name):
     G, meta, states, bank, mods, ts = _setup(golden_dir, name, torch.float32)
+    REL_L2_STEP = REL_L2_BY_FIXTURE.get(name, globals()['REL_L2_STEP'])
     _feed(ts, G, 0)
     ts.step()
     torch.cuda.synchronize()
