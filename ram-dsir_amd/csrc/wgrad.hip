@@ -622,8 +622,8 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     }
     const int cout32 = (p.Cout + 31) / 32, cin32 = (p.Cin + 31) / 32;
     // fp32 keeps 32x32 blocks (LDS budget); bf16 uses 64-wide tiles where the layer has them
-    g.MB = (sizeof(T) == 2 && cout32 % 2 == 0) ? 2 : 1;
-    g.NB = (sizeof(T) == 2 && cin32 % 2 == 0) ? 2 : 1;
+    g.MB = (sizeof(T) == 2 && cout32 % 2 == 0 && rd_switch("RD_WG_MB_MAX", 2) >= 2) ? 2 : 1;
+    g.NB = (sizeof(T) == 2 && cin32 % 2 == 0 && rd_switch("RD_WG_NB_MAX", 2) >= 2) ? 2 : 1;
     g.KS = 4 / (g.MB * g.NB);
     g.CoutPadW = cout32 * 32;
     g.CinPadW = cin32 * 32;
@@ -631,7 +631,7 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     const int pairs = (g.CoutPadW / (g.MB * 32)) * (g.CinPadW / (g.NB * 32));
     // these kernels hold 144 accumulator registers per lane -> one workgroup per CU is resident: launching more
     // workgroups than CUs only multiplies the partial-sum traffic (147 KB per workgroup for a 64x64 tile)
-    int gx = (256 + pairs - 1) / pairs;
+    int gx = (rd_switch("RD_WG_SLOTS", 256) + pairs - 1) / pairs;
     if (gx > g.total_tiles) gx = g.total_tiles;
     if (gx < 1) gx = 1;
     g.gx = gx;

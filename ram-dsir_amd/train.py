@@ -160,8 +160,12 @@ def main(args):
         # consumes world x the reference's batch and an epoch is 1/world as many iterations; RAM partners / lambda / crops
         # are drawn rank-locally (workers are seeded from seed + rank).  Single process: exactly the reference's loaders.
         sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=args.seed, drop_last=True) if world > 1 else None
+        # the reference's loader settings (train.py:558-559) + persistent workers with a deeper queue: the reference respawns its
+        # 3 x 8 worker processes at every epoch, which costs seconds per 53-iteration epoch -- invisible next to its step time,
+        # 20x the step time here (profiles/README.md, end-to-end throughput)
+        extra = dict(persistent_workers=True, prefetch_factor=4) if args.num_workers > 0 else {}
         dl = DataLoader(ds, batch_size=bsl[idx], num_workers=args.num_workers, shuffle=sampler is None, sampler=sampler, drop_last=True,
-                        pin_memory=True, worker_init_fn=seed_worker)
+                        pin_memory=True, worker_init_fn=seed_worker, **extra)
         raw.append(dl)
         samplers.append(sampler)
         loaders.append(cycle(dl))                       # train.py:560: replays the first pass of the shorter loaders

@@ -16,14 +16,14 @@ sys.path[:0] = [os.path.join(ROOT, 'tests')]
 import synth_data as SD
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--n', type=int, default=48)
-ap.add_argument('--iters', type=int, default=120)
+ap.add_argument('--n', type=int, default=160)            # 160 / 3 = 53 iterations per epoch, like the real lists (train.py:210)
+ap.add_argument('--iters', type=int, default=270)
 ap.add_argument('--workers', type=int, default=8)
 ap.add_argument('--dtype', default='bf16')
 a = ap.parse_args()
 with tempfile.TemporaryDirectory() as tmp:
     t0 = time.time()
-    SD.make_fundus_tree(tmp, n_train=a.n, n_test=2, hw=(800, 800))
+    SD.make_fundus_tree(tmp, n_train=a.n, n_test=8, hw=(800, 800), vary=False)
     print('tree: 4 domains x %d train PNGs of ~800x800 in %.1f s' % (a.n, time.time() - t0), flush=True)
     cmd = [sys.executable, os.path.join(ROOT, 'ram-dsir_amd', 'train.py'), '--data_root', tmp, '--dataset', 'fundus', '--domain_idxs', '1,2,3',
            '--test_domain_idx', '0', '--ram', '--rec', '--is_out_domain', '--consistency', '--consistency_type', 'kd', '--save_path',

@@ -33,7 +33,9 @@ def _disc_mask(rng, h, w):
     return m
 
 
-def make_fundus_tree(root, n_train=4, n_test=2, hw=(280, 300), seed=20221):
+def make_fundus_tree(root, n_train=4, n_test=2, hw=(280, 300), seed=20221, vary=True):
+    """vary=True: every file gets its own size (h + 8 d, w - 4 i) -- exercises Resize; vary=False: all hw (the real ROIs are all
+    800x800, and the test dataset's native-size masks must collate)."""
     rng = np.random.RandomState(seed)
     base = os.path.join(root, 'fundus')
     h, w = hw
@@ -45,8 +47,9 @@ def make_fundus_tree(root, n_train=4, n_test=2, hw=(280, 300), seed=20221):
             for i in range(n):
                 ri = 'Domain%d/%s/ROIs/image/d%d_%s_%02d.png' % (d, split, d, split, i)
                 rm = ri.replace('/image/', '/mask/')
-                Image.fromarray(_smooth_rgb(rng, h + 8 * d, w - 4 * i)).save(os.path.join(base, ri))
-                Image.fromarray(_disc_mask(rng, h + 8 * d, w - 4 * i)).save(os.path.join(base, rm))
+                hh, ww = (h + 8 * d, w - 4 * i) if vary else (h, w)
+                Image.fromarray(_smooth_rgb(rng, hh, ww)).save(os.path.join(base, ri))
+                Image.fromarray(_disc_mask(rng, hh, ww)).save(os.path.join(base, rm))
                 lines.append(ri + ' ' + rm)
                 partner.append(ri.split('/', 1)[1] + ' ' + rm.split('/', 1)[1])
             with open(os.path.join(base, 'Domain%d_%s.list' % (d, split)), 'w') as f:
