@@ -62,6 +62,23 @@ def postprocessing(prediction, threshold=0.5, dataset='G'):
     return out
 
 
+def postprocess_binary(mask_u8):
+    """postprocessing() after the threshold: largest 8-connected component + hole filling per channel, disc (1) then cup (0)
+    like utils/utils.py:81-89.  mask_u8: (2, H, W) uint8 0/1."""
+    out = np.array(mask_u8, dtype=np.uint8)
+    out[1] = get_largest_fillhole(out[1]).astype(np.uint8)
+    out[0] = get_largest_fillhole(out[0]).astype(np.uint8)
+    return out
+
+
+def post_and_dice(args):
+    """(thresholded prediction (2,H,W) uint8, target (2,H,W) uint8) -> (cup dice, disc dice): one validation image
+    (train.py:116-118); a top-level function so that a process pool can run the images of a batch in parallel."""
+    mask_u8, target_u8 = args
+    post = postprocess_binary(mask_u8)
+    return dice_coefficient_numpy(post[0], target_u8[0]), dice_coefficient_numpy(post[1], target_u8[1])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # medpy.metric.binary restated.  The reference imports `medpy` (test_fundus_slice.py:19,125-136,
 # test_prostate_volume.py:14,121-126, utils/metrics.py:2,20; no version pinned, the package is not vendored and not

@@ -31,5 +31,5 @@ with tempfile.TemporaryDirectory() as tmp:
            '--dtype', a.dtype]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     out = r.stdout.decode()
-    print('\n'.join(l for l in out.splitlines() if 'throughput' in l or 'iter ' in l or 'Error' in l or 'error' in l)[-3000:])
+    print('\n'.join(l for l in out.splitlines() if 'throughput' in l or 'epoch ' in l or 'Error' in l or 'error' in l)[-3000:])
     sys.exit(r.returncode)
