@@ -2,9 +2,9 @@
 // per tile, plain per-pixel sources).  Same implicit GEMM, tile (8 x 32 pixels x 64 channels) and MFMA
 // (v_mfma_f32_32x32x16_bf16) as conv_pf_kernel (conv_pf.h); what changes is WHEN things happen:
 //
-//   * ONE workgroup per CU (4 wave64, one per SIMD, up to 512 VGPRs), persistent over a contiguous range of tiles
-//     (MODE 0: output-channel block fastest, so the blocks of one pixel tile re-read it from this XCD's L2; MODE 1/2:
-//     channel block slowest, so the BatchNorm sums of a block stay in registers across its tiles);
+//   * ONE workgroup per CU, persistent over a contiguous range of tiles (conv_pp_kernel: output-channel block fastest,
+//     so the blocks of one pixel tile re-read it from this XCD's L2; conv_ws_kernel: channel block slowest, so the
+//     BatchNorm sums of a block stay in registers across its tiles);
 //   * the (tile, 32-channel chunk) pairs of that range form one stream of STEPS.  While the MFMAs of step s run out
 //     of LDS buffer s&1, the same waves transform the raw vectors of step s+1 (BN affine + activation, bf16 pack)
 //     into buffer (s+1)&1 and request the vectors of step s+2 from HBM/L2 -- item by item, placed BETWEEN the MFMA
@@ -16,8 +16,8 @@
 //
 // conv_pf_kernel runs the same work as fill -> barrier -> MFMA -> barrier with two workgroups per CU (fill VALU and MFMA
 // of one wave never overlap, LDS reads are waited for right before their MFMA, every tile starts with an exposed HBM
-// round trip).  Measured (profiles/README.md): this kernel wins on forward launches with >= 3 tiles
-// per CU (64->64 @200x200: 121 -> 97 us) and loses elsewhere, so rd_conv_pp_dispatch only takes those by default.
+// round trip).  Two kernels live here: conv_pp_kernel (4 waves, every wave does everything, LDS-staged epilogue) and
+// conv_ws_kernel (8 waves, MFMA waves + loader waves, register epilogues); rd_conv_pp_dispatch says which launch takes which.
 #include "conv_device.h"
 #include "conv_epilogue.h"
 #include "conv_dispatch.h"
@@ -107,18 +107,8 @@ __device__ __forceinline__ void pp_advance(PpStage& s, const PpGeo& q, const Gro
     }
 }
 
-// LEAN = forward launches: the MFMA roles are swapped (A = weights, B = pixels), so a lane ends up with ONE pixel and
-// 16 output channels per 32-channel block, regroups them with v_permlane32_swap into 16-byte NHWC vectors and stores
-// them straight from registers; the BatchNorm sums stay in registers across the tiles of a (channel block, group) run.
-// Measured on dec.convu2.conv3 forward (64->64 at 200x200, 16 images): 157.7 us with the LDS-staged epilogue of
-// conv_epilogue.h (~3000 instructions per wave and tile, nothing to overlap them with at one workgroup per CU), 97 us
-// with this one; a throw-away build without any epilogue -- in which the compiler also drops the then-dead MFMA chain --
-// ran 42.3 us, i.e. loads + BN/ReLU fill + barriers of the whole K loop fit in that.
-// MODE: 0 = LDS-staged epilogue of conv_epilogue.h (any destination), 1 = LEAN forward, 2 = LEAN gradient (every
-// destination plain, whole 16-byte slots, c_split % 16 == 0): same register regrouping; the producer's raw tensor (for the
-// activation mask and sum g*z) and, for accumulating destinations, the old gradient are requested at the start of the
-// tile's last K step and consumed after it.
-template <int MODE>
+// The epilogue is the LDS-staged one of conv_epilogue.h (any destination kind).  Launches that qualify for a register
+// epilogue (forward, gradient into plain tensors) go to conv_ws_kernel below instead.
 __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int tiles_total) {
     typedef bf16_t T;
     constexpr int S = 8;
@@ -133,8 +123,7 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
     q.tiles_x = (W + TW - 1) / TW;
     q.tiles_xy = q.tiles_x * ((H + TH - 1) / TH);
     q.nch = p.CinPad / 32;
-    constexpr bool LEAN = MODE != 0;
-    q.cb_slow = LEAN ? 1 : 0;
+    q.cb_slow = 0;
     q.n_img = p.N;
     const int tile_begin = (int)((long long)blockIdx.x * tiles_total / gridDim.x);
     q.tile_end = (int)((long long)(blockIdx.x + 1) * tiles_total / gridDim.x);
@@ -261,17 +250,326 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
     };
 
     f32x16 acc[2][2];
+    // ---- prologue: step 0 into buffer 0, step 1 requested
+    begin_issue();
+#pragma unroll
+    for (int b = 0; b < PP_NIT; ++b) issue_item(b);
+#pragma unroll
+    for (int t = 0; t < PP_WIT; ++t) issue_w(t);
+    shift_stages();                      // C = step 0, L = step 1
+    begin_issue();
+#pragma unroll
+    for (int b = 0; b < PP_NIT; ++b) { consume_item(b, 0); issue_item(b); }
+#pragma unroll
+    for (int t = 0; t < PP_WIT; ++t) { consume_w(t, 0); issue_w(t); }
+    M = Cs;
+    shift_stages();                      // C = step 1, L = step 2
+    __syncthreads();
 
-    // ---- LEAN: per-lane BatchNorm partial sums (sum, sum of squares of conv + bias, fp32) of the current (channel block,
-    //      group) run and that block's bias; a lane owns channels n0 + nb*32 + 16v + 8h + e of pixel column li
-    float sa[2][2][S], sb[2][2][S], bs[2][2][S];
+    for (int s = 0; s < nsteps; ++s) {
+        const int par = s & 1, nxt = par ^ 1;
+        if (M.c == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+        }
+        load_frags(0, par, fr[0]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) load_frags(t + 1, par, fr[(t + 1) & 1]);
+            const Frag& f = fr[t & 1];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[mb][ks]),
+                                                                              __builtin_bit_cast(bf16x8, f.b[nb][ks]), acc[mb][nb], 0, 0, 0);
+            // fill of step s+1 / requests of step s+2, one piece per tap
+            if (t == 0) begin_issue();
+            if (t >= 3) {
+                consume_item(t - 3, nxt);
+                issue_item(t - 3);
+            }
+            consume_w(t, nxt);
+            issue_w(t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (M.c == q.nch - 1) {
+            const int slot = (M.txy + 7 * M.n) % RD_STAT_SLOTS;
+            conv_epilogue<T, 2>(p, acc, smem + PP_EPI, tid, M.n, M.g, M.y0, M.x0, M.n0, slot);
+        }
+        M = Cs;
+        shift_stages();
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------ warp-specialised variant
+// conv_pp_kernel above is INSTRUCTION-ISSUE bound: one wave per SIMD carries ~13 non-MFMA instructions per MFMA (fill
+// transform, LDS fragment reads, address arithmetic), of which an in-order wave hides ~5 behind a 32-cycle
+// v_mfma_f32_32x32x16_bf16 (SQ counters, profiles/README.md round 2: 51% of the wave cycles issuing, 18% issue-stalled,
+// matrix pipe 26% busy).  Here the same step stream is split over TWO waves per SIMD with different jobs:
+//   waves 0-3 (MFMA waves):   LDS fragment reads + the 72 MFMAs of a step + the register epilogue  (~1.5 instr / MFMA)
+//   waves 4-7 (loader waves): global loads of step s+2, BN / activation transform + LDS fill of step s+1, weights
+// so that the VALU work of the fill issues from another wave while the matrix pipe runs.  Same LDS planes, same tile
+// order and the same arithmetic as conv_pp_kernel (bit-identical results); one barrier per step for all eight waves.
+// MODE 1 = forward, MODE 2 = gradient into plain destinations (the register epilogues; nothing else is launched here).
+// The loader's per-item cost is what bounds a step (s_memtime traces, scripts/ws_trace.py), so it is kept lean: halo
+// offsets and bounds are computed once per TILE, the affine runs as v_pk_fma_f32, ReLU as v_pk_max_i16 on the packed
+// bf16 pair (identical to ReLU before the rounding), raw sources are copied without touching the VALU.
+constexpr int WS_TAB = PP_EPI;                               // MODE 1: bias [CoutPad]; MODE 2: [G][2][CoutPad] producer scale | shift
+#ifdef RD_DEBUG_SWITCHES
+__device__ unsigned long long ws_trace[2][64][4];          // [role][step][event] shader-clock stamps of workgroup 5 (debug build)
+#define WS_T(role, s, ev) do { if (blockIdx.x == 5 && tid == 0 && (s) < 63) ws_trace[role][s][ev] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_T(role, s, ev) do { } while (0)
+#endif
+#if defined(RD_DEBUG_SWITCHES) && defined(RD_WS_EXP)         // timing experiments (results wrong): -DRD_WS_EXP + RD_CONV_WS_EXP=bits
+#define WS_EXP(bit) ((exp_ & (bit)) != 0)
+#else
+#define WS_EXP(bit) false
+#endif
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int tiles_total) {
+    typedef bf16_t T;
+    constexpr int S = 8;
+    static_assert(MODE == 1 || MODE == 2, "register epilogues only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // 0: MFMA waves, 1: loader waves
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+#ifdef RD_DEBUG_SWITCHES
+    const int exp_ = tiles_total >> 26;
+    tiles_total &= (1 << 26) - 1;
+#endif
+    PpGeo q;
+    q.ncb = p.CoutPad / PP_NT;
+    q.tiles_x = (W + TW - 1) / TW;
+    q.tiles_xy = q.tiles_x * ((H + TH - 1) / TH);
+    q.nch = p.CinPad / 32;
+    q.cb_slow = 1;
+    q.n_img = p.N;
+    const int tile_begin = (int)((long long)blockIdx.x * tiles_total / gridDim.x);
+    q.tile_end = (int)((long long)(blockIdx.x + 1) * tiles_total / gridDim.x);
+    const int nsteps = (q.tile_end - tile_begin) * q.nch;
+    if (nsteps <= 0) return;
+
+    // ---- tables: channel-slot descriptors of every chunk, bias / producer coefficients of every output channel
+    if ((int)threadIdx.x < q.nch * 4) {
+        const int t = threadIdx.x;
+        const int c = (t >> 2) * 32 + (t & 3) * S;
+        const int si = (p.nsrc == 1 || c < p.src[0].C) ? 0 : 1;
+        const rd_src_t sd = select_src(p.src, si);
+        const bool live = c < p.Cin, rawm = sd.mode == RD_SRC_RAW;
+        const int cc = live ? c - (si ? p.src[0].C : 0) : 0;
+        PpSlot e;
+        e.ptr = reinterpret_cast<const T*>(sd.ptr) + cc;
+        e.scale = rawm ? reinterpret_cast<const float*>(p.w) : sd.scale + cc;
+        e.shift = rawm ? reinterpret_cast<const float*>(p.w) : sd.shift + cc;
+        e.C = sd.C;
+        e.n_off = sd.n_off;
+        e.slope = sd.mode == RD_SRC_AFFACT ? sd.slope : 1.f;
+        e.g_fixed = rawm ? 0 : sd.g_fixed;
+        e.flags = (live ? 1 : 0) | (rawm ? 2 : 0);
+        e.pad_ = 0;
+        reinterpret_cast<PpSlot*>(smem + PP_TAB)[t] = e;
+    }
+    {
+        float* tab = reinterpret_cast<float*>(smem + WS_TAB);
+        if constexpr (MODE == 1) {
+            for (int c = threadIdx.x; c < p.CoutPad; c += 512) tab[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+        } else {
+            for (int i = threadIdx.x; i < p.G * p.CoutPad; i += 512) {
+                const int g = i / p.CoutPad, c = i - g * p.CoutPad;
+                const int di = c >= p.c_split ? 1 : 0;
+                const rd_dst_t d = select_dst(p, di);
+                const int cd = c - (di ? p.c_split : 0);
+                const bool ok = c < p.Cout && d.kind != RD_DST_NONE && d.scale != nullptr && cd < d.Cd;
+                const int gd = d.g_fixed >= 0 ? d.g_fixed : g;
+                tab[(g * 2 + 0) * p.CoutPad + c] = ok ? d.scale[gd * d.Cd + cd] : 1.f;
+                tab[(g * 2 + 1) * p.CoutPad + c] = ok ? d.shift[gd * d.Cd + cd] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    if (role == 1) {
+        // =============================================================================== loader waves
+        const int sw = tid & 3, nn_w = tid >> 2;
+        int it_yx[PP_NIT], it_lds[PP_NIT];
+#pragma unroll
+        for (int b = 0; b < PP_NIT; ++b) {
+            const int pix = (tid >> 2) + 64 * b;
+            const int py = pix / PP_PW;
+            it_yx[b] = (py << 16) | (pix - py * PP_PW);
+            it_lds[b] = sw * PP_PLANE_A + (pix < PP_NPIX ? pix : PP_NPIX) * 16;
+        }
+        const int w_lds = PP_W0 + sw * PP_PLANE_W + nn_w * 16;
+        const T* wbase = reinterpret_cast<const T*>(p.w) + nn_w * 32 + sw * S;
+        const size_t w_tap = (size_t)p.CoutPad * 32;            // elements between the taps of one chunk
+        uint4 raw[PP_NIT] = {}, wr[PP_WIT] = {};
+        float scC[S], shC[S], scL[S], shL[S];
+        float slopeC = 1.f, slopeL = 1.f;
+        bool copyC = false, copyL = false;   // raw source without activation: the 16 bytes go to LDS as they are
+        const T* ldbase = nullptr;
+        int ldC = 0;
+        int offL[PP_NIT];                    // stage L's tile: pixel index (clamped into the image) of each halo item
+        int inL = 0, inC = 0;                // bit b: halo item b lies inside the image (and this slot carries a channel)
+        PpStage L, Cs;
+        L.tile = tile_begin;
+        L.c = 0;
+        pp_decode(L, q, gm);
+        auto tile_geom = [&]() {
+            inL = 0;
+#pragma unroll
+            for (int b = 0; b < PP_NIT; ++b) {
+                const int y = L.y0 - 1 + (it_yx[b] >> 16), x = L.x0 - 1 + (it_yx[b] & 0xffff);
+                inL |= (((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W)) ? (1 << b) : 0;
+                offL[b] = min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+            }
+        };
+        int maskL = 0;
+        auto begin_issue = [&]() {
+            const PpSlot e = reinterpret_cast<const PpSlot*>(smem + PP_TAB)[L.c * 4 + sw];
+            const bool live = (e.flags & 1) != 0, rawm = (e.flags & 2) != 0;
+            maskL = live ? inL : 0;
+            ldC = e.C;
+            ldbase = e.ptr + (size_t)(L.n + e.n_off) * H * W * e.C;
+            slopeL = e.slope;
+            copyL = rawm && e.slope == 1.f;
+            const int g = e.g_fixed >= 0 ? e.g_fixed : L.g;
+            const float* sp = e.scale + (rawm ? 0 : g * e.C);
+            const float* hp = e.shift + (rawm ? 0 : g * e.C);
+            const float4 a0 = ldf4g(sp), a1 = ldf4g(sp + 4), b0 = ldf4g(hp), b1 = ldf4g(hp + 4);
+            scL[0] = a0.x; scL[1] = a0.y; scL[2] = a0.z; scL[3] = a0.w; scL[4] = a1.x; scL[5] = a1.y; scL[6] = a1.z; scL[7] = a1.w;
+            shL[0] = b0.x; shL[1] = b0.y; shL[2] = b0.z; shL[3] = b0.w; shL[4] = b1.x; shL[5] = b1.y; shL[6] = b1.z; shL[7] = b1.w;
+#pragma unroll
+            for (int e2 = 0; e2 < S; ++e2) {
+                scL[e2] = rawm ? 1.f : scL[e2];
+                shL[e2] = rawm ? 0.f : shL[e2];
+            }
+        };
+        auto issue_item = [&](int b) {
+            if (!WS_EXP(2)) raw[b] = ld16g(ldbase + (size_t)(unsigned)offL[b] * (unsigned)ldC);
+        };
+        const T* wptr = nullptr;
+        auto begin_w = [&]() { wptr = wbase + ((size_t)(L.c * 9) * p.CoutPad + L.n0) * 32; };
+        auto issue_w = [&](int t) {
+            if (!WS_EXP(1)) wr[t] = ld16(wptr + t * w_tap);
+        };
+        int maskC = 0;
+        // XFORM is wave-uniform (a ballot over the wave's slots): false = every slot of this step is a plain copy
+        auto consume_item = [&](int b, int par, bool xform) {
+            uint4 u = raw[b];
+            if (xform) {
+                float v[S];
+                Slot<T>::unpack(u, v);
+#pragma unroll
+                for (int e = 0; e < S; ++e) v[e] = act_fn(scC[e] * v[e] + shC[e], slopeC);
+                u = Slot<T>::pack(v);
+            }
+            const bool in = ((maskC >> b) & 1) != 0;
+            *reinterpret_cast<uint4*>(smem + par * PP_IN_BYTES + it_lds[b]) = in ? u : make_uint4(0, 0, 0, 0);
+        };
+        auto consume_w = [&](int t, int par) {
+            *reinterpret_cast<uint4*>(smem + par * PP_W_BYTES + w_lds + t * (PP_NT * 16)) = wr[t];
+        };
+        auto shift_stages = [&]() {
+            Cs = L;
+            maskC = maskL;
+            slopeC = slopeL;
+            copyC = copyL;
+#pragma unroll
+            for (int e = 0; e < S; ++e) { scC[e] = scL[e]; shC[e] = shL[e]; }
+            const int tile0 = L.tile;
+            pp_advance(L, q, gm);
+            if (L.tile != tile0) tile_geom();
+        };
+        // prologue: step 0 into buffer 0, step 1 requested
+        tile_geom();
+        begin_issue();
+        begin_w();
+#pragma unroll
+        for (int b = 0; b < PP_NIT; ++b) raw[b] = ld16g(ldbase + (size_t)(unsigned)offL[b] * (unsigned)ldC);
+#pragma unroll
+        for (int t = 0; t < PP_WIT; ++t) wr[t] = ld16(wptr + t * w_tap);
+        shift_stages();
+        begin_issue();
+        begin_w();
+#pragma unroll
+        for (int b = 0; b < PP_NIT; ++b) { consume_item(b, 0, true); raw[b] = ld16g(ldbase + (size_t)(unsigned)offL[b] * (unsigned)ldC); }
+#pragma unroll
+        for (int t = 0; t < PP_WIT; ++t) { consume_w(t, 0); wr[t] = ld16(wptr + t * w_tap); }
+        shift_stages();
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int nxt = (s & 1) ^ 1;
+            if (WS_EXP(8)) { __syncthreads(); continue; }
+            WS_T(1, s, 0);
+            begin_issue();
+            begin_w();
+            if (__builtin_amdgcn_ballot_w64(!copyC) != 0) {
+#pragma unroll
+                for (int b = 0; b < PP_NIT; ++b) { consume_item(b, nxt, true); issue_item(b); }
+            } else {
+#pragma unroll
+                for (int b = 0; b < PP_NIT; ++b) { consume_item(b, nxt, false); issue_item(b); }
+            }
+            WS_T(1, s, 1);
+#pragma unroll
+            for (int t = 0; t < PP_WIT; ++t) { consume_w(t, nxt); issue_w(t); }
+            WS_T(1, s, 2);
+            shift_stages();
+            __syncthreads();
+            WS_T(1, s, 3);
+        }
+        return;
+    }
+
+    // =================================================================================== MFMA waves
+    const int a_base = h * PP_PLANE_A + (wave * 2 * PP_PW + li) * 16;
+    const int b_base = PP_W0 + h * PP_PLANE_W + li * 16;
+    const float* tab = reinterpret_cast<const float*>(smem + WS_TAB);
+    PpStage M;
+    M.tile = tile_begin;
+    M.c = 0;
+    pp_decode(M, q, gm);
+
+    // operand fragments of one (tap, k-step) group: A = 2 x (32 pixels x 16 channels), B = 2 x (32 outputs x 16 channels);
+    // the next group is read while the four MFMAs of this one run (register double buffer at group granularity)
+    struct Frag { uint4 a[2], b[2]; };
+    Frag fr[2];
+    auto load_group = [&](int grp, int par, Frag& f) {
+        const int tap = grp >> 1, ks = grp & 1;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const char* s_a = smem + par * PP_IN_BYTES + a_base + ks * 2 * PP_PLANE_A;
+        const char* s_b = smem + par * PP_W_BYTES + b_base + ks * 2 * PP_PLANE_W;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) f.a[mb] = *reinterpret_cast<const uint4*>(s_a + ((mb + kh) * PP_PW + kw) * 16);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) f.b[nb] = *reinterpret_cast<const uint4*>(s_b + (tap * PP_NT + nb * 32) * 16);
+    };
+
+    f32x16 acc[2][2];
+    // per-lane BatchNorm partial sums of the current (channel block, group) run; a lane owns channels
+    // n0 + nb*32 + 16v + 8h + e of pixel column li
+    float sa[2][2][S], sb[2][2][S];
     int cur_n0 = -1, cur_g = -1;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
-            for (int e = 0; e < S; ++e) sa[nb][v][e] = sb[nb][v][e] = bs[nb][v][e] = 0.f;
+            for (int e = 0; e < S; ++e) sa[nb][v][e] = sb[nb][v][e] = 0.f;
     auto flush_stats = [&]() {
         if (cur_n0 < 0) return;
         const int slot = blockIdx.x % RD_STAT_SLOTS;
@@ -307,22 +605,16 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
                     sa[nb][v][e] = sb[nb][v][e] = 0.f;
                 }
     };
-
-    // ---- MODE 2: producer BN coefficients of the destinations (bs = scale, dsh = shift) and the prefetched operands
-    float dsh[2][2][S];
-    uint4 zq[2][2][2], gq[2][2][2];
+    // MODE 2: the producer's raw tensor of this tile (activation mask, sum g*z), requested at the start of its last K step;
+    // the old gradient of an accumulating destination (skip connections: few launches) is read in the epilogue itself --
+    // prefetching it too costs 16 more registers, which spill at two waves per SIMD
+    uint4 zq[2][2][2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                zq[mb][nb][v] = gq[mb][nb][v] = make_uint4(0, 0, 0, 0);
-                if (mb == 0) {
-#pragma unroll
-                    for (int e = 0; e < S; ++e) dsh[nb][v][e] = 0.f;
-                }
-            }
+            for (int v = 0; v < 2; ++v) zq[mb][nb][v] = make_uint4(0, 0, 0, 0);
     auto dst_index = [&](const rd_dst_t& d, int di, int nb, int v, int y, int x) -> size_t {
         const int cd = M.n0 + nb * 32 + 16 * v - (di ? p.c_split : 0) + 8 * h;
         return ((size_t)((M.n + d.n_off) * H + y) * W + x) * d.Cd + cd;
@@ -340,29 +632,26 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
                     if (d.kind == RD_DST_NONE) continue;
                     const size_t idx = dst_index(d, di, nb, v, y, x);
                     if (d.z) zq[mb][nb][v] = ld16(reinterpret_cast<const T*>(d.z) + idx);
-                    if (d.accumulate) gq[mb][nb][v] = ld16(reinterpret_cast<const T*>(d.g) + idx);
                 }
         }
     };
+    // one accumulator block's 16 channels of a lane's pixel as two 8-channel NHWC vectors
+    auto regroup = [&](const f32x16& a, int v, float* o) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[8 * v + j]), __float_as_uint(a[8 * v + 4 + j]), false, false);
+            o[j] = __uint_as_float(r[0]);
+            o[4 + j] = __uint_as_float(r[1]);
+        }
+    };
 
-    // ---- prologue: step 0 into buffer 0, step 1 requested
-    begin_issue();
-#pragma unroll
-    for (int b = 0; b < PP_NIT; ++b) issue_item(b);
-#pragma unroll
-    for (int t = 0; t < PP_WIT; ++t) issue_w(t);
-    shift_stages();                      // C = step 0, L = step 1
-    begin_issue();
-#pragma unroll
-    for (int b = 0; b < PP_NIT; ++b) { consume_item(b, 0); issue_item(b); }
-#pragma unroll
-    for (int t = 0; t < PP_WIT; ++t) { consume_w(t, 0); issue_w(t); }
-    M = Cs;
-    shift_stages();                      // C = step 1, L = step 2
-    __syncthreads();
-
+#ifdef RD_DEBUG_SWITCHES
+    if (blockIdx.x == 5 && tid == 0) { ws_trace[0][63][0] = __builtin_readcyclecounter(); ws_trace[0][63][1] = wall_clock64(); }
+#endif
+    __syncthreads();                     // buffer 0 filled (the loader waves' prologue)
     for (int s = 0; s < nsteps; ++s) {
-        const int par = s & 1, nxt = par ^ 1;
+        const int par = s & 1;
+        WS_T(0, s, 0);
         if (M.c == 0) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -374,145 +663,101 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
         if constexpr (MODE == 2) {
             if (M.c == q.nch - 1) dgrad_prefetch();
         }
-        load_frags(0, par, fr[0]);
+        load_group(0, par, fr[0]);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (t + 1 < 9) load_frags(t + 1, par, fr[(t + 1) & 1]);
-            const Frag& f = fr[t & 1];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+        for (int grp = 0; grp < 18; ++grp) {
+            if (grp + 1 < 18 && !WS_EXP(64)) load_group(grp + 1, par, fr[(grp + 1) & 1]);
+            const Frag& f = fr[grp & 1];
+            if (!WS_EXP(4)) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
-                        if constexpr (LEAN)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[nb][ks]),
-                                                                                  __builtin_bit_cast(bf16x8, f.a[mb][ks]), acc[mb][nb], 0, 0, 0);
-                        else
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[mb][ks]),
-                                                                                  __builtin_bit_cast(bf16x8, f.b[nb][ks]), acc[mb][nb], 0, 0, 0);
-            // fill of step s+1 / requests of step s+2, one piece per tap
-            if (t == 0) begin_issue();
-            if (t >= 3) {
-                consume_item(t - 3, nxt);
-                issue_item(t - 3);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[nb]),
+                                                                              __builtin_bit_cast(bf16x8, f.a[mb]), acc[mb][nb], 0, 0, 0);
             }
-            consume_w(t, nxt);
-            issue_w(t);
             __builtin_amdgcn_sched_barrier(0);
         }
+        WS_T(0, s, 1);
         if (M.c == q.nch - 1) {
+            if (M.n0 != cur_n0 || M.g != cur_g) {
+                flush_stats();
+                cur_n0 = M.n0;
+                cur_g = M.g;
+            }
+            const int y0r = M.y0 + wave * 2, x = M.x0 + li;
             if constexpr (MODE == 1) {
-                if (M.n0 != cur_n0 || M.g != cur_g) {
-                    flush_stats();
-                    cur_n0 = M.n0;
-                    cur_g = M.g;
+                T* out = reinterpret_cast<T*>(p.out) + ((size_t)(M.n * H + y0r) * W + x) * p.Cout + M.n0 + 8 * h;
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                        for (int v = 0; v < 2; ++v)
+                    for (int v = 0; v < 2; ++v) {
+                        // the bias vector of these 8 channels is read once for both tile rows of the wave
+                        const float* bp = tab + M.n0 + nb * 32 + 16 * v + 8 * h;
+                        const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+                        const float bs[S] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-                            for (int e = 0; e < S; ++e) bs[nb][v][e] = p.bias ? p.bias[M.n0 + nb * 32 + 16 * v + 8 * h + e] : 0.f;
-                }
-                T* out = reinterpret_cast<T*>(p.out);
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    const int y = M.y0 + wave * 2 + mb, x = M.x0 + li;
-                    const bool valid = y < H && x < W;
-                    T* orow = out + ((size_t)(M.n * H + y) * W + x) * p.Cout + M.n0 + 8 * h;
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            // accumulator rows: channel (r&3) + 8*(r>>2) + 4*h; the swap leaves lanes h=0 with channels
-                            // 16v..16v+7 and lanes h=1 with 16v+8..16v+15 of this 32-channel block (as in conv_small.hip)
+                        for (int mb = 0; mb < 2; ++mb) {
                             float o[S];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const unsigned a = __float_as_uint(acc[mb][nb][8 * v + j]);
-                                const unsigned b = __float_as_uint(acc[mb][nb][8 * v + 4 + j]);
-                                const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-                                o[j] = __uint_as_float(r[0]);
-                                o[4 + j] = __uint_as_float(r[1]);
-                            }
-                            if (valid) {
+                            regroup(acc[mb][nb], v, o);
+                            if (y0r + mb < H && x < W) {
 #pragma unroll
                                 for (int e = 0; e < S; ++e) {
-                                    sa[nb][v][e] += o[e];              // sums exclude the bias (ramdsir.h, RD_STAT_SLOTS)
-                                    sb[nb][v][e] += o[e] * o[e];
-                                    o[e] += bs[nb][v][e];
+                                    if (!WS_EXP(32)) {
+                                        sa[nb][v][e] += o[e];          // sums exclude the bias (ramdsir.h, RD_STAT_SLOTS)
+                                        sb[nb][v][e] += o[e] * o[e];
+                                    }
+                                    o[e] += bs[e];
                                 }
-                                *reinterpret_cast<uint4*>(orow + nb * 32 + 16 * v) = Slot<T>::pack(o);
+                                if (!WS_EXP(16)) *reinterpret_cast<uint4*>(out + (size_t)mb * W * p.Cout + nb * 32 + 16 * v) = Slot<T>::pack(o);
                             }
                         }
-                }
-            } else if constexpr (MODE == 2) {
-                if (M.n0 != cur_n0 || M.g != cur_g) {
-                    flush_stats();
-                    cur_n0 = M.n0;
-                    cur_g = M.g;
+                    }
+            } else {
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            const int c = M.n0 + nb * 32 + 16 * v;
-                            const int di = c >= p.c_split ? 1 : 0;
-                            const rd_dst_t d = select_dst(p, di);
-                            const bool ok = d.kind != RD_DST_NONE && d.scale != nullptr;
-                            const int gd = d.g_fixed >= 0 ? d.g_fixed : M.g;
-                            const int cd = c - (di ? p.c_split : 0) + 8 * h;
+                    for (int v = 0; v < 2; ++v) {
+                        const int di = (M.n0 + nb * 32 + 16 * v) >= p.c_split ? 1 : 0;
+                        const rd_dst_t d = select_dst(p, di);
+                        if (d.kind == RD_DST_NONE) continue;
+                        const float* cp = tab + (size_t)(M.g * 2) * p.CoutPad + M.n0 + nb * 32 + 16 * v + 8 * h;
+                        const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+                        const float4 d0 = *reinterpret_cast<const float4*>(cp + p.CoutPad), d1 = *reinterpret_cast<const float4*>(cp + p.CoutPad + 4);
+                        const float psc[S] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                        const float psh[S] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                        const bool masked = d.act && d.z;
 #pragma unroll
-                            for (int e = 0; e < S; ++e) {
-                                bs[nb][v][e] = ok ? d.scale[gd * d.Cd + cd + e] : 1.f;
-                                dsh[nb][v][e] = ok ? d.shift[gd * d.Cd + cd + e] : 0.f;
-                            }
-                        }
-                }
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    const int y = M.y0 + wave * 2 + mb, x = M.x0 + li;
-                    const bool valid = y < H && x < W;
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                        for (int v = 0; v < 2; ++v) {
+                        for (int mb = 0; mb < 2; ++mb) {
                             float da[S];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const unsigned a = __float_as_uint(acc[mb][nb][8 * v + j]);
-                                const unsigned b = __float_as_uint(acc[mb][nb][8 * v + 4 + j]);
-                                const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-                                da[j] = __uint_as_float(r[0]);
-                                da[4 + j] = __uint_as_float(r[1]);
-                            }
-                            const int di = (M.n0 + nb * 32 + 16 * v) >= p.c_split ? 1 : 0;
-                            const rd_dst_t d = select_dst(p, di);
-                            if (d.kind == RD_DST_NONE || !valid) continue;
+                            regroup(acc[mb][nb], v, da);
+                            if (!(y0r + mb < H && x < W)) continue;
+                            T* gp = reinterpret_cast<T*>(d.g) + dst_index(d, di, nb, v, y0r + mb, x);
                             float z[S], gw[S];
                             Slot<T>::unpack(zq[mb][nb][v], z);
-                            Slot<T>::unpack(gq[mb][nb][v], gw);
-                            const bool masked = d.act && d.z;
+                            Slot<T>::unpack(d.accumulate ? ld16(gp) : make_uint4(0, 0, 0, 0), gw);
 #pragma unroll
                             for (int e = 0; e < S; ++e) {
-                                const float m = masked ? act_grad(z[e] * bs[nb][v][e] + dsh[nb][v][e], d.slope) : 1.f;
+                                const float m = masked ? act_grad(z[e] * psc[e] + psh[e], d.slope) : 1.f;
                                 const float gn = da[e] * m;
                                 sa[nb][v][e] += gn;
                                 sb[nb][v][e] += gn * (d.z ? z[e] : 0.f);
-                                gw[e] = (d.accumulate ? gw[e] : 0.f) + gn;
+                                gw[e] += gn;
                             }
-                            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(d.g) + dst_index(d, di, nb, v, y, x)) = Slot<T>::pack(gw);
+                            *reinterpret_cast<uint4*>(gp) = Slot<T>::pack(gw);
                         }
-                }
-            } else {
-                const int slot = (M.txy + 7 * M.n) % RD_STAT_SLOTS;
-                conv_epilogue<T, 2>(p, acc, smem + PP_EPI, tid, M.n, M.g, M.y0, M.x0, M.n0, slot);
+                    }
             }
         }
-        M = Cs;
-        shift_stages();
+        WS_T(0, s, 2);
+        pp_advance(M, q, gm);
         __syncthreads();
+        WS_T(0, s, 3);
     }
-    if constexpr (LEAN) flush_stats();
+#ifdef RD_DEBUG_SWITCHES
+    if (blockIdx.x == 5 && tid == 0) { ws_trace[0][63][2] = __builtin_readcyclecounter(); ws_trace[0][63][3] = wall_clock64(); }
+#endif
+    flush_stats();
 }
 
 // plain per-pixel single-operand sources made of whole 16-byte channel slots (the fill above is branch-free)
@@ -527,39 +772,44 @@ bool pp_sources_ok(const rd_conv_t& p) {
 
 }  // namespace
 
+#ifdef RD_DEBUG_SWITCHES
+extern "C" int rd_debug_ws_trace(unsigned long long* out) {             // debug library only: 2 x 64 x 4 stamps
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(unsigned long long) * 2 * 64 * 4);
+}
+#endif
+
 int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     if (p.taps != 9 || p.CoutPad % PP_NT || p.CinPad > 32 * PP_MAX_CHUNKS || !pp_sources_ok(p)) return RD_CONV_PP_NA;
     static int n_cu = 0;
     if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RD_CONV_PP_NA;
-        n_cu = prop.multiProcessorCount;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        n_cu = rd_num_cus();
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / PP_NT);
-    // Measured (gpurun_out/lb_pp*.txt): with at most one tile per CU -- the 25x25 level -- the pipelined K loop wins
-    // 1.06-1.2x; on longer tile ranges the un-overlapped epilogue (2100 VALU per tile and wave, one workgroup per CU)
-    // costs more than the K loop gains (0.7-0.9x), so those launches stay with conv_pf_kernel.  RD_CONV_PP_ALL=1 lifts the limit.
-    static const bool pp_all = rd_switch("RD_CONV_PP_ALL", 0) != 0;
-    // forward launches whose output is whole 64-channel blocks take the register epilogue (LEAN) at any size
-    // Which launches take this kernel (layer timings in gpurun_out/lb_lean*.txt, us, conv_pf_kernel -> this kernel):
-    //   forward, >= 3 tiles per CU:  64->64 @200x200 121 -> 97, 128->128 @100x100 113 -> 98, 128->64 @100x100 67 -> 62,
-    //                                64->64 @100x100 49 -> 45;  with fewer tiles it loses (128->128 @50x50 38 -> 40):
-    //                                the register epilogue pays once there are enough tiles to pipeline across;
-    //   gradient (MODE 2):           slower almost everywhere (40 -> 57, 74 -> 87; only 64->64 @200x200 gains, 155 -> 142):
-    //                                its sources are already-materialised dz tensors, which conv_pf_kernel streams with
-    //                                two workgroups per CU -- opt-in only (RD_CONV_PP_LEAN2=1).
-    static const bool lean_off = rd_switch("RD_CONV_PP_LEAN_OFF", 0) != 0, lean2_on = rd_switch("RD_CONV_PP_LEAN2", 0) != 0;
-    int lean = lean_off ? 0 : rd_conv_lean_mode(p, PP_NT);               // 0 none, 1 forward, 2 plain gradient (conv_dispatch.h)
-    if (lean == 1 && !(tiles >= 3 * n_cu || pp_all)) lean = 0;
-    if (lean == 2 && !lean2_on) lean = 0;
-    if (!lean && tiles > n_cu && !pp_all) return RD_CONV_PP_NA;
     const int grid = tiles < n_cu ? tiles : n_cu;
-    if (lean == 1) hipLaunchKernelGGL(conv_pp_kernel<1>, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
-    else if (lean == 2) hipLaunchKernelGGL(conv_pp_kernel<2>, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
-    else hipLaunchKernelGGL(conv_pp_kernel<0>, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
+    // Launches that qualify for a register epilogue (conv_dispatch.h: 1 forward, 2 gradient into plain tensors) take the
+    // warp-specialised kernel.  Layer timings (scripts/ab_layers.sh, us, previous kernel -> conv_ws_kernel):
+    //   forward:   256->256 @50x50 102 -> 90, 128->128 @100x100 99 -> 85, 64->64 @200x200 96 -> 84, 128->64 @100x100 62 -> 54,
+    //              64->64 @100x100 43 -> 38: every forward launch gains;
+    //   gradient:  64->64 @200x200 153 -> 137, 128->128 @100x100 129 -> 122, but 128->128 @50x50 40 -> 52, 64->64 @100x100
+    //              55 -> 62: with few tiles per CU the two-workgroup conv_pf_kernel streams the materialised dz better, so
+    //              gradient launches need >= RD_CONV_WS_MIN2 tiles (default 1536 = 6 per CU).
+    static const int ws = rd_switch("RD_CONV_WS", 3), ws_min2 = rd_switch("RD_CONV_WS_MIN2", 1536);
+    const int mode = rd_conv_lean_mode(p, PP_NT);
+    const size_t tab = (size_t)(mode == 1 ? 1 : 2 * p.G) * p.CoutPad * sizeof(float);
+    if (mode && (ws & mode) && (mode == 1 || tiles >= ws_min2) && tab <= (size_t)PP_EPI_BYTES) {
+        static const int ws_exp = rd_switch("RD_CONV_WS_EXP", 0);           // timing experiments (debug build with -DRD_WS_EXP)
+        if (mode == 1) hipLaunchKernelGGL(conv_ws_kernel<1>, dim3(grid), dim3(512), PP_LDS, st, p, tiles | (ws_exp << 26));
+        else hipLaunchKernelGGL(conv_ws_kernel<2>, dim3(grid), dim3(512), PP_LDS, st, p, tiles | (ws_exp << 26));
+        return (int)hipGetLastError();
+    }
+    // conv_pp_kernel (LDS-staged epilogue, any destination): measured (gpurun_out/lb_pp*.txt) 1.06-1.2x over conv_pf_kernel
+    // with at most one tile per CU -- the 25x25 level -- and 0.7-0.9x on longer tile ranges, where its un-overlapped
+    // epilogue (2100 VALU per tile and wave at one workgroup per CU) costs more than the pipelined K loop gains.
+    static const bool pp_all = rd_switch("RD_CONV_PP_ALL", 0) != 0;
+    if (tiles > n_cu && !pp_all) return RD_CONV_PP_NA;
+    hipLaunchKernelGGL(conv_pp_kernel, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
     return (int)hipGetLastError();
 }

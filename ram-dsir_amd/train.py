@@ -226,6 +226,7 @@ def main(args):
     previous_best, iter_num = 0.0, 0
     t_mark, it_mark, imgs_per_iter = None, 0, world * sum(bsl[:len(domain_idx_list)])
     for epoch in range(args.epochs):
+        it_epoch = iter_num
         if rank == 0:
             print('\n==> Epoch %i, learning rate = %.6f' % (epoch, args.lr if iter_num == 0 else trainer.lr()))
         for m in (encoder, seg_decoder, rec_decoder):
@@ -277,7 +278,9 @@ def main(args):
             save_checkpoint(os.path.join(args.save_path, 'model_%.2f.pth' % avg_dice), encoder, seg_decoder, rec_decoder)
             previous_best = avg_dice
         if rank == 0:
-            print('epoch %d: training %.2f s, validation + checkpoint %.2f s' % (epoch, t_train, time.time() - t_epoch - t_train))
+            t_all, n_img = time.time() - t_epoch, (iter_num - it_epoch) * imgs_per_iter
+            print('epoch %d: training %.2f s (%.0f images/s), validation + checkpoint %.2f s (%.0f images/s over the whole epoch)'
+                  % (epoch, t_train, n_img / max(t_train, 1e-9), t_all - t_train, n_img / max(t_all, 1e-9)))
         if args.max_iters and iter_num >= args.max_iters:
             break
     if rank == 0:
