@@ -1,0 +1,38 @@
+"""How long the CPU takes to ENQUEUE one eager step (3 streams, ctypes launches) next to how long the GPU takes to run it."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'ram-dsir_amd')]
+import torch
+from ramdsir import step as S
+import bench as Bn
+bank, mods = S.make_bank('cuda:0', 3, 16, 2, 3)
+Bn.init_weights(bank)
+ts = S.TrainStep(bank, mods, torch.bfloat16, [2, 3, 3], 400, 400, ram='u8')
+ts.wpack.refresh()
+src, trg, lam, mask, _ = Bn.synth_inputs(8, 400, 0, 'cuda:0')
+ts.load_raw(src, trg, lam); ts.load_target(mask)
+for _ in range(5):
+    ts.step()
+torch.cuda.synchronize()
+n = 20
+t0 = time.perf_counter()
+for _ in range(n):
+    ts.step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print('eager: CPU enqueue %.2f ms/step, until GPU done %.2f ms/step (%d launches/step)' % ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3, len(ts._ops)))
+# one step enqueued on an idle GPU: pure enqueue cost
+torch.cuda.synchronize()
+t0 = time.perf_counter(); ts.step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print('single step on an idle GPU: enqueue %.2f ms, done after %.2f ms' % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+ts.capture()
+for _ in range(3):
+    ts.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    ts.step()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print('hipGraph (one chain): %.2f ms/step' % ((t2 - t0) / n * 1e3))
