@@ -27,11 +27,16 @@ __global__ void pack_weights_kernel(const float* w, T* out, int Cout, int Cin, i
     }
 }
 
-// all convs of the network in one launch: entry e owns packed elements [start_e, start_{e+1})
+// all convs of the network in one launch: entry e owns packed elements [start_e, start_{e+1}).  A thread produces one
+// 16-byte vector (V = 8 bf16 / 4 fp32 consecutive input channels of one (chunk, tap, row): CK is a multiple of V, so a
+// vector never straddles rows or entries): one table search and one store per V elements
 template <typename T>
 __global__ void pack_weights_batched_kernel(const float* params, T* packed, const rd_pack_entry_t* tab, int n_entries,
                                             int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    constexpr int CK = 64 / (int)sizeof(T), V = 16 / (int)sizeof(T);
+    const int64_t nvec = total / V;
+    for (int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = iv * V;
         int lo = 0, hi = n_entries - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -39,16 +44,20 @@ __global__ void pack_weights_batched_kernel(const float* params, T* packed, cons
         }
         const rd_pack_entry_t e = tab[lo];
         const int j = (int)(i - e.start);
-        constexpr int CK = 64 / (int)sizeof(T);
-        const int cc = j % CK, row = (j / CK) % e.RowPad, tap = (j / (CK * e.RowPad)) % e.taps, col = (j / (CK * e.RowPad * e.taps)) * CK + cc;
+        const int cc = j % CK, row = (j / CK) % e.RowPad, tap = (j / (CK * e.RowPad)) % e.taps, col0 = (j / (CK * e.RowPad * e.taps)) * CK + cc;
         const float* w = params + e.src_off;
-        float v = 0.f;
-        if (!e.transpose) {
-            if (row < e.Cout && col < e.Cin) v = w[((size_t)row * e.Cin + col) * e.taps + tap];
-        } else {
-            if (row < e.Cin && col < e.Cout) v = w[((size_t)col * e.Cin + row) * e.taps + (e.taps - 1 - tap)];
+        float v[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int col = col0 + k;
+            v[k] = 0.f;
+            if (!e.transpose) {
+                if (row < e.Cout && col < e.Cin) v[k] = w[((size_t)row * e.Cin + col) * e.taps + tap];
+            } else {
+                if (row < e.Cin && col < e.Cout) v[k] = w[((size_t)col * e.Cin + row) * e.taps + (e.taps - 1 - tap)];
+            }
         }
-        packed[e.dst_off + j] = from_f<T>(v);
+        *reinterpret_cast<uint4*>(packed + e.dst_off + j) = Slot<T>::pack(v);
     }
 }
 
@@ -85,7 +94,8 @@ int rd_pack_weights(const float* w_oihw, void* packed, int Cout, int Cin, int ta
 int rd_pack_weights_batched(const float* params, void* packed, const rd_pack_entry_t* table_dev, int n_entries, int64_t total,
                             int dtype, void* stream) {
     if (n_entries < 1 || total < 1) return -1;
-    int64_t blocks = (total + 255) / 256;
+    if (total % 8) return -2;                                   // entries are whole 64-byte K chunks
+    int64_t blocks = (total / (dtype == RD_BF16 ? 8 : 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RD_BF16)
