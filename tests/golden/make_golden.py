@@ -304,8 +304,9 @@ def gen_steps(RU, ref_losses, only64=False):
     for dataset, bsl, S, ncls, cons in (('fundus', [2, 3, 3], 32, 2, 'kd'),
                                         ('fundus_mse', [1, 2, 1], 32, 2, 'mse'),
                                         ('prostate', [2, 2, 2, 2, 2], 32, 2, 'kd'),
-                                        ('fundus64', [2, 3, 3], 64, 2, 'kd')):       # 4x4-pixel bottleneck: tighter gradient checks
-        if only64 and dataset != 'fundus64':
+                                        ('fundus64', [2, 3, 3], 64, 2, 'kd'),        # 4x4-pixel bottleneck: tighter gradient checks
+                                        ('prostate96', [1, 2, 1, 1, 1], 96, 2, 'kd')):  # 5 domain groups, 6x6 bottleneck, 3 tiles per row
+        if only64 and dataset not in ('fundus64', 'prostate96'):
             continue
         out = {}
         nd = len(bsl)
@@ -327,7 +328,7 @@ def gen_steps(RU, ref_losses, only64=False):
         rec_criterion = MSELoss()
         consistency_criterion = KD if cons == 'kd' else MSELoss()
         encoder.train(); seg_decoder.train(); rec_decoder.train()
-        nsteps = 3
+        nsteps = 3 if S < 96 else 2
         iter_num = 0
         for it in range(nsteps):
             img_multi = torch.rand(B, 3, S, S, generator=g) * 2 - 1

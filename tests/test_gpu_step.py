@@ -25,7 +25,13 @@ DEV = 'cuda:0'
 REL_L2_STEP = 4e-2
 # ... and the 64x64 fixture (4x4-pixel bottleneck, BatchNorm batches of >= 32 values) to 2.5e-2 (runs give 1.2e-2 .. 1.7e-2); at the benchmark sizes
 # tests/test_gpu_fullsize.py holds every gradient to the reference's own noise floor (<= 2e-2 worst, 6e-3 median).
-REL_L2_BY_FIXTURE = {'fundus64': 2.5e-2}
+REL_L2_BY_FIXTURE = {'fundus64': 2.5e-2, 'prostate96': 8e-2}
+# prostate96: DSBN groups of ONE image at the 6x6 bottleneck = 36-sample BatchNorm batches.  The reference's own one-ulp
+# noise floor there (oracle vs oracle on inputs perturbed by 6e-8, scripts/noise_floor.py's method) is 3.5-4.7e-3 median /
+# 1.8e-2 worst per tensor; the HIP step sits at 3.9e-3 median and, depending on the run's accumulation order, 1.2e-2 ... 4.8e-2
+# on its worst tensor (one ReLU decision of a 36-sample channel flips in about a third of the runs).  Hence a loose
+# per-tensor bound AND a sharp bound on the median.
+MEDIAN_REL_L2_BY_FIXTURE = {'fundus64': 1e-2, 'prostate96': 1e-2}
 
 
 def rel_l2(got, ref):
@@ -52,7 +58,7 @@ def _feed(ts, G, it):
     ts.load_target(T(G['s%d.mask' % it]).to(DEV))
 
 
-@pytest.mark.parametrize('name', ['fundus', 'fundus_mse', 'prostate', 'fundus64'])
+@pytest.mark.parametrize('name', ['fundus', 'fundus_mse', 'prostate', 'fundus64', 'prostate96'])
 def test_step_fp32_matches_reference_fixture(golden_dir, name):
     G, meta, states, bank, mods, ts = _setup(golden_dir, name, torch.float32)
     REL_L2_STEP = REL_L2_BY_FIXTURE.get(name, globals()['REL_L2_STEP'])
@@ -65,6 +71,7 @@ def test_step_fp32_matches_reference_fixture(golden_dir, name):
     np.testing.assert_allclose(got, ref, rtol=1e-4)
     np.testing.assert_allclose(ld['rec'], G['s0.rec_losses'], rtol=1e-4)
     # gradients of every parameter vs the reference's (signatures: L2, L1, first 8 elements)
+    full = []
     for m in ('enc', 'dec', 'rec'):
         for key, shape, kind, _ in dict(mods)[m]:
             if kind != 'param':
@@ -78,7 +85,10 @@ def test_step_fp32_matches_reference_fixture(golden_dir, name):
             np.testing.assert_allclose(float(g.double().abs().sum()), ref[1], rtol=REL_L2_STEP, err_msg=key)
             fk = 's0.g%s.full.%s' % (m, key)
             if fk in G.files:
-                assert rel_l2(g, T(G[fk])) <= REL_L2_STEP, key
+                full.append(rel_l2(g, T(G[fk])))
+                assert full[-1] <= REL_L2_STEP, key
+    if name in MEDIAN_REL_L2_BY_FIXTURE:
+        assert len(full) > 100 and float(np.median(full)) <= MEDIAN_REL_L2_BY_FIXTURE[name], (len(full), float(np.median(full)))
     # post-step state.  Adam's first update is ~lr*sign(g): elements whose gradient is below fp32 noise take
     # a platform-dependent sign, so parameters are held to |diff| <= 2*lr per element and 1e-2 on the norm;
     # running statistics / num_batches_tracked are plain fp32 averages and held to 1e-3.

@@ -10,7 +10,7 @@ from golden_util import (assert_sig_close, load_step, step_states, state_checksu
 T = torch.from_numpy
 
 
-@pytest.mark.parametrize('name', ['fundus', 'fundus_mse', 'prostate', 'fundus64'])
+@pytest.mark.parametrize('name', ['fundus', 'fundus_mse', 'prostate', 'fundus64', 'prostate96'])
 def test_three_steps(golden_dir, name):
     G, meta = load_step(golden_dir, name)
     enc, dec, rec = step_states(meta)
