@@ -169,6 +169,11 @@ __device__ __forceinline__ void reduce_stats_d(double (&A1)[S], double (&A2)[S],
 // sum / sum of squares of the virtual upsampled tensor; grid (blocks, N)
 template <typename T>
 __global__ __launch_bounds__(256) void up_stats_kernel(const T* t, double* stats, T* y_out, int h, int w, int C, GroupMap gm) {
+    // One item = the 2 x 2 hi-res pixels between four lo-res pixels (i..i+1, j..j+1; i, j from -1: the image border
+    // clamps): those four outputs read the SAME four lo-res vectors with row / column weights {0.25, 0.75}, so an item
+    // costs 4 loads and 12 flops per channel for 4 outputs (a pixel-per-item loop needs 16 and 24).  Per output the
+    // arithmetic is unchanged -- top = t00 + lx (t01 - t00), bot likewise, u = top + ly (bot - top) (ATen's order) -- so
+    // the results are bit-identical to interpolating every pixel on its own.
     constexpr int S = Slot<T>::N;
     extern __shared__ double s_redd[];                     // [C][2]
     const int n = blockIdx.y, g = group_of(gm, n);
@@ -176,46 +181,60 @@ __global__ __launch_bounds__(256) void up_stats_kernel(const T* t, double* stats
     __syncthreads();
     const int SL = C / S;
     const int H = 2 * h, W = 2 * w;
-    const int items = H * W * SL;
+    const int bw = w + 1, items = (h + 1) * bw * SL;
     const int sl = threadIdx.x % SL;                       // constant per thread (256 % SL == 0, stride % SL == 0)
     float a1[S], a2[S], piv[S];
     int cnt = 0;
 #pragma unroll
     for (int e = 0; e < S; ++e) a1[e] = a2[e] = piv[e] = 0.f;
+    const T* b = t + (size_t)n * h * w * C + sl * S;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < items; idx += gridDim.x * blockDim.x) {
-        const int pix = idx / SL;
-        const int Y = pix / W, X = pix - Y * W;
-        int y0, y1, x0, x1;
-        float ly, lx;
-        up2_coord(Y, h, y0, y1, ly);
-        up2_coord(X, w, x0, x1, lx);
+        const int blk = idx / SL;
+        const int bi = blk / bw, i = bi - 1, j = blk - bi * bw - 1;
+        const int r0 = max(i, 0), r1 = min(i + 1, h - 1), c0 = max(j, 0), c1 = min(j + 1, w - 1);
         float t00[S], t01[S], t10[S], t11[S];
-        const T* b = t + (size_t)n * h * w * C + sl * S;
-        ldv<T>(b + ((size_t)y0 * w + x0) * C, t00);
-        ldv<T>(b + ((size_t)y0 * w + x1) * C, t01);
-        ldv<T>(b + ((size_t)y1 * w + x0) * C, t10);
-        ldv<T>(b + ((size_t)y1 * w + x1) * C, t11);
-        float uu[S];
+        ldv<T>(b + ((size_t)r0 * w + c0) * C, t00);
+        ldv<T>(b + ((size_t)r0 * w + c1) * C, t01);
+        ldv<T>(b + ((size_t)r1 * w + c0) * C, t10);
+        ldv<T>(b + ((size_t)r1 * w + c1) * C, t11);
+        // the weights of up2_coord: hi-res 2i+1 sits at lo-res i + 0.25, 2i+2 at i + 0.75; at a clamped border both
+        // lo-res vectors are the same one and any weight returns it exactly
+        float u[2][2][S];
 #pragma unroll
         for (int e = 0; e < S; ++e) {
-            const float top = t00[e] + lx * (t01[e] - t00[e]), bot = t10[e] + lx * (t11[e] - t10[e]);
-            uu[e] = top + ly * (bot - top);
+            const float dt = t01[e] - t00[e], db = t11[e] - t10[e];
+            const float tl = t00[e] + 0.25f * dt, tr = t00[e] + 0.75f * dt;
+            const float bl = t10[e] + 0.25f * db, br = t10[e] + 0.75f * db;
+            const float dl = bl - tl, dr = br - tr;
+            u[0][0][e] = tl + 0.25f * dl; u[1][0][e] = tl + 0.75f * dl;
+            u[0][1][e] = tr + 0.25f * dr; u[1][1][e] = tr + 0.75f * dr;
         }
-        if (y_out) {
-            const uint4 pk = Slot<T>::pack(uu);
-            *reinterpret_cast<uint4*>(y_out + ((size_t)n * H * W + pix) * C + sl * S) = pk;
-            Slot<T>::unpack(pk, uu);
-        }
-        if (cnt == 0) {
 #pragma unroll
-            for (int e = 0; e < S; ++e) piv[e] = uu[e];
-        }
-        ++cnt;
+        for (int dy = 0; dy < 2; ++dy) {
+            const int Y = 2 * i + 1 + dy;
+            if ((unsigned)Y >= (unsigned)H) continue;
 #pragma unroll
-        for (int e = 0; e < S; ++e) {
-            const float d = uu[e] - piv[e];
-            a1[e] += d;
-            a2[e] += d * d;
+            for (int dx = 0; dx < 2; ++dx) {
+                const int X = 2 * j + 1 + dx;
+                if ((unsigned)X >= (unsigned)W) continue;
+                float* uu = u[dy][dx];
+                if (y_out) {
+                    const uint4 pk = Slot<T>::pack(uu);
+                    *reinterpret_cast<uint4*>(y_out + ((size_t)n * H * W + (size_t)Y * W + X) * C + sl * S) = pk;
+                    Slot<T>::unpack(pk, uu);
+                }
+                if (cnt == 0) {
+#pragma unroll
+                    for (int e = 0; e < S; ++e) piv[e] = uu[e];
+                }
+                ++cnt;
+#pragma unroll
+                for (int e = 0; e < S; ++e) {
+                    const float d = uu[e] - piv[e];
+                    a1[e] += d;
+                    a2[e] += d * d;
+                }
+            }
         }
     }
     double A1[S], A2[S];
@@ -616,8 +635,8 @@ int rd_up_stats(const void* t, double* stats, void* y_out, int N, int h, int w, 
     const int S = dtype == RD_BF16 ? 8 : 4;
     if (C % S || 256 % (C / S)) return -2;
     const GroupMap gm = host_gm(G, gstart_host);
-    const int items = 4 * h * w * (C / S);
-    static const int us_per = rd_switch("RD_UPS_PER", 8);
+    const int items = (h + 1) * (w + 1) * (C / S);                     // 2 x 2 output pixels per item
+    static const int us_per = rd_switch("RD_UPS_PER", 2);
     int bx = grid_for(items, 256 * us_per, 4096);
     dim3 grid(bx, N);
     if (dtype == RD_BF16)
