@@ -771,17 +771,18 @@ def test_layout_boundary_kernels(dtype):
     np.testing.assert_allclose(outc.cpu(), t3.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
 
 
-# ------------------------------------------------------------------------------------ conv_pp_kernel, every mode
+# ------------------------------------------------------------------------------------ every 64-wide conv kernel
 @pytest.mark.parametrize('env', [
-    {'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0'},                              # MODE 1 forward, MODE 0 (staged) gradients
-    {'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_PP_LEAN2': '1'},     # + MODE 2 register gradient epilogue
-    {'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_PP_LEAN_OFF': '1'},  # MODE 0 everywhere
+    {'RD_CONV_WS': '3', 'RD_CONV_WS_MIN2': '0', 'RD_CONV_NB1_BELOW': '0'},          # conv_ws_kernel: forward AND gradient launches
+    {'RD_CONV_WS': '0', 'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0'},           # conv_pp_kernel (LDS-staged epilogue) everywhere
+    {'RD_CONV_PP_OFF': '1', 'RD_CONV_NB1_BELOW': '0'},                              # conv_pf_kernel with the register epilogues
+    {'RD_CONV_PP_OFF': '1', 'RD_CONV_PF_LEAN_OFF': '1', 'RD_CONV_NB1_BELOW': '0'},  # conv_pf_kernel with the LDS-staged epilogue
     {'RD_CONV_NB1_BELOW': '100000'},                                                # 32-wide tiles for every 64-wide launch
-], ids=['pp_lean_fwd', 'pp_lean_fwd_bwd', 'pp_staged', 'nb1_everywhere'])
+], ids=['ws_fwd_bwd', 'pp_staged', 'pf_lean', 'pf_staged', 'nb1_everywhere'])
 def test_conv_kernels_under_forced_dispatch(env):
-    """The persistent pipelined kernel only takes large forward launches by default (the cases above are small), and the
-    dispatch switches (debug build of the library only) are read once per process: re-run the conv parity tests in a child process with every eligible
-    launch forced through conv_pp_kernel (each epilogue mode) / through the 32-wide tiles."""
+    """Which kernel a 64-wide launch takes depends on its size (csrc/conv_pp.hip, conv_big.hip), and the cases above are small.
+    The dispatch switches (debug build of the library only) are read once per process: re-run the conv parity tests in a child
+    process with every eligible launch forced through each kernel / epilogue / tile width."""
     import subprocess
     import sys
     e = dict(os.environ, RAMDSIR_DEBUG_LIB='1')        # the RD_* overrides exist only in the debug build (csrc/common.h rd_switch)
