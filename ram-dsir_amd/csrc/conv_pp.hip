@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
 constexpr int WS_TAB = PP_EPI;                               // MODE 1: bias [CoutPad]; MODE 2: [G][2][CoutPad] producer scale | shift
 #ifdef RD_DEBUG_SWITCHES
 __device__ unsigned long long ws_trace[2][64][4];          // [role][step][event] shader-clock stamps of workgroup 5 (debug build)
-#define WS_T(role, s, ev) do { if (blockIdx.x == 5 && tid == 0 && (s) < 63) ws_trace[role][s][ev] = __builtin_readcyclecounter(); } while (0)
+#define WS_T(role, s, ev) do { if (trace_ && blockIdx.x == 5 && tid == 0 && (s) < 63) ws_trace[role][s][ev] = __builtin_readcyclecounter(); } while (0)
 #else
 #define WS_T(role, s, ev) do { } while (0)
 #endif
@@ -348,8 +348,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     const int H = p.H, W = p.W;
     const GroupMap gm = make_gm(p.gstart, p.G);
 #ifdef RD_DEBUG_SWITCHES
-    const int exp_ = tiles_total >> 26;
-    tiles_total &= (1 << 26) - 1;
+    const int exp_ = tiles_total >> 26;                    // WS_EXP bits
+    const bool trace_ = ((tiles_total >> 25) & 1) != 0;    // this launch records the s_memtime trace
+    tiles_total &= (1 << 25) - 1;
 #endif
     PpGeo q;
     q.ncb = p.CoutPad / PP_NT;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     };
 
 #ifdef RD_DEBUG_SWITCHES
-    if (blockIdx.x == 5 && tid == 0) { ws_trace[0][63][0] = __builtin_readcyclecounter(); ws_trace[0][63][1] = wall_clock64(); }
+    if (trace_ && blockIdx.x == 5 && tid == 0) { ws_trace[0][63][0] = __builtin_readcyclecounter(); ws_trace[0][63][1] = wall_clock64(); }
 #endif
     __syncthreads();                     // buffer 0 filled (the loader waves' prologue)
     for (int s = 0; s < nsteps; ++s) {
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         WS_T(0, s, 3);
     }
 #ifdef RD_DEBUG_SWITCHES
-    if (blockIdx.x == 5 && tid == 0) { ws_trace[0][63][2] = __builtin_readcyclecounter(); ws_trace[0][63][3] = wall_clock64(); }
+    if (trace_ && blockIdx.x == 5 && tid == 0) { ws_trace[0][63][2] = __builtin_readcyclecounter(); ws_trace[0][63][3] = wall_clock64(); }
 #endif
     flush_stats();
 }
@@ -800,9 +801,12 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     const int mode = rd_conv_lean_mode(p, PP_NT);
     const size_t tab = (size_t)(mode == 1 ? 1 : 2 * p.G) * p.CoutPad * sizeof(float);
     if (mode && (ws & mode) && (mode == 1 || tiles >= ws_min2) && tab <= (size_t)PP_EPI_BYTES) {
-        static const int ws_exp = rd_switch("RD_CONV_WS_EXP", 0);           // timing experiments (debug build with -DRD_WS_EXP)
-        if (mode == 1) hipLaunchKernelGGL(conv_ws_kernel<1>, dim3(grid), dim3(512), PP_LDS, st, p, tiles | (ws_exp << 26));
-        else hipLaunchKernelGGL(conv_ws_kernel<2>, dim3(grid), dim3(512), PP_LDS, st, p, tiles | (ws_exp << 26));
+        // debug build only: RD_CONV_WS_EXP = timing experiments (-DRD_WS_EXP), RD_CONV_WS_TRACE_MIN = launches with at least
+        // that many tiles record the s_memtime trace (scripts/ws_trace.py); both ride in the high bits of the tile count
+        static const int ws_exp = rd_switch("RD_CONV_WS_EXP", 0), ws_trace_min = rd_switch("RD_CONV_WS_TRACE_MIN", 1 << 30);
+        const int arg = tiles | (ws_exp << 26) | (tiles >= ws_trace_min ? 1 << 25 : 0);
+        if (mode == 1) hipLaunchKernelGGL(conv_ws_kernel<1>, dim3(grid), dim3(512), PP_LDS, st, p, arg);
+        else hipLaunchKernelGGL(conv_ws_kernel<2>, dim3(grid), dim3(512), PP_LDS, st, p, arg);
         return (int)hipGetLastError();
     }
     // conv_pp_kernel (LDS-staged epilogue, any destination): measured (gpurun_out/lb_pp*.txt) 1.06-1.2x over conv_pf_kernel

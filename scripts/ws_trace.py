@@ -1,5 +1,5 @@
 """Debug library only: per-step shader-clock stamps of one workgroup of conv_ws_kernel (the last launch that took it).
-usage: RAMDSIR_DEBUG_LIB=1 RD_CONV_WS=1 RD_CONV_WS_MIN=2000 python scripts/ws_trace.py"""
+usage: RAMDSIR_DEBUG_LIB=1 RD_CONV_WS=1 RD_CONV_WS_TRACE_MIN=2000 python scripts/ws_trace.py   (2800 tiles = dec.convu2.conv3 forward, 64->64 at 200x200)"""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'ram-dsir_amd')]
