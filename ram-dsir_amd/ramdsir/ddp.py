@@ -56,7 +56,10 @@ class DataParallelStep:
         n_enc = b.module_range['enc'][1]
         # arena order = parameters() order: encoder levels 1..5, then the decoders
         self.buckets = GradBuckets(b.grads, [0, ts.enc_deep_offset, n_enc, b.n], group)
-        self.comm = torch.cuda.Stream()
+        # The collectives are LAUNCHED from the weight-gradient lane (RCCL runs them on its own stream and only makes that
+        # stream wait for the launching one): a separate communication stream would be the fifth stream of the step, and
+        # HIP gives a process four hardware queues -- a fifth one aliases a lane (streams.py; 5.9 -> 9-11 ms/step measured)
+        self.comm = ts.side[0]
         self.graphs = None
 
     def _segments(self):
@@ -118,7 +121,8 @@ class DataParallelStep:
                 open_lanes |= E.Plan.run_lanes(segs[seg_i], main, lanes)
                 self.comm.wait_stream(main)
                 for name in open_lanes:
-                    self.comm.wait_stream(lanes[name])
+                    if lanes[name] is not self.comm:
+                        self.comm.wait_stream(lanes[name])
                 with torch.cuda.stream(self.comm):
                     works.append(self.buckets.reduce(bucket, async_op=True))
             for name in open_lanes:

@@ -17,6 +17,7 @@ import torch
 from . import _lib as L
 from . import engine as E
 from . import ram as R
+from . import streams
 from . import tuning as T
 
 
@@ -110,8 +111,13 @@ class TrainStep:
         # RD_FORK=0: everything on one stream.  Captured into a hipGraph the same forks become parallel branches,
         # which ROCm 7's graph executor runs SLOWER than the single chain (measured), so
         # capture() records the one-stream order.
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(self.n_side)]
-        self.rec_stream = torch.cuda.Stream(device=dev)
+        # The lanes must sit on different HARDWARE queues than the caller's stream and than each other: streams.pick_lanes
+        # measures that instead of trusting the creation order (a process group or a DataLoader created before this object
+        # shifts the stream -> queue mapping: 5.7 -> 6.5 ... 11 ms/step when two lanes share a queue)
+        with torch.cuda.device(dev):
+            picked = streams.pick_lanes(self.n_side + 1, dev, [torch.cuda.current_stream(dev)]) if opt['fork'] else \
+                [torch.cuda.Stream(device=dev) for _ in range(self.n_side + 1)]
+        self.side, self.rec_stream = picked[:self.n_side], picked[self.n_side]
         self.fork = bool(opt['fork'])
         self.rec_lane = bool(opt['rec_lane'])
         self._ops = self._build_ops()

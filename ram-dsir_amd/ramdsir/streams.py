@@ -1,0 +1,70 @@
+"""Lane streams that REALLY run beside each other.
+
+HIP multiplexes a process's streams onto a small number of hardware queues (4 by default on this stack) and which queue a
+stream gets depends on how many streams the process created before it (torch's pool, a process group, a DataLoader pin
+thread ...).  Two lanes of the fused step on one hardware queue serialise: measured 5.7 -> 6.5 ms/step with the main and
+the restoration lane aliased, 9-11 ms with main and the weight-gradient lane aliased (scripts/stream_alias.py,
+scripts/ddp_diag.py).  Raising GPU_MAX_HW_QUEUES is not the answer: with more than four ACTIVE queues
+the data-parallel step took 9-10 ms.  So the lanes are picked by measurement: a candidate stream is accepted only if a tiny
+kernel on it completes while a long spin kernel occupies each stream it has to run beside."""
+import sys
+import time
+
+import torch
+
+_SPIN = 6_000_000            # cycles of torch.cuda._sleep: a few ms
+
+
+def _spin_ms(stream):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(_SPIN)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3
+
+
+def runs_beside(busy, probe, scratch, spin_ms):
+    """True when work submitted to `probe` does not wait for work running on `busy`."""
+    torch.cuda.synchronize()
+    with torch.cuda.stream(busy):
+        torch.cuda._sleep(_SPIN)
+    ev = torch.cuda.Event()
+    with torch.cuda.stream(probe):
+        scratch.add_(1.0)
+        ev.record(probe)
+    t0 = time.perf_counter()
+    ev.synchronize()
+    dt = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    return dt < 0.3 * spin_ms
+
+
+def pick_lanes(n, device, beside, tries=12):
+    """n new streams on `device`, each measured to run beside every stream in `beside` and beside each other.  Falls back to
+    unverified streams (with a warning) when the stack does not offer enough independent queues."""
+    if n <= 0:
+        return []
+    scratch = torch.zeros(256, device=device)
+    spin_ms = min(_spin_ms(beside[0]) for _ in range(2))
+    chosen, rejected = [], []
+    for _ in range(tries):
+        if len(chosen) == n:
+            break
+        cand = torch.cuda.Stream(device=device)
+        # a stream's FIRST submission can go to whichever hardware queue is idle at that moment; only from the second one on
+        # does it show the queue it keeps (scripts/pick_debug.py): warm it up, then ask twice
+        with torch.cuda.stream(cand):
+            scratch.add_(1.0)
+        torch.cuda.synchronize()
+        if all(runs_beside(b, cand, scratch, spin_ms) and runs_beside(b, cand, scratch, spin_ms) for b in list(beside) + chosen):
+            chosen.append(cand)
+        else:
+            rejected.append(cand)
+    if len(chosen) < n:
+        print('[ramdsir] only %d of %d lane streams run concurrently with the main stream on this stack; '
+              'the remaining lanes share a hardware queue (slower, still correct)' % (len(chosen), n), file=sys.stderr)
+        chosen += rejected[:n - len(chosen)]
+        while len(chosen) < n:
+            chosen.append(torch.cuda.Stream(device=device))
+    return chosen
