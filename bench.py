@@ -292,6 +292,12 @@ def main():
         if args.dtype == 'bf16':
             out['roofline'] = kernel_roofline(ts, DOMINANT, eager=not args.graph)
             out['roofline_conv64'] = kernel_roofline(ts, CONV64, eager=not args.graph)
+            if not args.graph:
+                # the same launches on ONE stream (nothing beside them): what the kernels do when they have the GPU to
+                # themselves, next to the headline figures above, which are measured under the step's three-stream contention
+                for key, fam in (('roofline', DOMINANT), ('roofline_conv64', CONV64)):
+                    a = kernel_roofline(ts, fam, eager=False)
+                    out[key]['alone'] = {k: a[k] for k in ('achieved', 'unit', 'frac', 'avg_launch_us')}
         if world == 1 and args.dtype == 'bf16' and not args.no_fp32_leg:
             out['extra'] = {'fp32': fp32_leg(params0, bs, Sz, dev, src, trg, lam, mask)}
         if world == 1 and not args.no_cpu_baseline:
