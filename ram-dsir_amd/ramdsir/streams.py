@@ -45,6 +45,14 @@ def pick_lanes(n, device, beside, tries=12):
     unverified streams (with a warning) when the stack does not offer enough independent queues."""
     if n <= 0:
         return []
+    try:
+        return _pick(n, device, list(beside), tries)
+    except Exception as e:                                  # a stack without torch.cuda._sleep, a probe that fails: lanes still work
+        print('[ramdsir] lane-stream probing failed (%s: %s); using unverified streams' % (type(e).__name__, e), file=sys.stderr)
+        return [torch.cuda.Stream(device=device) for _ in range(n)]
+
+
+def _pick(n, device, beside, tries):
     scratch = torch.zeros(256, device=device)
     spin_ms = min(_spin_ms(beside[0]) for _ in range(2))
     chosen, rejected = [], []
