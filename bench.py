@@ -31,7 +31,7 @@ import torch
 # convs 20 %, 3x3 convs on 64-wide output-channel tiles 16 %.  `roofline` is the weight-gradient family (one launch =
 # one rd_wgrad call = MFMA kernel + split reduction); `roofline_conv64` keeps the previous rounds' family for continuity.
 DOMINANT = 'wgrad'
-DOMINANT_SYMBOLS = ('wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel')   # mangled-name fragments (profiles/)
+DOMINANT_SYMBOLS = ('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel')   # mangled-name fragments (profiles/)
 CONV64 = 'conv_kernel<bf16,9,2>'         # conv_ws_kernel + conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> (pooled sources) + conv_pp_kernel
 CONV64_SYMBOLS = ('conv_ws_kernel', 'conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel')
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

@@ -386,6 +386,151 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
     }
 }
 
+// Warp-specialised twin of wgrad_tr_kernel<9, 2, 2, NQZ, true> (3x3 taps, 64 x 64 channel blocks, plain sources): 512
+// threads = two waves per SIMD with different jobs.  Waves 0-3 own one 32 x 32 quadrant each (144 accumulator registers) and
+// do nothing but transpose reads + MFMAs; waves 4-7 fill the OTHER LDS buffer with the next tile (BN affine + activation of
+// `a`, the dz operand(s)) and keep the tile after that in flight.  The single-role kernel runs fill and MFMAs back to back
+// at one wave per SIMD (SQ counters: 47% of the wave cycles issuing, 20% issue-stalled: profiles/r02_sq_counters.txt).
+// LDS tiles are 4 rows x 32 pixels (half of the single-role kernel's) so that two buffers fit: 2 x 48 KB.
+template <int NQZ>
+__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+    typedef bf16_t T;
+    constexpr int S = 8, TAPS = 9;
+    constexpr int THW = 4;
+    constexpr int PH = THW + 2, PW = TW + 2, NPIX = PH * PW;
+    constexpr int CA = 64, CZ = 64, PA = 144, PZ = 144;
+    constexpr int NSA = CA / S, NSZ = CZ / S;
+    constexpr int NITA = (NPIX * NSA + 255) / 256, NITZ = (THW * TW * NSZ) / 256;
+    constexpr int A_BYTES = (NPIX + 4) * PA, Z_BYTES = THW * TW * PZ, BUF = A_BYTES + Z_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // 0: MFMA waves, 1: loader waves
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int nbase = blockIdx.y * CZ, cbase = blockIdx.z * CA;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + THW - 1) / THW;
+    const int H = p.H, W = p.W;
+    auto coords = [&](int tile, int& n, int& y0, int& x0) {
+        n = tile / (tiles_x * tiles_y);
+        const int trem = tile - n * tiles_x * tiles_y;
+        y0 = (trem / tiles_x) * THW;
+        x0 = (trem % tiles_x) * TW;
+    };
+    {
+        uint4* z4 = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < 2 * BUF / 16; i += 512) z4[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    if (role == 1) {
+        // =============================================================================== loader waves
+        const GroupMap gm = make_gm(p.gstart, p.G);
+        const int sla = tid % NSA, slz = tid % NSZ;
+        const int ca_abs = cbase + sla * S, cz_abs = nbase + slz * S;
+        const int sia = (p.na == 1 || ca_abs < p.a[0].C) ? 0 : 1;
+        const rd_src_t sda = select_src(p.a, sia);
+        const int ca = ca_abs - (sia ? p.a[0].C : 0);
+        const bool live_a = ca_abs < p.Cin, live_z = cz_abs < p.Cout;
+        PlainSrc<T> psa, psz;
+        plain_src_init<T>(psa, sda, live_a ? ca : 0);
+        plain_src_init<T>(psz, p.dz, live_z ? cz_abs : 0);
+        ItemGeom<NITA> iga;
+        ItemGeom<NITZ> igz;
+#pragma unroll
+        for (int b = 0; b < NITA; ++b) {
+            const int pix = tid / NSA + (256 / NSA) * b, py = pix / PW, px = pix - py * PW;
+            iga.py[b] = (short)py;
+            iga.px[b] = (short)px;
+            iga.lds[b] = pix < NPIX ? pix * PA + sla * 16 : -1;
+        }
+#pragma unroll
+        for (int b = 0; b < NITZ; ++b) {
+            const int pix = tid / NSZ + (256 / NSZ) * b;
+            igz.py[b] = (short)(pix / TW);
+            igz.px[b] = (short)(pix % TW);
+            igz.lds[b] = pix * PZ + slz * 16;
+        }
+        uint4 raw_a[NITA][1], raw_z[NITZ][NQZ];
+        auto issue = [&](int tile) {
+            int n, y0, x0;
+            coords(tile, n, y0, x0);
+            if (live_a) pfu_issue<T, NITA>(raw_a, psa, iga, n, H, W, y0 - 1, x0 - 1);
+            if (live_z) pfu_issue<T, NITZ>(raw_z, psz, igz, n, H, W, y0, x0);
+        };
+        int g_ctx = -1, it = 0;
+        if ((int)blockIdx.x < total_tiles) issue(blockIdx.x);
+        for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
+            int n, y0, x0;
+            coords(tile, n, y0, x0);
+            const int g = group_of(gm, n);
+            if (g != g_ctx) {
+                if (live_a) plain_src_coef<T>(psa, sda, g, ca);
+                if (live_z) plain_src_coef<T>(psz, p.dz, g, cz_abs);
+                g_ctx = g;
+            }
+            char* s_a = smem + (it & 1) * BUF;
+            char* s_z = s_a + A_BYTES;
+            if (live_a)
+                pfu_consume<T, NITA, 1>(raw_a, psa, iga, H, W, y0 - 1, x0 - 1,
+                                        [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
+            if (live_z)
+                pfu_consume<T, NITZ, NQZ>(raw_z, psz, igz, H, W, y0, x0,
+                                          [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_z + l) = u; });
+            if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
+            __syncthreads();               // tile `it` is in its buffer; the MFMA waves are done with the other one
+        }
+        return;
+    }
+
+    // =================================================================================== MFMA waves
+    const int mb = wave >> 1, nb = wave & 1;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // fragment addressing: 16-lane group gq = lane >> 4 -> 16-channel sub-block (gq & 1), K half (gq >> 1)
+    const int i16 = lane & 15, gq = lane >> 4;
+    const int zoff = ((gq >> 1) * 8 + (i16 >> 2)) * PZ + (mb * 32 + (gq & 1) * 16 + (i16 & 3) * 4) * 2;
+    const int aoff = ((gq >> 1) * 8 + (i16 >> 2)) * PA + (nb * 32 + (gq & 1) * 16 + (i16 & 3) * 4) * 2;
+    int it = 0;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
+        __syncthreads();
+        const char* s_a = smem + (it & 1) * BUF;
+        const char* s_z = s_a + A_BYTES;
+#pragma unroll
+        for (int row = 0; row < THW; ++row) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* zp = s_z + zoff + (row * TW + ks * 16) * PZ;
+                const uint2 z0 = lds_tr(zp), z1 = lds_tr(zp + 4 * PZ);
+                const bf16x8 afrag = __builtin_bit_cast(bf16x8, make_uint4(z0.x, z0.y, z1.x, z1.y));
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const char* ap = s_a + aoff + ((row + kh) * PW + ks * 16) * PA;     // halo coords: input = output + tap
+                    const uint2 a0 = lds_tr(ap), a1 = lds_tr(ap + 4 * PA), a2 = lds_tr(ap + 8 * PA);
+                    const uint4 dq = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                    const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(a0.y, a0.x, 16), __builtin_amdgcn_alignbit(a1.x, a0.y, 16),
+                                                __builtin_amdgcn_alignbit(a1.y, a1.x, 16), __builtin_amdgcn_alignbit(a2.x, a1.y, 16));
+                    const uint4 m2 = make_uint4(a0.y, a1.x, a1.y, a2.x);
+                    acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kh * 3 + 0], 0, 0, 0);
+                    acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kh * 3 + 1], 0, 0, 0);
+                    acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kh * 3 + 2], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int li = lane & 31, h = lane >> 5;
+    float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nrow = nbase + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ccol = cbase + nb * 32 + li;
+            out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
+        }
+}
+
 // 16-channel twin of wgrad_tr_kernel (v_mfma_f32_16x16x32_bf16, K = the 32 pixels of a tile row, one 16x16 block,
 // the 4 waves split the 8 rows): 32 bytes of channels per pixel, pitch 48 B (disjoint 8-bank spans for 4 pixel rows).
 template <int TAPS, int NQZ>
@@ -688,6 +833,25 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<TAPS, MB, NB, 1, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
+    }
+    if constexpr (TAPS == 9 && MB == 2 && NB == 2) {
+        // 64 x 64 blocks, plain sources: the warp-specialised kernel (4-row LDS tiles: twice the tile count)
+        static const int ws = rd_switch("RD_WG_WS", 1);
+        if (ws && wgrad_pf_ok(p)) {
+            static bool ws_attr = false;
+            constexpr int ws_lds = 2 * ((6 * PW + 4) * 144 + 4 * TW * 144);
+            if (!ws_attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds);
+                ws_attr = true;
+            }
+            const int tiles_ws = p.N * ((p.H + 3) / 4) * ((p.W + TW - 1) / TW);
+            if (p.dz.mode == RD_SRC_BNBWD)
+                hipLaunchKernelGGL(wgrad_ws_kernel<2>, grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws);
+            else
+                hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws);
+            return (int)hipGetLastError();
+        }
     }
     if (!wgrad_pf_ok(p))
         hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);

@@ -10,9 +10,9 @@ sys.path.insert(0, ROOT)
 run = os.path.join(ROOT, 'gpurun_out', 'profiles_run')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 FAMILIES = {          # == bench.DOMINANT_SYMBOLS / bench.CONV64_SYMBOLS; 'count' = which symbols count as one launch
-    'wgrad': dict(frags=('wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel'),
-                  count=('wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel'),
-                  name='rd_wgrad: wgrad_tr_kernel / wgrad_c16_tr_kernel / wgrad_kernel + wgrad_reduce_kernel'),
+    'wgrad': dict(frags=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel'),
+                  count=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel'),
+                  name='rd_wgrad: wgrad_ws_kernel / wgrad_tr_kernel / wgrad_c16_tr_kernel / wgrad_kernel + wgrad_reduce_kernel'),
     'conv_kernel<bf16,9,2>': dict(frags=('conv_ws_kernel', 'conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel'), count=None,
                                   name='conv_ws_kernel + conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> + conv_pp_kernel'),
 }
