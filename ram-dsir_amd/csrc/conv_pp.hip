@@ -340,6 +340,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     typedef bf16_t T;
     constexpr int S = 8;
     static_assert(MODE == 1 || MODE == 2, "register epilogues only");
+    // who stages the weight chunk of the next step: the MFMA waves in the forward mode (they have ~1.5 issue slots per MFMA
+    // gap to spare and 36 registers of headroom; the loader's nine weight vectors cost 1000-3000 cycles per step on top of
+    // its ~3000 for the halo items against ~3300 of MFMAs: traces in profiles/r02_ws_trace.txt), the loader waves in the
+    // gradient mode (its MFMA waves are at the register limit, and its loader mostly copies raw dz vectors)
+    constexpr bool WMFMA = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // 0: MFMA waves, 1: loader waves
@@ -501,15 +506,19 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         begin_w();
 #pragma unroll
         for (int b = 0; b < PP_NIT; ++b) raw[b] = ld16g(ldbase + (size_t)(unsigned)offL[b] * (unsigned)ldC);
+        if constexpr (!WMFMA) {
 #pragma unroll
-        for (int t = 0; t < PP_WIT; ++t) wr[t] = ld16(wptr + t * w_tap);
+            for (int t = 0; t < PP_WIT; ++t) wr[t] = ld16(wptr + t * w_tap);
+        }
         shift_stages();
         begin_issue();
         begin_w();
 #pragma unroll
         for (int b = 0; b < PP_NIT; ++b) { consume_item(b, 0, true); raw[b] = ld16g(ldbase + (size_t)(unsigned)offL[b] * (unsigned)ldC); }
+        if constexpr (!WMFMA) {
 #pragma unroll
-        for (int t = 0; t < PP_WIT; ++t) { consume_w(t, 0); wr[t] = ld16(wptr + t * w_tap); }
+            for (int t = 0; t < PP_WIT; ++t) { consume_w(t, 0); wr[t] = ld16(wptr + t * w_tap); }
+        }
         shift_stages();
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
@@ -526,8 +535,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                 for (int b = 0; b < PP_NIT; ++b) { consume_item(b, nxt, false); issue_item(b); }
             }
             WS_T(1, s, 1);
+            if constexpr (!WMFMA) {
 #pragma unroll
-            for (int t = 0; t < PP_WIT; ++t) { consume_w(t, nxt); issue_w(t); }
+                for (int t = 0; t < PP_WIT; ++t) { consume_w(t, nxt); issue_w(t); }
+            }
             WS_T(1, s, 2);
             shift_stages();
             __syncthreads();
@@ -544,6 +555,24 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     M.tile = tile_begin;
     M.c = 0;
     pp_decode(M, q, gm);
+    // WMFMA: this wave's share of the weight chunk (thread -> row nn_w, channel slot sw, all nine taps), one step ahead in
+    // LDS and one more in registers, exactly as the loader does it in the other mode
+    uint4 wq[PP_WIT] = {};
+    PpStage Lw = M;                                        // the step whose weights are in flight
+    const int sw_w = tid & 3, nn_w = tid >> 2;
+    const int w_lds = PP_W0 + sw_w * PP_PLANE_W + nn_w * 16;
+    const T* wbase = reinterpret_cast<const T*>(p.w) + nn_w * 32 + sw_w * S;
+    const size_t w_tap = (size_t)p.CoutPad * 32;
+    auto w_issue = [&](int t) { wq[t] = ld16(wbase + ((size_t)(Lw.c * 9) * p.CoutPad + Lw.n0) * 32 + t * w_tap); };
+    auto w_store = [&](int t, int par) { *reinterpret_cast<uint4*>(smem + par * PP_W_BYTES + w_lds + t * (PP_NT * 16)) = wq[t]; };
+    if constexpr (WMFMA) {
+#pragma unroll
+        for (int t = 0; t < PP_WIT; ++t) w_issue(t);       // step 0
+        pp_advance(Lw, q, gm);
+#pragma unroll
+        for (int t = 0; t < PP_WIT; ++t) { w_store(t, 0); w_issue(t); }   // step 0 -> buffer 0, step 1 requested
+        pp_advance(Lw, q, gm);                             // Lw = step 2: what the first loop iteration requests
+    }
 
     // operand fragments of one (tap, k-step) group: A = 2 x (32 pixels x 16 channels), B = 2 x (32 outputs x 16 channels);
     // the next group is read while the four MFMAs of this one run (register double buffer at group granularity)
@@ -667,6 +696,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         load_group(0, par, fr[0]);
 #pragma unroll
         for (int grp = 0; grp < 18; ++grp) {
+            if constexpr (WMFMA) {
+                // weights of step s+1 (in registers since the previous step) -> the other buffer, step s+2 requested: one
+                // tap per (tap, k-step) group pair, between the MFMA groups
+                if ((grp & 1) == 0) { w_store(grp >> 1, par ^ 1); w_issue(grp >> 1); }
+            }
             if (grp + 1 < 18 && !WS_EXP(64)) load_group(grp + 1, par, fr[(grp + 1) & 1]);
             const Frag& f = fr[grp & 1];
             if (!WS_EXP(4)) {
@@ -752,6 +786,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         }
         WS_T(0, s, 2);
         pp_advance(M, q, gm);
+        if constexpr (WMFMA) pp_advance(Lw, q, gm);
         __syncthreads();
         WS_T(0, s, 3);
     }
