@@ -101,7 +101,9 @@ typedef struct {
     double* stats;       /* forward: [G][RD_STAT_SLOTS][Cout][2] += (sum, sum of squares) of the result BEFORE the bias, or NULL */
     rd_dst_t dst[2];     /* gradient: channels [0,c_split) -> dst[0], [c_split,Cout) -> dst[1] */
     int32_t c_split;
-    int32_t pad_;
+    int32_t cu_limit;    /* >0: compute-unit budget of the launch where the kernel is persistent (the small-channel kernel, the
+                          * warp-specialised 64-wide kernel): a conv of a side lane leaves the rest of the GPU to the main
+                          * chain; 0: the whole device */
 } rd_conv_t;
 
 int rd_conv(const rd_conv_t* p, int dtype, void* stream);
@@ -120,7 +122,9 @@ typedef struct {
     float* partial;
     float* dW;
     float beta;
-    int32_t pad_;
+    int32_t cu_limit;    /* >0: workgroup budget of the (persistent) launch in compute units -- a launch that runs on a side
+                          * stream beside the dgrad chain leaves the rest of the GPU to it; 0: the whole device.  Enters
+                          * rd_wgrad_workspace() (one partial per workgroup).  The 16-channel layers ignore it. */
 } rd_wgrad_t;
 
 int64_t rd_wgrad_workspace(const rd_wgrad_t* p, int dtype);

@@ -824,7 +824,8 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / PP_NT);
-    const int grid = tiles < n_cu ? tiles : n_cu;
+    const int cus = (p.cu_limit > 0 && p.cu_limit < n_cu) ? p.cu_limit : n_cu;     // a side lane's budget (ramdsir.h)
+    const int grid = tiles < cus ? tiles : cus;
     // Launches that qualify for a register epilogue (conv_dispatch.h: 1 forward, 2 gradient into plain tensors) take the
     // warp-specialised kernel.  Layer timings (scripts/ab_layers.sh, us, previous kernel -> conv_ws_kernel):
     //   forward:   256->256 @50x50 102 -> 90, 128->128 @100x100 99 -> 85, 64->64 @200x200 96 -> 84, 128->64 @100x100 62 -> 54,

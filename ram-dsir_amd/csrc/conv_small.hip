@@ -484,13 +484,18 @@ int launch_conv_small(const rd_conv_t& p, hipStream_t st) {
     // x 4 tile-times, 21 tiles/workgroup is 1 round x 21 -- charging half a tile-time per workgroup prologue
     int tpw = tpw_env;
     if (tpw <= 0) {
-        const long slots = 2L * rd_num_cus();
+        const bool limited = p.cu_limit > 0 && p.cu_limit < rd_num_cus();
+        const long slots = 2L * (limited ? p.cu_limit : rd_num_cus());
         double best = 1e30;
-        for (int t = 1; t <= 32 && t <= ntiles; ++t) {
+        // a limited launch (side lane: ramdsir.h cu_limit) must fit ONE round of its budget, however many tiles that takes
+        const int tmin = limited ? (int)(((long)ntiles * p.N + slots - 1) / slots) : 1;
+        for (int t = tmin < 1 ? 1 : tmin; (t <= 32 || limited) && t <= ntiles; ++t) {
             const long wgs = (long)((ntiles + t - 1) / t) * p.N;
             const double cost = (double)((wgs + slots - 1) / slots) * (t + 0.5);
             if (cost < best - 1e-9) { best = cost; tpw = t; }
+            if (limited) break;                             // the smallest count that fits is the one
         }
+        if (tpw <= 0) tpw = ntiles;
     }
     dim3 grid((ntiles + tpw - 1) / tpw, 1, p.N);
     static bool attr_set = false;

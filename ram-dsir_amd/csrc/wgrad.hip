@@ -759,6 +759,7 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
         g.CinPadW = (p.Cin + 15) / 16 * 16;
         g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
         // exactly the resident set (no second, partially filled round) at 3 workgroups/CU
+        // (cu_limit does not apply: these layers are the 400x400 / 200x200 ones, HBM-bound, and want every CU's load path)
         int gx = 3 * rd_num_cus() / (g.CinPadW / 16);
         if (gx > g.total_tiles) gx = g.total_tiles;
         g.gx = gx < 1 ? 1 : gx;
@@ -776,7 +777,10 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     const int pairs = (g.CoutPadW / (g.MB * 32)) * (g.CinPadW / (g.NB * 32));
     // these kernels hold 144 accumulator registers per lane -> one workgroup per CU is resident: launching more
     // workgroups than CUs only multiplies the partial-sum traffic (147 KB per workgroup for a 64x64 tile)
-    int gx = (rd_switch("RD_WG_SLOTS", 256) + pairs - 1) / pairs;
+    // cu_limit: a weight gradient launched on a side stream beside the dgrad chain takes only part of the GPU (its persistent
+    // workgroups cannot share a CU with the chain's kernels, so a full-width launch makes the chain wait: tuning.py side_cus)
+    const int slots = p.cu_limit > 0 ? p.cu_limit : rd_switch("RD_WG_SLOTS", 256);
+    int gx = (slots + pairs - 1) / pairs;
     if (gx > g.total_tiles) gx = g.total_tiles;
     if (gx < 1) gx = 1;
     g.gx = gx;

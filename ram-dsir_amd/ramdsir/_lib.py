@@ -31,13 +31,13 @@ class RdConv(C.Structure):
     _fields_ = [('src', RdSrc * 2), ('nsrc', i32), ('taps', i32), ('w', vp), ('bias', fp), ('CinPad', i32),
                 ('CoutPad', i32), ('N', i32), ('H', i32), ('W', i32), ('Cin', i32), ('Cout', i32), ('G', i32),
                 ('gstart', i32 * (MAXG + 1)), ('emode', i32), ('out', vp), ('stats', fp), ('dst', RdDst * 2),
-                ('c_split', i32), ('pad_', i32)]
+                ('c_split', i32), ('cu_limit', i32)]
 
 
 class RdWgrad(C.Structure):
     _fields_ = [('a', RdSrc * 2), ('na', i32), ('taps', i32), ('dz', RdSrc), ('N', i32), ('H', i32), ('W', i32),
                 ('Cin', i32), ('Cout', i32), ('G', i32), ('gstart', i32 * (MAXG + 1)), ('partial', fp), ('dW', fp),
-                ('beta', f32), ('pad_', i32)]
+                ('beta', f32), ('cu_limit', i32)]
 
 
 class RdBnFwd(C.Structure):

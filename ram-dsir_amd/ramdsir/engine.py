@@ -269,6 +269,8 @@ class Plan:
         # wgrad (level 2 at 400x400, 16 images: 576 -> ~230 us for the three launches; profiles/README.md round 2).
         # False: RD_SRC_POOL / RD_DST_POOL fused into the conv's tile loader / gradient epilogue.
         self.materialize_pool = T.options()['pool_mat']
+        self.side_cus = 0               # >0: compute-unit budget of the weight-gradient launches (they run on a side stream)
+        self.conv_cus = 0               # >0: compute-unit budget of this plan's persistent conv launches (a side-lane plan)
         self.materialize_min_c = None   # channels from which BN+ReLU outputs are stored once (rd_bn_apply)
         self.materialize_dz_min_c = None  # ... and from which the BN-backward gradients dz are
         self._unit = {}
@@ -404,6 +406,7 @@ class Plan:
                 continue
             # ---------------- forward conv
             p = L.RdConv()
+            p.cu_limit = int(self.conv_cus)
             for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
                 p.src[i] = self._src(a, mode, n_off, g_fixed)
             p.nsrc, p.taps = len(node.inputs), node.taps
@@ -495,6 +498,7 @@ class Plan:
             wg.G, wg.gstart = self.G, self.gs_arr
             wg.dW = self.bank.g(node.mname, node.name + '.weight').data_ptr()
             wg.beta = 0.0
+            wg.cu_limit = int(self.side_cus)
             ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
             self.keep.append(wg)
             node.wg = wg
@@ -539,6 +543,7 @@ class Plan:
             if all(d.kind == L.DST_NONE for d in dsts):
                 continue
             p = L.RdConv()
+            p.cu_limit = int(self.conv_cus)
             p.src[0] = self._dz_src(node)
             p.nsrc, p.taps = 1, node.taps
             p.w = wpack.ptr(node.mname, node.name, True)

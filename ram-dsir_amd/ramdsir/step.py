@@ -38,6 +38,7 @@ class TrainStep:
         self.seg = E.Plan(bank, dtype, 2 * B, [0, B, 2 * B], slope=slope)
         self.seg.pad_narrow = self.seg.materialize_up = True
         self.seg.materialize_pool = bool(opt['pool_mat'])
+        self.seg.side_cus = int(opt['side_cus']) if opt['fork'] else 0
         self.seg.materialize_min_c = opt['mat_min_c'] if opt['mat_min_c'] > 0 else None
         self.seg.materialize_dz_min_c = opt['mat_dz_min_c'] if opt['mat_dz_min_c'] > 0 else None
         slot = self.seg.slot_channels()
@@ -50,6 +51,9 @@ class TrainStep:
         self.rec = E.Plan(bank, dtype, B, gs, slope=slope)
         self.rec.pad_narrow = self.rec.materialize_up = True
         self.rec.materialize_pool = self.seg.materialize_pool
+        lane = bool(opt['fork'] and opt['rec_lane'])
+        self.rec.side_cus = int(opt['rec_cus']) if lane else 0    # its weight gradients run inline on its own lane
+        self.rec.conv_cus = int(opt['rec_cus']) if lane else 0
         self.rec.materialize_min_c = self.seg.materialize_min_c
         self.rec.materialize_dz_min_c = self.seg.materialize_dz_min_c
         self.rec_logits = E.build_rec_decoder(self.rec, self.feats[4], n_off=B, g_fixed=1, domains=list(range(len(batch_sizes))),

@@ -9,12 +9,17 @@ DEFAULTS = dict(
     mat_dz_min_c=64,      # store the BN-backward gradient dz once for layers with at least this many channels
     pool_mat=True,        # store the 2x2 max-pool in front of ConvD levels 2-5 once (rd_pool_fwd / rd_pool_bwd)
     side_streams=1,       # HIP streams for the weight-gradient launches
+    rec_cus=128,          # compute units the restoration-decoder lane's persistent launches may take (0: all); the lane ends
+                          # 1.4 ms before the main one, so it can run narrower: 5.59 -> 5.55 ms/step (96: 5.57, 64: 5.70)
+    side_cus=128,         # compute units a weight-gradient launch may take while it runs beside the dgrad chain (fork=True);
+                          # its persistent workgroups cannot share a CU with the chain's kernels: 256 -> 128 = 5.70 -> 5.63 ms/step
+                          # (144: 5.69, 112: 5.68, 96: 5.75, 64: 6.4); the HBM-bound 16-channel launches keep the whole GPU
     fork=True,            # eager launch over main / side / rec streams (False: one stream)
     rec_lane=True,        # the restoration decoder branch on its own stream
     graph_fork=False,     # capture(): keep the forks as graph branches (slower on ROCm 7: DESIGN.md section 3)
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
 )
-_ENV = dict(mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS',
+_ENV = dict(mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
             fork='RD_FORK', rec_lane='RD_REC_LANE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
 
 
