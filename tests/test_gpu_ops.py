@@ -230,6 +230,8 @@ WG_CASES = [
     ('cat64_aff64_64_rawdz', 9, [(L.SRC_AFFACT, 64), (L.SRC_AFFACT, 64)], 64, 3, 10, 12, 0),
     ('c64_64_many_tiles', 9, [(L.SRC_AFFACT, 64)], 64, 4, 40, 70, 1),
     ('c256_128', 9, [(L.SRC_AFFACT, 256)], 128, 2, 6, 7, 1),
+    ('c64_64_25x25', 9, [(L.SRC_AFFACT, 64)], 64, 3, 25, 25, 1),       # 4-row tiles of the warp-specialised kernel: one live row in the last
+    ('c128_64_25x25_rawdz', 9, [(L.SRC_AFFACT, 128)], 64, 3, 25, 25, 0),
     ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, 0),
     ('k1_128_64', 1, [(L.SRC_AFFACT, 128)], 64, 2, 10, 34, 0),
     ('k1_16_16', 1, [(L.SRC_AFFACT, 16)], 16, 2, 20, 20, 0),
