@@ -236,8 +236,9 @@ def main():
     bank, mods = S.make_bank(dev, 3, 16, 2, len(bs))
     init_weights(bank)
     params0 = bank.params.clone()
+    # a captured graph replays ONE chain: nothing runs beside the weight gradients, so they keep the whole GPU (tuning.py)
     ts = S.TrainStep(bank, mods, dtype, bs, Sz, Sz, dataset='fundus', consistency='kd', lambda_rec=0.1, lr=2e-3,
-                     total_iters=21200, ram='u8')
+                     total_iters=21200, ram='u8', options=dict(side_cus=0, rec_cus=0) if args.graph else None)
     ts.wpack.refresh()
     src, trg, lam, mask, host_inputs = synth_inputs(B, Sz, rank, dev)
     ts.load_raw(src, trg, lam)

@@ -23,7 +23,9 @@ class FusedTrainer:
         slope = encoder._slope
         self.ts = S.TrainStep(self.bank, mods, dtype, batch_sizes, H, W, dataset=dataset, consistency=consistency,
                               lambda_rec=lambda_rec, lr=lr, total_iters=total_iters, in_channels=encoder._c, n=encoder._n,
-                              num_classes=seg_decoder._k, slope=slope, ram='u8' if dataset == 'fundus' else True)
+                              num_classes=seg_decoder._k, slope=slope, ram='u8' if dataset == 'fundus' else True,
+                              # a captured graph replays one chain: no lane to leave compute units to (tuning.py)
+                              options=dict(side_cus=0, rec_cus=0) if use_graph else None)
         self.ts.wpack.refresh()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         if self.world > 1:
