@@ -190,6 +190,29 @@ def fp32_leg(bank_init, bs, Sz, dev, src, trg, lam, mask, steps=6, warmup=2):
     return out
 
 
+def bucket_allreduce_us(runner, world, reps=10):
+    """Mean time of each gradient bucket's all-reduce alone (HIP events on the stream the step launches it from), in the
+    order the step issues them (decoders, encoder levels 3-5, encoder levels 1-2), with the payload sizes."""
+    import torch.distributed as dist
+    comm, out = runner.comm, []
+    for i in (2, 1, 0):
+        t = runner.buckets.views[i]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(comm):
+            e0.record(comm)
+            for _ in range(reps):
+                w = runner.buckets.reduce(i, async_op=True)
+                if w is not None:
+                    w.wait()
+            e1.record(comm)
+        torch.cuda.synchronize()
+        out.append(dict(bucket=i, bytes=int(t.numel() * t.element_size()), allreduce_us=round(e0.elapsed_time(e1) * 1e3 / reps, 1)))
+    return out
+
+
 def whole_step_roofline(B, Sz, ms_per_step, dtype):
     """SURVEY.md 8(d) conventions for the WHOLE step: algorithmic bytes = every conv reads its logical input once and
     writes its output once, everything else fused (170.3 M elements forward per image at 400x400, x3 for forward +
@@ -223,6 +246,9 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d runs one rank per GPU but WORLD_SIZE is %d: launch it with `python -m torch.distributed.run '
+                         '--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...`' % (args.gpus, world, args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import torch.distributed as dist
@@ -249,6 +275,9 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    runner = None
+    if world > 1:
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)      # what RCCL sees == what was asked for
     if world > 1 or force_ddp:
         runner = D.DataParallelStep(ts)
         if args.graph:
@@ -278,6 +307,9 @@ def main():
     elapsed = float(el.item())
     losses = ts.loss_dict()
     assert np.isfinite(losses['loss']), losses
+    # data parallel: each gradient bucket's all-reduce on its own (nothing else on the GPU), so that a multi-GPU run says
+    # what the exchange costs next to what the step hides of it
+    exchange = bucket_allreduce_us(runner, world) if runner is not None else None
 
     if rank == 0:
         out = {
@@ -287,6 +319,7 @@ def main():
             'config': {'workload': 'Fundus target0 --ram --rec --consistency kd, batch 8=[2,3,3] per GPU, %dx%dx3' % (Sz, Sz),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world,
                        'process_group': ('%s world %d' % (dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else 'none (single process)', 'hipgraph': bool(args.graph), 'streams': 1 if (args.graph or not ts.fork) else 1 + len(ts.lanes()),
+                       'lanes_verified': bool(ts.lanes_verified), 'gradient_exchange': exchange,
                        'final_loss': round(losses['loss'], 4)},
         }
         out['roofline_step'] = whole_step_roofline(B, Sz, out['ms_per_step'], args.dtype)

@@ -295,6 +295,11 @@ typedef struct {
 } rd_adam_t;
 int rd_adam_step(const rd_adam_t* p, void* stream);
 
+/* optimizer.zero_grad() (code/train.py:285,454) and the per-step reset of the BatchNorm sum buffers (stats / bstats arenas,
+ * which the conv epilogues add into): n device ranges [ptrs_host[i], +bytes_host[i]) := 0, asynchronously on `stream`.
+ * The two arrays are HOST arrays (read before the call returns). */
+int rd_zero(void* const* ptrs_host, const int64_t* bytes_host, int n, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Random Amplitude Mixup for a whole batch on the GPU.  Replaces extract_amp_spectrum /

@@ -341,4 +341,15 @@ int rd_adam_step(const rd_adam_t* p, void* stream) {
     return (int)hipGetLastError();
 }
 
+// optimizer.zero_grad() (train.py:285,454) + the per-step reset of the BatchNorm sum buffers: n device ranges set to zero bytes
+// by the copy engine / blit path of the runtime on `stream` (no tensor-library operator on the step path)
+int rd_zero(void* const* ptrs_host, const int64_t* bytes_host, int n, void* stream) {
+    if (n < 0 || (n > 0 && (!ptrs_host || !bytes_host))) return -1;
+    for (int i = 0; i < n; ++i) {
+        if (!ptrs_host[i] || bytes_host[i] <= 0) continue;
+        RD_CHECK(hipMemsetAsync(ptrs_host[i], 0, (size_t)bytes_host[i], (hipStream_t)stream));
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -779,7 +779,7 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     // workgroups than CUs only multiplies the partial-sum traffic (147 KB per workgroup for a 64x64 tile)
     // cu_limit: a weight gradient launched on a side stream beside the dgrad chain takes only part of the GPU (its persistent
     // workgroups cannot share a CU with the chain's kernels, so a full-width launch makes the chain wait: tuning.py side_cus)
-    const int slots = p.cu_limit > 0 ? p.cu_limit : rd_switch("RD_WG_SLOTS", 256);
+    const int slots = p.cu_limit > 0 ? p.cu_limit : rd_switch("RD_WG_SLOTS", rd_num_cus());
     int gx = (slots + pairs - 1) / pairs;
     if (gx > g.total_tiles) gx = g.total_tiles;
     if (gx < 1) gx = 1;

@@ -109,6 +109,7 @@ _SIGS = {
                               C.c_int, vp]),
     'rd_rec_loss_workspace': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'rd_adam_step': (C.c_int, [C.POINTER(RdAdam), vp]),
+    'rd_zero': (C.c_int, [C.POINTER(vp), C.POINTER(i64), C.c_int, vp]),
 }
 
 _lib = None

@@ -59,7 +59,7 @@ class DataParallelStep:
         # The collectives are LAUNCHED from the weight-gradient lane (RCCL runs them on its own stream and only makes that
         # stream wait for the launching one): a separate communication stream would be the fifth stream of the step, and
         # HIP gives a process four hardware queues -- a fifth one aliases a lane (streams.py; 5.9 -> 9-11 ms/step measured)
-        self.comm = ts.side[0]
+        self.comm = torch.cuda.Stream(device=b.device) if ts.opt['ddp_own_comm_stream'] else ts.side[0]
         self.graphs = None
 
     def _segments(self):
@@ -68,6 +68,7 @@ class DataParallelStep:
 
     def capture(self):
         ts = self.ts
+        ts._refuse_budgets_on_one_chain('DataParallelStep.capture()')
         ts.wpack.refresh(ts._stream())
         torch.cuda.synchronize()
         saved = ts._snapshot()

@@ -41,7 +41,7 @@ class TrainStep:
         # lane budgets are tuned for the bf16 kernels (in fp32 the weight gradients are several times heavier and the side lane
         # itself becomes the critical path when it is narrowed: 315 -> 268 images/s)
         budget = bool(opt['fork']) and dtype == torch.bfloat16
-        self.seg.side_cus = int(opt['side_cus']) if budget else 0
+        self.seg.side_cus = T.cu_budget(opt['side_cus'], dev) if budget else 0
         self.seg.materialize_min_c = opt['mat_min_c'] if opt['mat_min_c'] > 0 else None
         self.seg.materialize_dz_min_c = opt['mat_dz_min_c'] if opt['mat_dz_min_c'] > 0 else None
         slot = self.seg.slot_channels()
@@ -55,8 +55,8 @@ class TrainStep:
         self.rec.pad_narrow = self.rec.materialize_up = True
         self.rec.materialize_pool = self.seg.materialize_pool
         lane = bool(budget and opt['rec_lane'])
-        self.rec.side_cus = int(opt['rec_cus']) if lane else 0    # its weight gradients run inline on its own lane
-        self.rec.conv_cus = int(opt['rec_cus']) if lane else 0
+        self.rec.side_cus = T.cu_budget(opt['rec_cus'], dev) if lane else 0    # its weight gradients run inline on its own lane
+        self.rec.conv_cus = T.cu_budget(opt['rec_cus'], dev) if lane else 0
         self.rec.materialize_min_c = self.seg.materialize_min_c
         self.rec.materialize_dz_min_c = self.seg.materialize_dz_min_c
         self.rec_logits = E.build_rec_decoder(self.rec, self.feats[4], n_off=B, g_fixed=1, domains=list(range(len(batch_sizes))),
@@ -113,6 +113,7 @@ class TrainStep:
             self.ram = R.RamMixer(B, H, W, dtype, dev, dataset)
             self.ram.bind(self.src, self.trg, self.lam, self.x.buf[:B], self.x.buf[B:])
         self.graph = None
+        self._zero_args = None
         # eager execution uses three HIP streams (Plan.run_lanes): main = the forward / dgrad chain, 'side' = the
         # weight-gradient kernels beside it, 'rec' = the whole restoration-decoder branch beside the seg decoder.
         # RD_FORK=0: everything on one stream.  Captured into a hipGraph the same forks become parallel branches,
@@ -125,6 +126,8 @@ class TrainStep:
             picked = streams.pick_lanes(self.n_side + 1, dev, [torch.cuda.current_stream(dev)]) if opt['fork'] else \
                 [torch.cuda.Stream(device=dev) for _ in range(self.n_side + 1)]
         self.side, self.rec_stream = picked[:self.n_side], picked[self.n_side]
+        # True: every lane stream was MEASURED to run beside the main stream and the other lanes (bench.py reports it)
+        self.lanes_verified = bool(opt['fork']) and all(streams.verified.get(id(st), False) for st in picked)
         self.fork = bool(opt['fork'])
         self.rec_lane = bool(opt['rec_lane'])
         self._ops = self._build_ops()
@@ -185,7 +188,13 @@ class TrainStep:
 
     def load_raw(self, src_nhwc, trg_nhwc, lam):
         """RAM inputs: what Fundus_Multi.__getitem__ holds before the FFTs (fundus.py:209-212): the
-        transformed image and the partner image as HWC arrays (uint8 or float32), and the mix ratio."""
+        transformed image and the partner image as HWC arrays, and the mix ratio.  The buffers are uint8 when the step
+        was built with ram='u8' (decoded PNG pixels) and float32 otherwise; a float image handed to a uint8 step would be
+        truncated / wrapped by the copy where the reference mixes it as float32, so that combination is refused."""
+        for name, t in (('src', src_nhwc), ('trg', trg_nhwc)):
+            if self.src.dtype == torch.uint8 and t.dtype != torch.uint8:
+                raise TypeError('%s images are %s but this TrainStep was built with ram=\'u8\' (uint8 buffers): pass uint8 '
+                                'pixels or build the step with ram=True (float32 buffers)' % (name, t.dtype))
         self.src.copy_(src_nhwc)
         self.trg.copy_(trg_nhwc)
         self.lam.copy_(lam)
@@ -198,10 +207,12 @@ class TrainStep:
         return torch.cuda.current_stream().cuda_stream
 
     # ---- execution
-    def zero(self):
-        self.seg.stat_arena.zero_()
-        self.rec.stat_arena.zero_()
-        self.bank.grads.zero_()
+    def zero(self, stream=None):
+        """optimizer.zero_grad() (train.py:285) + the BatchNorm sum arenas, through the library (rd_zero)."""
+        if self._zero_args is None:
+            ts = (self.seg.stat_arena, self.rec.stat_arena, self.bank.grads)
+            self._zero_args = ((L.vp * 3)(*[t.data_ptr() for t in ts]), (L.i64 * 3)(*[t.numel() * t.element_size() for t in ts]))
+        L.check(L.lib().rd_zero(self._zero_args[0], self._zero_args[1], 3, self._stream() if stream is None else stream), 'rd_zero')
 
     def run_segment(self, ops, main=None, lanes=None, wrap=None):
         """One segment over the lanes; every lane it used is joined before returning."""
@@ -217,6 +228,7 @@ class TrainStep:
 
     def capture(self):
         """Capture one step (zeroing + every launch) into a hipGraph on a side stream."""
+        self._refuse_budgets_on_one_chain('capture()')
         self.wpack.refresh(self._stream())
         torch.cuda.synchronize()
         st = torch.cuda.Stream()
@@ -233,6 +245,14 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(st)
         self.graph = g
         return g
+
+    def _refuse_budgets_on_one_chain(self, what):
+        """The lane budgets (tuning.py side_cus / rec_cus) are baked into the launch descriptors and the weight-gradient
+        workspace when the plans are built; on ONE chain (a captured graph without forked branches) they would silently run
+        the weight gradients and the restoration branch on half of the GPU."""
+        if (self.seg.side_cus or self.rec.side_cus or self.rec.conv_cus) and not self.opt['graph_fork']:
+            raise ValueError('%s runs the step as one chain, but this TrainStep was built with lane budgets (side_cus=%d, rec_cus=%d): '
+                             'build it with options=dict(side_cus=0, rec_cus=0)' % (what, self.seg.side_cus, self.rec.conv_cus))
 
     def _snapshot(self):
         b = self.bank

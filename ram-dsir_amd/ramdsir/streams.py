@@ -8,36 +8,36 @@ scripts/ddp_diag.py).  Raising GPU_MAX_HW_QUEUES is not the
 the data-parallel step took 9-10 ms.  So the lanes are picked by measurement: a candidate stream is accepted only if a tiny
 kernel on it completes while a long spin kernel occupies each stream it has to run beside."""
 import sys
-import time
 
 import torch
 
 _SPIN = 6_000_000            # cycles of torch.cuda._sleep: a few ms
 
 
-def _spin_ms(stream):
+def runs_beside(busy, probe, scratch):
+    """True when work submitted to `probe` does not wait for work running on `busy`.  Timed on the GPU: events around the
+    spin kernel on `busy` and behind a tiny kernel on `probe` -- host wall-clock jitter (a busy host, another rank
+    sharing the device) cannot turn an independent queue into an aliased one or the other way round."""
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        torch.cuda._sleep(_SPIN)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) * 1e3
-
-
-def runs_beside(busy, probe, scratch, spin_ms):
-    """True when work submitted to `probe` does not wait for work running on `busy`."""
-    torch.cuda.synchronize()
+    e0, e1, ep = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     with torch.cuda.stream(busy):
+        e0.record(busy)
         torch.cuda._sleep(_SPIN)
-    ev = torch.cuda.Event()
+        e1.record(busy)
     with torch.cuda.stream(probe):
         scratch.add_(1.0)
-        ev.record(probe)
-    t0 = time.perf_counter()
-    ev.synchronize()
-    dt = (time.perf_counter() - t0) * 1e3
+        ep.record(probe)
     torch.cuda.synchronize()
-    return dt < 0.3 * spin_ms
+    return e0.elapsed_time(ep) < 0.3 * e0.elapsed_time(e1)
+
+
+def _beside_consistent(busy, probe, scratch):
+    """Two probes that agree, or the majority of three."""
+    a, b = runs_beside(busy, probe, scratch), runs_beside(busy, probe, scratch)
+    return a if a == b else runs_beside(busy, probe, scratch)
+
+
+verified = {}                # id(stream) -> True / False: what the last pick_lanes call measured (TrainStep.lanes_verified)
 
 
 def pick_lanes(n, device, beside, tries=12):
@@ -49,30 +49,37 @@ def pick_lanes(n, device, beside, tries=12):
         return _pick(n, device, list(beside), tries)
     except Exception as e:                                  # a stack without torch.cuda._sleep, a probe that fails: lanes still work
         print('[ramdsir] lane-stream probing failed (%s: %s); using unverified streams' % (type(e).__name__, e), file=sys.stderr)
-        return [torch.cuda.Stream(device=device) for _ in range(n)]
+        out = [torch.cuda.Stream(device=device) for _ in range(n)]
+        for st in out:
+            verified[id(st)] = False
+        return out
 
 
 def _pick(n, device, beside, tries):
     scratch = torch.zeros(256, device=device)
-    spin_ms = min(_spin_ms(beside[0]) for _ in range(2))
     chosen, rejected = [], []
     for _ in range(tries):
         if len(chosen) == n:
             break
         cand = torch.cuda.Stream(device=device)
         # a stream's FIRST submission can go to whichever hardware queue is idle at that moment; only from the second one on
-        # does it show the queue it keeps (scripts/pick_debug.py): warm it up, then ask twice
+        # does it show the queue it keeps (scripts/pick_debug.py): warm it up, then ask (twice, a third time on disagreement)
         with torch.cuda.stream(cand):
             scratch.add_(1.0)
         torch.cuda.synchronize()
-        if all(runs_beside(b, cand, scratch, spin_ms) and runs_beside(b, cand, scratch, spin_ms) for b in list(beside) + chosen):
+        if all(_beside_consistent(b, cand, scratch) for b in list(beside) + chosen):
             chosen.append(cand)
+            verified[id(cand)] = True
         else:
             rejected.append(cand)
     if len(chosen) < n:
         print('[ramdsir] only %d of %d lane streams run concurrently with the main stream on this stack; '
               'the remaining lanes share a hardware queue (slower, still correct)' % (len(chosen), n), file=sys.stderr)
+        for st in rejected[:n - len(chosen)]:
+            verified[id(st)] = False
         chosen += rejected[:n - len(chosen)]
         while len(chosen) < n:
-            chosen.append(torch.cuda.Stream(device=device))
+            st = torch.cuda.Stream(device=device)
+            verified[id(st)] = False
+            chosen.append(st)
     return chosen

@@ -44,7 +44,8 @@ class FusedTrainer:
             self._step = self.ts.step
 
     def step(self, src_nhwc, trg_nhwc, lam, target):
-        """src/trg: fp32 NHWC images as the dataset holds them before RAM (0..255 fundus, [-1,1] prostate);
+        """src/trg: NHWC images as the dataset holds them before RAM -- fundus: uint8 pixels 0..255 (the step is built with
+        uint8 RAM buffers; float images are refused by TrainStep.load_raw), prostate: float32 in [-1,1];
         lam: [B]; target: fundus (B,2,H,W) float multilabel mask / prostate (B,H,W) int64."""
         self.ts.load_raw(src_nhwc, trg_nhwc, lam)
         self.ts.load_target(target)

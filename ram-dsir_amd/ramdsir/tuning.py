@@ -9,18 +9,23 @@ DEFAULTS = dict(
     mat_dz_min_c=64,      # store the BN-backward gradient dz once for layers with at least this many channels
     pool_mat=True,        # store the 2x2 max-pool in front of ConvD levels 2-5 once (rd_pool_fwd / rd_pool_bwd)
     side_streams=1,       # HIP streams for the weight-gradient launches
-    rec_cus=128,          # compute units the restoration-decoder lane's persistent launches may take (0: all); the lane ends
+    rec_cus=-1,           # compute units the restoration-decoder lane's persistent launches may take (0: all, -1: half of
+                          # the device = 128 on MI355X, where the numbers below were measured); the lane ends
                           # 1.4 ms before the main one, so it can run narrower: 5.59 -> 5.55 ms/step (96: 5.57, 64: 5.70)
-    side_cus=128,         # compute units a weight-gradient launch may take while it runs beside the dgrad chain (fork=True);
+    side_cus=-1,          # compute units a weight-gradient launch may take while it runs beside the dgrad chain (fork=True;
+                          # 0: all, -1: half of the device);
                           # its persistent workgroups cannot share a CU with the chain's kernels: 256 -> 128 = 5.70 -> 5.63 ms/step
                           # (144: 5.69, 112: 5.68, 96: 5.75, 64: 6.4); the HBM-bound 16-channel launches keep the whole GPU
     fork=True,            # eager launch over main / side / rec streams (False: one stream)
     rec_lane=True,        # the restoration decoder branch on its own stream
     graph_fork=False,     # capture(): keep the forks as graph branches (slower on ROCm 7: DESIGN.md section 3)
+    ddp_own_comm_stream=False,  # data parallel: launch the all-reduces from a stream of their own instead of the weight-gradient
+                          # lane (a fifth stream: aliases a lane's hardware queue on a 4-queue stack, ddp.py; UNMEASURED on a
+                          # multi-GPU node either way -- SCALE_r0x were skipped -- hence selectable)
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
 )
 _ENV = dict(mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
-            fork='RD_FORK', rec_lane='RD_REC_LANE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
+            ddp_own_comm_stream='RD_DDP_OWN_COMM', fork='RD_FORK', rec_lane='RD_REC_LANE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
 
 
 def options(over=None):
@@ -30,8 +35,17 @@ def options(over=None):
             if name in os.environ:
                 o[k] = type(DEFAULTS[k])(int(os.environ[name]))
     if over:
+        over = {k: v for k, v in over.items() if v is not None}
         unknown = set(over) - set(DEFAULTS)
         if unknown:
             raise KeyError('unknown tuning option(s): %s' % sorted(unknown))
         o.update(over)
     return o
+
+
+def cu_budget(value, device):
+    """side_cus / rec_cus -> compute units: -1 = half of the device's compute units (the measured optimum on the 256-CU MI355X)."""
+    if value >= 0:
+        return int(value)
+    import torch
+    return torch.cuda.get_device_properties(device).multi_processor_count // 2

@@ -8,8 +8,9 @@ training semantics (code/train.py:195-361, 363-528, 530-601) -- on the fused HIP
 
 Differences, all deliberate: (i) RAM runs on the GPU per batch (the DataLoader workers only pick the partner
 image and lambda); (ii) the step is a static launch list enqueued ahead of the GPU, so the five loss scalars are read every
---log_every iterations instead of forcing a device sync every iteration (train.py:298-304); (iii) multi-GPU is
-one process per GPU with an RCCL gradient all-reduce instead of nn.DataParallel; (iv) tensorboard image
+--log_every iterations instead of forcing a device sync every iteration (train.py:298-304) -- and written, under the
+reference's tags, to a TensorBoard event file in <save_path>/log (utils/tfevents.py: tensorboardX is not a dependency);
+(iii) multi-GPU is one process per GPU with an RCCL gradient all-reduce instead of nn.DataParallel; (iv) tensorboard image
 grids and the source-tree snapshot (train.py:306-329,534-536) are not reproduced.
 """
 import argparse
@@ -35,6 +36,7 @@ from dataset.fundus import Fundus_Multi, Fundus
 from dataset.prostate import Prostate_Multi
 from networks.unet import Encoder, Decoder, Rec_Decoder, count_params
 from utils.metrics import postprocessing, dice_coeff_2label, post_and_dice
+from utils.tfevents import SummaryWriter
 
 fundus_batch_list = [[3, 6, 7], [2, 7, 7], [2, 4, 10], [2, 4, 10]]              # train.py:35-38
 prostate_batch_list = [[2, 2, 2, 2, 2]] * 6                                       # train.py:40-45
@@ -82,6 +84,15 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+def worker_cap(requested, world, n_domains, cpus=None):
+    """DataLoader workers per domain loader of one rank: min(requested, cores // (domains x ranks)), at least 1 unless 0 was
+    asked for (single-process loading)."""
+    if requested <= 0:
+        return 0
+    cpus = cpus or os.cpu_count() or 8
+    return max(1, min(requested, cpus // max(1, n_domains * world)))
+
+
 def seed_worker(worker_id):
     worker_seed = torch.initial_seed() % 2 ** 32
     np.random.seed(worker_seed)
@@ -112,9 +123,7 @@ def _close_val():
     for loader, pool in _VAL.values():
         pool.terminate()
         pool.join()
-        it = getattr(loader, '_iterator', None)
-        if it is not None:
-            it._shutdown_workers()
+        del loader                                          # persistent workers shut down with the loader's iterator
     _VAL.clear()
 
 
@@ -172,10 +181,22 @@ def main(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    data_root = os.path.join(args.data_root, args.dataset)
+    # The validation pool (fork) and the persistent test loader are created HERE, before the first GPU call of this process:
+    # their children are forked from an address space that has never initialised HIP (rank 0 validates, below)
+    has_val = args.dataset == 'fundus' and os.path.exists(os.path.join(data_root, 'Domain%d_test.list' % (args.test_domain_idx + 1)))
+    if rank == 0 and has_val:
+        _val_resources(data_root, args.test_domain_idx, args.test_batch_size)
+    # DataLoader workers per domain loader: the reference's 8 (train.py:558) on one GPU; under torchrun every rank has its own
+    # three loaders, so the host's cores are divided among ranks x domains (8 ranks x 3 x 8 = 192 decoder processes otherwise)
+    n_dom = len(args.domain_idxs.split(','))
+    args.num_workers = worker_cap(args.num_workers, world, n_dom)
     torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    data_root = os.path.join(args.data_root, args.dataset)
+    # host-side rendezvous (gloo) for the points where ranks wait for rank 0 on the CPU (validation): an RCCL barrier is a GPU
+    # kernel that spins until every peer has arrived
+    host_group = dist.new_group(backend='gloo') if world > 1 else None
     os.makedirs(args.save_path, exist_ok=True)
 
     zoo = {'fundus': Fundus_Multi, 'prostate': Prostate_Multi}
@@ -223,6 +244,7 @@ def main(args):
                            consistency=cons, lambda_rec=args.lambda_rec, lr=args.lr, total_iters=total_iters,
                            dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
 
+    writer = SummaryWriter(os.path.join(args.save_path, 'log')) if rank == 0 else None      # train.py:538
     previous_best, iter_num = 0.0, 0
     t_mark, it_mark, imgs_per_iter = None, 0, world * sum(bsl[:len(domain_idx_list)])
     for epoch in range(args.epochs):
@@ -244,8 +266,12 @@ def main(args):
             if iter_num % args.log_every == 0:
                 l = trainer.losses()                    # collective when world > 1: the mean over the ranks
             if rank == 0 and iter_num % args.log_every == 0:
-                print('iter %d lr %.6f ' % (iter_num, trainer.lr()) + ' '.join('%s %.4f' % (k, v) for k, v in l.items() if k != 'rec')
+                lr_now = trainer.lr()
+                print('iter %d lr %.6f ' % (iter_num, lr_now) + ' '.join('%s %.4f' % (k, v) for k, v in l.items() if k != 'rec')
                       + ' loss_rec %.4f' % (sum(l['rec']) / 4))               # train.py:304 logs avg/4
+                # the reference's scalars (train.py:298-304 / 467-473), at the iterations whose losses are read back
+                writer.add_scalars_at(iter_num, [('lr', lr_now)] + [('loss/' + k, v) for k, v in l.items() if k not in ('rec', 'loss')]
+                                      + [('loss/loss_rec', sum(l['rec']) / 4)])
             iter_num += 1
             if iter_num == 5:                           # end-to-end throughput (files -> DataLoader -> H2D -> step), start-up excluded
                 torch.cuda.synchronize()
@@ -270,6 +296,12 @@ def main(args):
             if os.path.isdir(os.path.join(data_root, DOMAIN_LIST[args.test_domain_idx])):
                 print('Test on target domain {}'.format(args.test_domain_idx))
                 avg_dice = test_prostate(encoder, seg_decoder, epoch, data_root, args.test_domain_idx, args.save_path, args.test_batch_size)
+        if world > 1:
+            # every rank has finished its epoch (synchronize above) and none has entered the next step's all-reduce: the
+            # other ranks wait HERE, on the host (gloo), while rank 0 validates with replica 0's BatchNorm statistics (what
+            # nn.DataParallel evaluates, train.py:343) -- not inside an RCCL gradient exchange with a missing peer, which
+            # spins their GPUs and, past the watchdog timeout, aborts the job
+            dist.barrier(group=host_group)
         if avg_dice is not None and avg_dice >= previous_best:
             if previous_best != 0:
                 old = os.path.join(args.save_path, 'model_%.2f.pth' % previous_best)
@@ -286,9 +318,11 @@ def main(args):
     if rank == 0:
         save_checkpoint(os.path.join(args.save_path, 'final_model.pth'), encoder, seg_decoder, rec_decoder)
         print('\nSave Final Model to {}'.format(args.save_path))
+    if writer is not None:
+        writer.close()
     _close_val()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=host_group)
 
 
 if __name__ == '__main__':

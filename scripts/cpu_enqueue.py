@@ -26,6 +26,9 @@ print('eager: CPU enqueue %.2f ms/step, until GPU done %.2f ms/step (%d launches
 torch.cuda.synchronize()
 t0 = time.perf_counter(); ts.step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print('single step on an idle GPU: enqueue %.2f ms, done after %.2f ms' % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+# one chain: rebuilt without the lane budgets (TrainStep.capture refuses them)
+ts = S.TrainStep(bank, mods, torch.bfloat16, [2, 3, 3], 400, 400, ram='u8', options=dict(side_cus=0, rec_cus=0))
+ts.wpack.refresh(); ts.load_raw(src, trg, lam); ts.load_target(mask)
 ts.capture()
 for _ in range(3):
     ts.step()

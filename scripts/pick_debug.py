@@ -10,8 +10,6 @@ if len(sys.argv) > 1 and sys.argv[1] == 'pg':
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 main = torch.cuda.current_stream(dev)
 scratch = torch.zeros(256, device=dev)
-spin = min(ST._spin_ms(main) for _ in range(2))
-print('spin ms', spin)
 cands = [torch.cuda.Stream(device=dev) for _ in range(8)]
 def dt(busy, probe):
     torch.cuda.synchronize()
@@ -30,3 +28,4 @@ picked = ST.pick_lanes(2, dev, [main])
 print('picked vs main:', ['%.2f' % dt(main, p) for p in picked], 'picked pair:', '%.2f' % dt(picked[0], picked[1]))
 for rnd in range(2):
     print('again picked vs main:', ['%.2f' % dt(main, p) for p in picked])
+print('verified (GPU-timed):', [ST.verified.get(id(p)) for p in picked], 'beside main again:', [ST.runs_beside(main, p, scratch) for p in picked])

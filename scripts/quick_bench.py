@@ -18,7 +18,8 @@ for (m, k), (off, shape) in bank.index.items():
         v.fill_(1.0)
     else:
         v.zero_()
-ts = S.TrainStep(bank, mods, dtype, [2, 3, 3], Ssz, Ssz, dataset='fundus', consistency='kd')
+ts = S.TrainStep(bank, mods, dtype, [2, 3, 3], Ssz, Ssz, dataset='fundus', consistency='kd',
+                 options=dict(side_cus=0, rec_cus=0) if graph else None)
 ts.wpack.refresh()
 img = torch.rand(8, 3, Ssz, Ssz, device='cuda') * 2 - 1
 imgf = (img + 0.2 * torch.randn_like(img)).clamp(-1, 1)

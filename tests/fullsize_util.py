@@ -112,7 +112,8 @@ def hip_step(cfg, states, src, trg, lam, mask, dtype, consistency='kd', lr=2e-3,
     for m, sd in zip(('enc', 'dec', 'rec'), states):
         S.load_state(bank, m, sd)
     ts = S.TrainStep(bank, mods, dtype, cfg['bs'], cfg['S'], cfg['S'], dataset=cfg['dataset'], consistency=consistency,
-                     lr=lr, total_iters=total_iters, ram=given_images is None, num_classes=K)
+                     lr=lr, total_iters=total_iters, ram=given_images is None, num_classes=K,
+                     options=dict(side_cus=0, rec_cus=0) if graph else None)
     ts.wpack.refresh()
     T = lambda a: torch.from_numpy(a).to(dev)
     if given_images is None:

@@ -101,3 +101,26 @@ def test_gradient_buckets_average_over_two_gloo_ranks(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and 'ok' in o, o
+
+
+def test_dataloader_worker_cap_divides_the_host_between_ranks_and_domains():
+    """train.py: 8 workers per domain loader on one GPU (the reference's num_workers, train.py:558); under torchrun the
+    host's cores are shared by ranks x domain loaders."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('rd_train', os.path.join(ROOT, 'ram-dsir_amd', 'train.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.worker_cap(8, 1, 3, cpus=64) == 8
+    assert m.worker_cap(8, 8, 3, cpus=128) == 5             # 8 ranks x 3 loaders x 5 = 120 <= 128 (uncapped: 192)
+    assert m.worker_cap(8, 8, 3, cpus=16) == 1
+    assert m.worker_cap(0, 8, 3, cpus=128) == 0             # in-process loading stays in-process
+    assert m.worker_cap(2, 2, 3, cpus=256) == 2
+
+
+def test_tuning_options_and_cu_budget_defaults():
+    from ramdsir import tuning as T
+    o = T.options(dict(side_cus=0, rec_cus=None))
+    assert o['side_cus'] == 0 and o['rec_cus'] == -1 and o['ddp_own_comm_stream'] is False
+    assert T.cu_budget(96, None) == 96 and T.cu_budget(0, None) == 0
+    with pytest.raises(KeyError):
+        T.options(dict(no_such_option=1))

@@ -38,7 +38,7 @@ def rel_l2(got, ref):
     return float((got.double() - ref.double()).norm() / (ref.double().norm() + 1e-30))
 
 
-def _setup(golden_dir, name, dtype):
+def _setup(golden_dir, name, dtype, options=None):
     G, meta = load_step(golden_dir, name)
     enc, dec, rec = step_states(meta)
     nd = len(meta['batch_sizes'])
@@ -48,7 +48,7 @@ def _setup(golden_dir, name, dtype):
     ts = S.TrainStep(bank, mods, dtype, meta['batch_sizes'], meta['S'], meta['S'],
                      dataset='fundus' if name.startswith('fundus') else 'prostate', consistency=meta['consistency'],
                      lambda_rec=meta['lambda_rec'], lr=meta['base_lr'], total_iters=meta['total_iters'],
-                     num_classes=meta['num_classes'])
+                     num_classes=meta['num_classes'], options=options)
     ts.wpack.refresh()
     return G, meta, (enc, dec, rec), bank, mods, ts
 
@@ -200,7 +200,9 @@ def test_step_bf16_loss_band_and_graph_replay(golden_dir):
     got = np.array([ts.losses[i].item() for i in range(5)])
     np.testing.assert_allclose(got, G['s0.losses'][:5], rtol=5e-2)
     # graph path
-    G2, meta2, _, bank2, mods2, ts2 = _setup(golden_dir, 'fundus', torch.bfloat16)
+    with pytest.raises(ValueError, match='side_cus'):
+        ts.capture()                                    # lane budgets are baked in: one chain would run on half of the GPU
+    G2, meta2, _, bank2, mods2, ts2 = _setup(golden_dir, 'fundus', torch.bfloat16, options=dict(side_cus=0, rec_cus=0))
     _feed(ts2, G2, 0)
     ts2.capture()
     ts2.step()
@@ -228,7 +230,8 @@ def test_step_at_baseline_config_shapes(dataset, bs, S):
             v.copy_((torch.randn(shape, generator=g) * (2.0 / (shape[0] * shape[2] * shape[3])) ** 0.5).to(DEV))
         elif '.bn' in k and k.endswith('weight'):
             v.fill_(1.0)
-    ts = S_.TrainStep(bank, mods, torch.bfloat16, bs, S, S, dataset=dataset, consistency='kd', lr=1e-3, total_iters=100, ram=True)
+    ts = S_.TrainStep(bank, mods, torch.bfloat16, bs, S, S, dataset=dataset, consistency='kd', lr=1e-3, total_iters=100, ram=True,
+                      options=dict(side_cus=0, rec_cus=0))           # captured below: one chain, no lane budgets
     ts.wpack.refresh()
     if dataset == 'fundus':
         src = torch.rand(B, S, S, 3, device=DEV) * 255
@@ -281,9 +284,13 @@ def test_data_parallel_step_matches_plain_step_on_one_rank(golden_dir):
         ts.step()
         torch.cuda.synchronize()
         l_ref2 = [ts.losses[i].item() for i in range(5)]
-        for use_graph in (False, True):
-            G2, _, _, bank2, _, ts2 = _setup(golden_dir, 'fundus', torch.float32)
+        for use_graph, own_comm in ((False, False), (True, False), (False, True)):
+            G2, _, _, bank2, _, ts2 = _setup(golden_dir, 'fundus', torch.float32, options=dict(ddp_own_comm_stream=own_comm))
             runner = D.DataParallelStep(ts2)
+            # RCCL: the asynchronous AVG branch of GradBuckets.reduce (gloo, tests/test_gpu_ddp.py, takes the SUM + divide one);
+            # the collectives are launched from the weight-gradient lane unless a stream of their own is asked for
+            assert runner.buckets._avg == dist.ReduceOp.AVG and (runner.comm is ts2.side[0]) == (not own_comm)
+            assert runner.buckets.reduce(1, async_op=True) is not None
             b = runner.buckets.bounds
             assert b[0] == 0 and b[-1] == bank2.n and b == sorted(b) and len(b) == 4
             assert b[2] == bank2.module_range['enc'][1] and 0 < b[1] < b[2]            # encoder levels 1-2 | 3-5 | decoders
@@ -293,7 +300,7 @@ def test_data_parallel_step_matches_plain_step_on_one_rank(golden_dir):
             runner.step()
             torch.cuda.synchronize()
             np.testing.assert_allclose([ts2.losses[i].item() for i in range(5)], l_ref, rtol=1e-5)
-            assert rel_l2(bank2.grads.cpu(), g_ref) < 4e-2, use_graph
+            assert rel_l2(bank2.grads.cpu(), g_ref) < 4e-2, (use_graph, own_comm)
             assert float(bank2.grads.abs().max()) > 0
             _feed(ts2, G2, 1)
             runner.step()

@@ -59,6 +59,16 @@ def test_train_cli_smoke(tmp_path):
     assert int(ck['encoder_state_dict']['convd1.bn1.num_batches_tracked']) == 12          # 6 iterations x 2 passes
     assert all(torch.isfinite(v.float()).all() for v in ck['encoder_state_dict'].values())
     assert os.path.exists(os.path.join(out, '0_val_log.csv'))
+    # the reference's tensorboard scalars (train.py:298-304) as an event file in <save_path>/log, at the logged iterations
+    sys.path.insert(0, os.path.join(ROOT, 'ram-dsir_amd'))
+    from utils import tfevents
+    logs = os.listdir(os.path.join(out, 'log'))
+    assert len(logs) == 1 and logs[0].startswith('events.out.tfevents.')
+    ev = tfevents.read_events(os.path.join(out, 'log', logs[0]))
+    assert ev[0]['file_version'] == 'brain.Event:2'
+    tags = ['lr', 'loss/loss_bce_1', 'loss/loss_dice_1', 'loss/loss_bce_2', 'loss/loss_dice_2', 'loss/loss_consistency', 'loss/loss_rec']
+    assert [(e['step'], e['scalars'][0][0]) for e in ev[1:]] == [(it, t) for it in (0, 2, 4) for t in tags]
+    assert all(np.isfinite(e['scalars'][0][1]) for e in ev[1:])
     # offline evaluation script on that checkpoint (BN back in train mode, test_fundus_slice.py:75-83)
     ev = [sys.executable, os.path.join(ROOT, 'ram-dsir_amd', 'test_fundus_slice.py'), '--model_file', os.path.join(out, 'final_model.pth'),
           '--data_dir', data, '--datasetTest', '0', '--test_prediction_save_path', str(tmp_path / 'pred'), '--batch_size', '4']

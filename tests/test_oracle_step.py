@@ -35,7 +35,12 @@ def test_three_steps(golden_dir, name):
         # on weights of std ~0.03, so steps >= 1 agree only to ~1e-2 (measured 5e-3 on the 3-sample
         # DSBN slice) -- the reference itself is not reproducible beyond that across BLAS builds.
         np.testing.assert_allclose(got, ref, rtol=2e-5 if it == 0 else 1e-2)
-        np.testing.assert_allclose(comps['rec'].numpy(), G['s%d.rec_losses' % it], rtol=2e-5 if it == 0 else 1e-2)
+        # per-domain restoration losses: one to three images per DomainSpecificBatchNorm group, 2x2-pixel BatchNorm batches at
+        # the bottleneck -- the most host-sensitive scalars of the step after the first Adam update.  Measured against the
+        # fixtures (generated in the build container): <= 5e-3 there, 1.5e-2 on the GPU box's host CPU (another core
+        # count / ISA, so other fp32 reduction orders inside torch's CPU convs); this test also runs there
+        # (tests/test_gpu_oracle_pinned.py), step 0 staying at 2e-5 on both hosts
+        np.testing.assert_allclose(comps['rec'].numpy(), G['s%d.rec_losses' % it], rtol=2e-5 if it == 0 else 3e-2)
         if it == 0:
             for (gname, k), g in grads.items():
                 if bn_shadowed_bias(k):
