@@ -130,6 +130,21 @@ typedef struct {
 int64_t rd_wgrad_workspace(const rd_wgrad_t* p, int dtype);
 int rd_wgrad(const rd_wgrad_t* p, int dtype, void* stream);
 
+/* Backward of a small-channel 3x3 conv (<= 32 channels in and out, bf16, plain per-pixel sources and destinations: every
+ * 400x400 / 200x200 layer of the U-Net) in ONE launch: cudnn's dgrad AND wgrad behind the same nn.Conv2d
+ * (unet.py:37-43,81-88,124-131,281,307).  Both halves are HBM-bound and read the same tensors -- g, z and the producer's raw
+ * tensor; fused they are read once, and the weight-gradient MFMAs run on matrix pipes the dgrad leaves idle.
+ * `dgrad` is the rd_conv descriptor of the gradient launch (emode 1), `wgrad` the rd_wgrad descriptor of the same conv;
+ * rd_conv_bwd_fused_ok() says whether the pair qualifies (else use rd_conv + rd_wgrad).  rd_conv_bwd_fused writes the input
+ * gradient exactly as rd_conv would and one block of weight-gradient sums per workgroup into wgrad->partial
+ * (rd_conv_bwd_fused_workspace() bytes; wgrad->cu_limit is ignored, dgrad->cu_limit sizes the launch);
+ * rd_conv_bwd_fused_reduce then sums them into wgrad->dW in a fixed order (a separate call so that a caller can run it
+ * on another stream than the dgrad chain). */
+int rd_conv_bwd_fused_ok(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype);
+int64_t rd_conv_bwd_fused_workspace(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype);
+int rd_conv_bwd_fused(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype, void* stream);
+int rd_conv_bwd_fused_reduce(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype, void* stream);
+
 /* rd_pack_weights: OIHW fp32 master weights -> the packed operand rd_conv reads.
  * K-chunk-major, CK = 32 (bf16) / 16 (fp32) input channels = the 64 bytes one K step of rd_conv consumes:
  * transpose=0: forward  [CinPad/CK][tap][CoutPad][CK]  (tap = kh*3+kw)

@@ -125,5 +125,26 @@ int rd_wgrad(const rd_wgrad_t* p, int dtype, void* stream) {
     return rd_wgrad_dispatch(*p, dtype, (hipStream_t)stream);
 }
 
+// ---- backward of a small-channel 3x3 conv in one launch (conv_fused.hip)
+int rd_conv_bwd_fused_ok(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype) {
+    if (!dgrad || !wgrad || dgrad->G < 1 || dgrad->G > RD_MAX_GROUPS) return 0;
+    return rd_bwd_fused_ok(*dgrad, *wgrad, dtype) ? 1 : 0;
+}
+
+int64_t rd_conv_bwd_fused_workspace(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype) {
+    if (!rd_conv_bwd_fused_ok(dgrad, wgrad, dtype)) return 0;
+    return rd_bwd_fused_ws_bytes(*dgrad, *wgrad);
+}
+
+int rd_conv_bwd_fused(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype, void* stream) {
+    if (!rd_conv_bwd_fused_ok(dgrad, wgrad, dtype) || !wgrad->partial || !wgrad->dW) return -1;
+    return rd_bwd_fused_dispatch(*dgrad, *wgrad, (hipStream_t)stream);
+}
+
+int rd_conv_bwd_fused_reduce(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype, void* stream) {
+    if (!rd_conv_bwd_fused_ok(dgrad, wgrad, dtype) || !wgrad->partial || !wgrad->dW) return -1;
+    return rd_bwd_fused_reduce_dispatch(*dgrad, *wgrad, (hipStream_t)stream);
+}
+
 }  // extern "C"
 

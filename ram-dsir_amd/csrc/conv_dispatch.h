@@ -6,6 +6,14 @@ int rd_conv_small_dispatch(const rd_conv_t& p, int dtype, hipStream_t st);   // 
 int rd_conv_big_dispatch(const rd_conv_t& p, int dtype, hipStream_t st);     // everything else
 int rd_wgrad_dispatch(const rd_wgrad_t& p, int dtype, hipStream_t st);
 int64_t rd_wgrad_ws_bytes(const rd_wgrad_t& p, int dtype);
+// split reduction of per-workgroup weight-gradient sums partial[nsplit][taps][CoutPadW][CinPadW] -> dW (wgrad.hip)
+int rd_wgrad_reduce_launch(const float* partial, float* dW, int nsplit, int taps, int Cout, int Cin, int CoutPadW, int CinPadW, float beta,
+                           hipStream_t st);
+// fused dgrad + weight gradient of the small-channel 3x3 convs (conv_fused.hip)
+bool rd_bwd_fused_ok(const rd_conv_t& dgrad, const rd_wgrad_t& wgrad, int dtype);
+int64_t rd_bwd_fused_ws_bytes(const rd_conv_t& dgrad, const rd_wgrad_t& wgrad);
+int rd_bwd_fused_dispatch(const rd_conv_t& dgrad, const rd_wgrad_t& wgrad, hipStream_t st);
+int rd_bwd_fused_reduce_dispatch(const rd_conv_t& dgrad, const rd_wgrad_t& wgrad, hipStream_t st);
 // persistent software-pipelined 3x3 kernel for bf16 launches with CoutPad % 64 == 0 and plain sources (conv_pp.hip);
 // RD_CONV_PP_NA when the launch does not qualify (the caller falls back to conv_big's kernels)
 constexpr int RD_CONV_PP_NA = -1000;

@@ -1,0 +1,493 @@
+// conv_fused.hip -- backward of a small-channel 3x3 conv in ONE launch: the input gradient (dgrad, with the activation mask,
+// the skip accumulation and the BatchNorm-backward sums of conv_small_kernel's gradient epilogue) AND the weight gradient.
+//
+// Why: on the 400x400 / 200x200 layers (<= 32 channels in and out) both halves of the backward are HBM-bound and read the
+// same tensors -- dgrad: g, z (the BatchNorm backward folded into the read) and the producer's raw tensor z_prev (mask, BN sums);
+// wgrad: g, z and act(bn(z_prev)).  Separately that is six tensor reads per layer; fused it is three, and the weight-gradient
+// MFMAs run on matrix pipes that the HBM-bound dgrad leaves idle (scripts/ablate_step.py: the <= 32-channel weight gradients
+// cost the step 0.74 ms although they sit on a side stream -- they compete with the dgrad chain for the same bandwidth).
+//
+// Structure (bf16 only): one 512-thread workgroup per CU walks consecutive 8x32 tiles of one image.
+//   waves 4-7  LOADER: the halo tile of dz = P*g + Q*z + R (or a stored dz / dlogits) of tile t+1 goes raw into registers while
+//              tile t is being used, is transformed and written to one of THREE LDS tile buffers [pixel][32 ch] (16-byte slots
+//              XOR-swizzled by pixel, as conv_small_kernel's);
+//   waves 0-3  COMPUTE, per iteration t:
+//              1. request the epilogue operands of tile t (the forward input's raw tensor, the old gradient when accumulating),
+//              2. dgrad MFMAs of tile t (weights x pixels roles, v_mfma_f32_32x32x16_bf16; weights resident in LDS),
+//              3. weight-gradient MFMAs of tile t-1: dW[tap][co][ci] += sum over the tile's pixels q of a[q][ci] * dz[q - tap][co]
+//                 -- K = pixels, so both operands come through the transposing LDS read ds_read_b64_tr_b16 from the [pixel][channel]
+//                 tiles: dz from the halo tile the dgrad used (still intact: three buffers), a from the tile the epilogue of
+//                 iteration t-1 wrote; v_mfma_f32_16x16x32_bf16, one 16x16 block x 9 taps per wave (36 accumulator registers;
+//                 layers with fewer blocks than waves split the tile rows instead),
+//              4. register epilogue of tile t: mask, skip accumulation, BN-backward sums, 16-byte NHWC stores -- and
+//                 a = act(bn(z_prev)) (the forward input, needed for the mask anyway) written to the `a` tile for step 3 of t+1;
+//              one barrier per iteration for both roles.
+//   At the end every workgroup stores its dW block sums [9][CoutPad16][CinPad16] fp32; wgrad_reduce_kernel (wgrad.hip) sums the
+//   workgroups in a fixed order (deterministic), as for the stand-alone weight-gradient kernels.
+#include "conv_device.h"
+#include "conv_dispatch.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short fz_s4;
+typedef __attribute__((address_space(3))) fz_s4 fz_lds_s4;
+__device__ __forceinline__ uint2 fz_tr(const char* p) {
+    const fz_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fz_lds_s4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
+// Workgroup barrier of the tile loop.  __syncthreads() is a fence + barrier: hipcc drains vmcnt(0) in front of it, i.e. every wave
+// would wait at every tile for the prefetches it has just issued (the loader's next two tiles, the compute waves' epilogue
+// operands and stores) -- one exposed memory latency per tile, which is what bounds a one-workgroup-per-CU kernel.  Only the LDS
+// traffic has to be complete at this barrier; loads into registers are waited for by the compiler at their first use.
+__device__ __forceinline__ void fz_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct FusedWg {
+    rd_src_t a[2];       // the conv's forward input (== the dgrad destinations' producer tensors), as rd_wgrad_t describes it
+    float* partial;      // [workgroups][9][CoutPadW][CinPadW]
+    int CoutPadW, CinPadW;
+};
+
+constexpr int FZ_PH = TH + 2, FZ_PW = TW + 2, FZ_NPIX = FZ_PH * FZ_PW;      // 10 x 34 halo tile
+constexpr int FZ_IN_BYTES = FZ_NPIX * 64;                                    // one dz tile buffer
+constexpr int FZ_A_BYTES = TH * TW * 64;                                     // one `a` tile buffer
+constexpr int FZ_W_BYTES = 9 * 32 * 64;
+constexpr int FZ_LDS = 3 * FZ_IN_BYTES + 2 * FZ_A_BYTES + FZ_W_BYTES + (64 + 32 + 32) * 4;
+
+// xp: timing experiments of the debug build (RD_FZ_EXP bits; results are wrong when set): 1 no weight-gradient phase, 2 no dgrad MFMAs,
+// 4 no gradient stores, 8 loader issues no global loads, 16 no epilogue-operand loads, 32 no `a` tile writes
+__global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_conv_t p, const FusedWg w, int tiles_per_wg, int xp) {
+    typedef bf16_t T;
+    constexpr int S = 8, NT = 32, NV = 2;
+    constexpr int NIT = (FZ_NPIX * 4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_inb = smem;                                                      // 3 x [NPIX][4 slots x 16 B]
+    char* s_ab = smem + 3 * FZ_IN_BYTES;                                     // 2 x [256][4 x 16 B]
+    uint4* s_w = reinterpret_cast<uint4*>(s_ab + 2 * FZ_A_BYTES);            // [9][32][4]
+    float* s_red = reinterpret_cast<float*>(reinterpret_cast<char*>(s_w) + FZ_W_BYTES);   // [32][2]
+    float* s_dsc = s_red + 64;                                               // [32] forward-input BN scale (1 for raw tensors)
+    float* s_dsh = s_dsc + 32;                                               // [32] shift
+
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int H = p.H, W = p.W;
+    const int tiles_x = (W + TW - 1) / TW, ntiles = tiles_x * ((H + TH - 1) / TH);
+    const int t_begin = blockIdx.x * tiles_per_wg;
+    const int t_end = min(ntiles, t_begin + tiles_per_wg);
+    const int nt = t_end - t_begin;
+    const int n = blockIdx.z;
+    const GroupMap gm = make_gm(p.gstart, p.G);
+    const int g = group_of(gm, n);
+    const int slot = (blockIdx.x + 7 * blockIdx.z) % RD_STAT_SLOTS;
+
+    // ---- LDS prologue (all 512 threads): zero the tile buffers (channel slots beyond the live ones stay zero), the packed
+    //      dgrad weights, the per-channel coefficients of the forward input
+    {
+        uint4* z4 = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < (3 * FZ_IN_BYTES + 2 * FZ_A_BYTES) / 16; i += 512) z4[i] = make_uint4(0, 0, 0, 0);
+        const T* wbase = reinterpret_cast<const T*>(p.w);
+        for (int idx = threadIdx.x; idx < 9 * NT * 4; idx += 512) {
+            const int sw = idx & 3, rec = idx >> 2;
+            const int nn = rec % NT, tap = rec / NT;
+            s_w[rec * 4 + (sw ^ ((nn >> 2) & 3))] = ld16(wbase + ((size_t)(tap * p.CoutPad + nn) * p.CinPad + sw * S));
+        }
+        if (threadIdx.x < 64) s_red[threadIdx.x] = 0.f;
+        if (threadIdx.x < 32) {
+            const int c = threadIdx.x;
+            const int dj = c >= p.c_split ? 1 : 0;
+            const rd_src_t as = select_src(w.a, dj);
+            const int cdd = c - (dj ? p.c_split : 0);
+            const int ga = as.g_fixed >= 0 ? as.g_fixed : g;
+            const bool live = c < p.Cout && cdd < as.C;
+            const bool aff = live && as.mode != RD_SRC_RAW;
+            s_dsc[c] = aff ? as.scale[ga * as.C + cdd] : 1.f;
+            s_dsh[c] = aff ? as.shift[ga * as.C + cdd] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    if (role == 1) {
+        // =============================================================================== loader + weight-gradient waves
+        int nsl = 4;
+        {
+            const int nl = (p.Cin + S - 1) / S;
+            nsl = nl <= 1 ? 1 : (nl <= 2 ? 2 : 4);
+        }
+        const int nsh = nsl == 1 ? 0 : (nsl == 2 ? 1 : 2);
+        const int sslot = tid & (nsl - 1);
+        const int nit = (FZ_NPIX * nsl + 255) >> 8;
+        ItemGeom<NIT> ig;
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            const int pixi = (tid + b * 256) >> nsh;
+            const int pix = min(pixi, FZ_NPIX - 1);
+            ig.py[b] = (short)(pix / FZ_PW);
+            ig.px[b] = (short)(pix - (pix / FZ_PW) * FZ_PW);
+            ig.lds[b] = pixi < FZ_NPIX ? pix * 4 + (sslot ^ ((ig.px[b] >> 2) & 3)) : -1;       // slots swizzled by the halo COLUMN
+        }
+        SlotCtx<T> ctx;
+        slot_ctx<T>(ctx, p.src, 1, p.Cin, g, sslot * S);
+        const rd_src_t ssrc = select_src(p.src, 0);
+        const bool live_slot = ctx.si >= 0;
+
+        // ---- weight-gradient roles: 16x16 blocks (cob, cib); nb blocks over these 4 waves, a block's waves split the tile rows
+        const int nbi = w.CinPadW >> 4, nb = (w.CoutPadW >> 4) * nbi;          // nb in {1, 2, 4}
+        const int blk = wave % nb, kq = wave / nb, wpb = 4 / nb;
+        const int cob = blk / nbi, cib = blk % nbi;
+        typedef __attribute__((ext_vector_type(4))) float f32x4v;
+        f32x4v accw[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) accw[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        // fragment addressing of the transposing reads: 16-lane group kg = 8-pixel K block, lane i16 -> pixel kg*8 + (i16>>2),
+        // 4 channels (i16 & 3) of the wave's 16-channel block
+        const int i16 = lane & 15, kg = lane >> 4;
+        const int cpx = kg * 8 + (i16 >> 2);                                    // pixel column of this lane's first read
+        const int zs0 = cob * 2 + ((i16 & 3) >> 1), as0 = cib * 2 + ((i16 & 3) >> 1), sub = (i16 & 1) * 8;
+        // dz halo tile: slot swizzle ((c >> 2) & 3) of the halo column c (a function of the column only, so that these offsets are
+        // per-lane constants + a row term; 16 consecutive columns of a row still spread over all banks for the dgrad's ds_read_b128)
+        int zoff[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = cpx + 4 * j;
+            zoff[j] = c * 64 + ((zs0 ^ ((c >> 2) & 3)) << 4) + sub;
+        }
+        // `a` tile [8 rows][32 px] x 64 B, slot swizzle x(c) = ((c>>1)&3) ^ (((c>>3)&1)<<1) of the pixel column c (written by the epilogue)
+        int aoff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = cpx + 4 * j;
+            aoff[j] = c * 64 + ((as0 ^ (((c >> 1) & 3) ^ (((c >> 3) & 1) << 1))) << 4) + sub;
+        }
+
+        // two register sets: tiles t+2 and t+3 are in flight while tile t+1 is transformed
+        uint4 rawA[NIT][2], rawB[NIT][2];
+        auto origin = [&](int t, int& yh, int& xh) {
+            yh = (t / tiles_x) * TH - 1;
+            xh = (t % tiles_x) * TW - 1;
+        };
+        int yh, xh;
+        // set A carries the even tiles of this workgroup, set B the odd ones
+        if (live_slot && nt > 0) {
+            origin(t_begin, yh, xh);
+            pf_issue<T, NIT, 2>(rawA, ssrc, ctx, ig, n, H, W, yh, xh, nit);
+            if (nt > 1) {
+                int y1, x1;
+                origin(t_begin + 1, y1, x1);
+                pf_issue<T, NIT, 2>(rawB, ssrc, ctx, ig, n, H, W, y1, x1, nit);
+            }
+            pf_consume<T, NIT>(rawA, ssrc, ctx, ig, H, W, yh, xh, reinterpret_cast<uint4*>(s_inb), nit);
+            if (nt > 2) {
+                origin(t_begin + 2, yh, xh);
+                pf_issue<T, NIT, 2>(rawA, ssrc, ctx, ig, n, H, W, yh, xh, nit);
+            }
+        }
+        __syncthreads();                                   // tile 0 is in buffer 0
+        // iteration `it`: tile it+1 goes into buffer (it+1) % 3, tile it+3 is requested into the register set just emptied, and the
+        // weight gradient of tile it-1 is accumulated from the `a` tile the epilogue of iteration it-1 wrote and that tile's dz
+        // halo buffer (still intact: three buffers) -- K = the 32 pixels of a tile row per MFMA
+        auto step = [&](uint4 (&raw)[NIT][2], int it) {
+            if (live_slot && it + 1 < nt) {
+                origin(t_begin + it + 1, yh, xh);
+                pf_consume<T, NIT>(raw, ssrc, ctx, ig, H, W, yh, xh, reinterpret_cast<uint4*>(s_inb + ((it + 1) % 3) * FZ_IN_BYTES), nit);
+                if (it + 3 < nt && !(xp & 8)) {
+                    origin(t_begin + it + 3, yh, xh);
+                    pf_issue<T, NIT, 2>(raw, ssrc, ctx, ig, n, H, W, yh, xh, nit);
+                }
+            }
+            if (it >= 1 && !(xp & 1)) {
+                const char* s_a = s_ab + ((it - 1) & 1) * FZ_A_BYTES;
+                const char* s_z = s_inb + ((it - 1) % 3) * FZ_IN_BYTES;
+                for (int r = kq; r < TH; r += wpb) {
+                    const uint2 a0 = fz_tr(s_a + aoff[0] + r * (TW * 64)), a1 = fz_tr(s_a + aoff[1] + r * (TW * 64));
+                    const bf16x8 bfrag = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int rr = r + kh;                               // halo row; halo column = tile column + kw
+                        uint2 d[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) d[j] = fz_tr(s_z + zoff[j] + rr * (FZ_PW * 64));
+                        const uint4 f0 = make_uint4(d[0].x, d[0].y, d[1].x, d[1].y);
+                        const uint4 f1 = make_uint4(__builtin_amdgcn_alignbit(d[0].y, d[0].x, 16), __builtin_amdgcn_alignbit(d[1].x, d[0].y, 16),
+                                                    __builtin_amdgcn_alignbit(d[1].y, d[1].x, 16), __builtin_amdgcn_alignbit(d[2].x, d[1].y, 16));
+                        const uint4 f2 = make_uint4(d[0].y, d[1].x, d[1].y, d[2].x);
+                        accw[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f0), bfrag, accw[kh * 3 + 0], 0, 0, 0);
+                        accw[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f1), bfrag, accw[kh * 3 + 1], 0, 0, 0);
+                        accw[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f2), bfrag, accw[kh * 3 + 2], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        for (int it = 0; it <= nt; it += 2) {
+            step(rawB, it);
+            fz_barrier();
+            if (it + 1 <= nt) {
+                step(rawA, it + 1);
+                fz_barrier();
+            }
+        }
+        // ---- weight-gradient blocks: waves that split a block's rows (kq > 0) hand their sums to kq == 0 through LDS
+        float* s_acc = reinterpret_cast<float*>(smem);     // [(wpb-1)][nb][9*4][64]: the tile buffers are dead now
+        if (kq > 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_acc[(((kq - 1) * nb + blk) * 36 + t * 4 + r) * 64 + lane] = accw[t][r];
+        }
+        __syncthreads();
+        if (kq == 0) {
+            for (int k2 = 0; k2 < wpb - 1; ++k2)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accw[t][r] += s_acc[((k2 * nb + blk) * 36 + t * 4 + r) * 64 + lane];
+            // D of the 16x16 MFMA: column (N = ci) = lane & 15, row (M = co) = 4 * (lane >> 4) + r; accumulator index t is the
+            // tap of the HALO offset (kh', kw'): the forward tap is the flipped one, 8 - t
+            float* out = w.partial + (size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 9 * w.CoutPadW * w.CinPadW;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[((size_t)(8 - t) * w.CoutPadW + cob * 16 + 4 * kg + r) * w.CinPadW + cib * 16 + i16] = accw[t][r];
+        }
+    } else {
+        // =============================================================================== dgrad waves
+        int nks = p.Cin <= 16 ? 1 : 2;
+        // ---- epilogue constants (conv_small_kernel's register epilogue: lane owns pixel li of a tile row and channels
+        //      16v + 8h .. +7 after the permlane regroup)
+        int cbv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cbv[v] = 16 * v + 8 * h;
+        float sa[NV][S], sb[NV][S];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < S; ++e) sa[v][e] = sb[v][e] = 0.f;
+        // per (v): destination / forward-input tensor of the lane's channel vector
+        const T* ap[NV];
+        T* gp[NV];
+        int Cd[NV], cd[NV];
+        bool live[NV], accum[NV], masked[NV];
+        float slp[NV];                                       // activation slope of a = act(.) (1: none): one destination per vector
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int cb = cbv[v];
+            const int di = cb >= p.c_split ? 1 : 0;
+            const rd_dst_t d = select_dst(p, di);
+            const rd_src_t as = select_src(w.a, di);
+            cd[v] = cb - (di ? p.c_split : 0);
+            Cd[v] = d.Cd;
+            live[v] = cb < p.Cout && d.kind == RD_DST_PLAIN;
+            accum[v] = live[v] && d.accumulate;
+            masked[v] = live[v] && d.act && d.z;
+            slp[v] = (live[v] && as.mode == RD_SRC_AFFACT) ? as.slope : 1.f;
+            ap[v] = reinterpret_cast<const T*>(as.ptr) + (size_t)(n + as.n_off) * H * W * as.C + cd[v];
+            gp[v] = reinterpret_cast<T*>(d.g) + (size_t)(n + d.n_off) * H * W * d.Cd + cd[v];
+        }
+        // layers with <= 16 input channels of the forward conv: the second channel vector does not exist (wave-uniform)
+        const bool two = __builtin_amdgcn_readfirstlane((int)(p.Cout > 16));
+        __syncthreads();                                   // tile 0 is in buffer 0
+
+        uint4 araw[2][NV];
+        // epilogue operands (the forward input's raw tensor) of a tile: requested one iteration ahead, right after the previous
+        // tile's epilogue has consumed the registers (clamped addresses: branch-free loads; invalid pixels are masked later)
+        auto request = [&](int t) {
+            if (xp & 16) return;
+            const int xx0 = (t % tiles_x) * TW, yy0 = (t / tiles_x) * TH;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int y = min(yy0 + wave * 2 + mb, H - 1), x = min(xx0 + li, W - 1);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    if (v == 1 && !two) continue;
+                    araw[mb][v] = live[v] ? ld16(ap[v] + (unsigned)((y * W + x) * Cd[v])) : make_uint4(0, 0, 0, 0);
+                }
+            }
+        };
+        if (nt > 0) request(t_begin);
+        for (int it = 0; it <= nt; ++it) {
+            const int t = t_begin + it;
+            const int x0 = (t % tiles_x) * TW, y0 = (t / tiles_x) * TH;
+            if (it < nt) {
+                const uint4* s_in = reinterpret_cast<const uint4*>(s_inb + (it % 3) * FZ_IN_BYTES);
+                char* s_aw = s_ab + (it & 1) * FZ_A_BYTES;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    // dgrad MFMAs of one tile row (weights x pixels roles)
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        if (xp & 2) break;
+                        const int kh = tap / 3, kw = tap % 3;
+                        const int pix = (wave * 2 + mb + kh) * FZ_PW + li + kw;
+                        Mma<T>::chunk(s_w + (tap * NT + li) * 4, (li >> 2) & 3, s_in + pix * 4, ((li + kw) >> 2) & 3, h, acc, nks);
+                    }
+                    // register epilogue of the row
+                    const int y = y0 + wave * 2 + mb, x = x0 + li;
+                    const bool valid = y < H && x < W;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        if (v == 1 && !two) continue;
+                        const int cb = cbv[v];
+                        float vec[S], xr[S], go[S], av[S];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned ua = __float_as_uint(acc[8 * v + j]);
+                            const unsigned ub = __float_as_uint(acc[8 * v + 4 + j]);
+                            const auto rs = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+                            vec[j] = __uint_as_float(rs[0]);
+                            vec[4 + j] = __uint_as_float(rs[1]);
+                        }
+                        Slot<T>::unpack(araw[mb][v], xr);
+                        const bool on = valid && live[v];
+#pragma unroll
+                        for (int e = 0; e < S; ++e) {
+                            const float yv = xr[e] * s_dsc[cb + e] + s_dsh[cb + e];
+                            av[e] = act_fn(yv, slp[v]);
+                            const float m = masked[v] ? act_grad(yv, p.dst[0].slope) : 1.f;
+                            const float gn = on ? vec[e] * m : 0.f;
+                            sa[v][e] += gn;
+                            sb[v][e] += gn * xr[e];
+                            go[e] = gn;
+                        }
+                        if (accum[v]) {                      // the old gradient of a second consumer (rare among these layers: not prefetched)
+                            float gold[S];
+                            Slot<T>::unpack(on ? ld16(gp[v] + (unsigned)((y * W + x) * Cd[v])) : make_uint4(0, 0, 0, 0), gold);
+#pragma unroll
+                            for (int e = 0; e < S; ++e) go[e] += gold[e];
+                        }
+                        if (on && !(xp & 4))
+                            *reinterpret_cast<uint4*>(gp[v] + (unsigned)((y * W + x) * Cd[v])) = Slot<T>::pack(go);
+                        // the forward input of this pixel for the weight gradient (zero outside the image / beyond the channels)
+                        const int c = li, sl = 2 * v + h;
+                        const uint4 au = on ? Slot<T>::pack(av) : make_uint4(0, 0, 0, 0);
+                        if (!(xp & 32)) *reinterpret_cast<uint4*>(s_aw + ((wave * 2 + mb) * TW + c) * 64 +
+                                                  ((sl ^ (((c >> 1) & 3) ^ (((c >> 3) & 1) << 1))) << 4)) = au;
+                    }
+                }
+                if (it + 1 < nt) request(t + 1);
+            }
+            fz_barrier();
+        }
+
+        // ---- BN-backward sums of all tiles: xor-reduce over the 32 lanes of a half-wave, LDS atomics, one global set per workgroup
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                float a = sa[v][e], b = sb[v][e];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    b += __shfl_xor(b, o, 64);
+                }
+                if (li == 0 && cbv[v] + e < 32) {
+                    atomicAdd(&s_red[(cbv[v] + e) * 2 + 0], a);
+                    atomicAdd(&s_red[(cbv[v] + e) * 2 + 1], b);
+                }
+            }
+        __syncthreads();                                   // (the other role's cross-wave dW barrier)
+        if (tid < 32 && tid < p.Cout) {
+            const int dj = tid >= p.c_split ? 1 : 0;
+            const rd_dst_t dd = select_dst(p, dj);
+            if (dd.kind != RD_DST_NONE && dd.bstats) {
+                const int cdd = tid - (dj ? p.c_split : 0);
+                const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
+                const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
+                atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
+            }
+        }
+    }
+}
+
+inline bool aligned16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------- host side
+bool rd_bwd_fused_ok(const rd_conv_t& p, const rd_wgrad_t& w, int dtype) {
+    if (dtype != RD_BF16 || rd_switch("RD_FUSED_BWD", 1) == 0) return false;
+    if (p.taps != 9 || w.taps != 9 || p.emode != 1 || p.nsrc != 1) return false;
+    if (p.CinPad != 32 || p.CoutPad != 32 || p.Cin > 32 || p.Cout > 32) return false;
+    const rd_src_t& s = p.src[0];
+    if (!(s.mode == RD_SRC_RAW || s.mode == RD_SRC_BNBWD) || s.C % 8 || s.C < p.Cin || !aligned16(s.ptr)) return false;
+    if (s.mode == RD_SRC_BNBWD && !aligned16(s.ptr2)) return false;
+    // the same tensor as the weight gradient's dz operand, the same geometry
+    if (w.dz.ptr != s.ptr || w.dz.ptr2 != s.ptr2 || w.dz.mode != s.mode || w.dz.C != s.C) return false;
+    if (w.N != p.N || w.H != p.H || w.W != p.W || w.Cout != p.Cin || w.Cin != p.Cout || w.G != p.G) return false;
+    if (p.c_split % 8) return false;
+    const int nd = p.c_split < p.Cout ? 2 : 1;
+    if (w.na != nd) return false;
+    float slope0 = p.dst[0].slope;
+    for (int i = 0; i < nd; ++i) {
+        const rd_dst_t& d = p.dst[i];
+        const rd_src_t& a = w.a[i];
+        const int width = i == 0 ? (nd == 2 ? p.c_split : p.Cout) : p.Cout - p.c_split;
+        if (d.kind != RD_DST_PLAIN || d.Cd % 8 || d.Cd != width || !aligned16(d.g)) return false;
+        if (!(a.mode == RD_SRC_RAW || a.mode == RD_SRC_AFF || a.mode == RD_SRC_AFFACT) || a.C != d.Cd || !aligned16(a.ptr)) return false;
+        if (a.n_off != d.n_off || a.g_fixed != d.g_fixed) return false;
+        if (d.z && d.z != a.ptr) return false;             // the mask is taken from the tensor the forward conv read
+        if (d.z && (a.scale != d.scale || a.shift != d.shift)) return false;
+        if (d.act && d.z && a.mode != RD_SRC_AFFACT) return false;
+        if (d.act && d.z && (d.slope != slope0 || a.slope != d.slope)) return false;
+        if (!d.z && a.mode != RD_SRC_RAW) return false;
+    }
+    if ((size_t)p.N * p.H * p.W * 32 >= (1ull << 31)) return false;     // 32-bit element offsets inside the kernel
+    return true;
+}
+
+static int fused_tiles_per_wg(const rd_conv_t& p, int& gx) {
+    const int ntiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
+    const bool limited = p.cu_limit > 0 && p.cu_limit < rd_num_cus();
+    const long slots = limited ? p.cu_limit : rd_num_cus();               // one 512-thread workgroup per CU
+    int tpw = 0;
+    double best = 1e30;
+    const int tmin = limited ? (int)(((long)ntiles * p.N + slots - 1) / slots) : 1;
+    for (int t = tmin < 1 ? 1 : tmin; (t <= 64 || limited) && t <= ntiles; ++t) {
+        const long wgs = (long)((ntiles + t - 1) / t) * p.N;
+        // whole rounds of resident workgroups; a workgroup pays about one tile-time of pipeline fill + drain
+        const double cost = (double)((wgs + slots - 1) / slots) * (t + 1.0);
+        if (cost < best - 1e-9) { best = cost; tpw = t; }
+        if (limited) break;
+    }
+    if (tpw <= 0) tpw = ntiles;
+    gx = (ntiles + tpw - 1) / tpw;
+    return tpw;
+}
+
+int64_t rd_bwd_fused_ws_bytes(const rd_conv_t& p, const rd_wgrad_t& w) {
+    int gx;
+    fused_tiles_per_wg(p, gx);
+    const int cop = (w.Cout + 15) / 16 * 16, cip = (w.Cin + 15) / 16 * 16;
+    return (int64_t)gx * p.N * 9 * cop * cip * (int64_t)sizeof(float);
+}
+
+int rd_bwd_fused_dispatch(const rd_conv_t& p, const rd_wgrad_t& w, hipStream_t st) {
+    int gx;
+    const int tpw = fused_tiles_per_wg(p, gx);
+    FusedWg fw;
+    fw.a[0] = w.a[0];
+    fw.a[1] = w.a[1];
+    fw.partial = w.partial;
+    fw.CoutPadW = (w.Cout + 15) / 16 * 16;
+    fw.CinPadW = (w.Cin + 15) / 16 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS);
+        attr_set = true;
+    }
+    dim3 grid(gx, 1, p.N);
+    hipLaunchKernelGGL(conv_small_bwd_fused_kernel, grid, dim3(512), FZ_LDS, st, p, fw, tpw, rd_switch("RD_FZ_EXP", 0));
+    return (int)hipGetLastError();
+}
+
+// the workgroups' dW block sums -> dW (fixed order: deterministic); its own entry point so that the host can put it on the
+// weight-gradient lane, off the dgrad chain
+int rd_bwd_fused_reduce_dispatch(const rd_conv_t& p, const rd_wgrad_t& w, hipStream_t st) {
+    int gx;
+    fused_tiles_per_wg(p, gx);
+    return rd_wgrad_reduce_launch(w.partial, w.dW, gx * p.N, 9, w.Cout, w.Cin, (w.Cout + 15) / 16 * 16, (w.Cin + 15) / 16 * 16, w.beta, st);
+}

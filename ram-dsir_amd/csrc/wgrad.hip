@@ -892,21 +892,25 @@ int dispatch_wgrad(const rd_wgrad_t& p, hipStream_t st) {
 #undef RD_WG
     }
     if (e) return e;
-    const int total = p.taps * p.Cout * p.Cin;
-    // many splits of a small filter (the 16/32-channel layers): 8 outputs x 32 split lanes per block
-    if (g.nsplit >= 128 && total <= 16384) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((total + 7) / 8), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
-                           g.CoutPadW, g.CinPadW, p.beta);
-    } else {
-        int blocks = (total + 31) / 32;
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, st, p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin,
-                           g.CoutPadW, g.CinPadW, p.beta);
-    }
-    return (int)hipGetLastError();
+    if (rd_switch("RD_WG_NO_REDUCE", 0)) return 0;          // debug build only: timing experiment (what the split reductions cost the step)
+    return rd_wgrad_reduce_launch(p.partial, p.dW, g.nsplit, p.taps, p.Cout, p.Cin, g.CoutPadW, g.CinPadW, p.beta, st);
 }
 
 }  // namespace
+
+int rd_wgrad_reduce_launch(const float* partial, float* dW, int nsplit, int taps, int Cout, int Cin, int CoutPadW, int CinPadW, float beta,
+                           hipStream_t st) {
+    const int total = taps * Cout * Cin;
+    // many splits of a small filter (the 16/32-channel layers): 8 outputs x 32 split lanes per block
+    if (nsplit >= 128 && total <= 16384) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((total + 7) / 8), dim3(256), 0, st, partial, dW, nsplit, taps, Cout, Cin, CoutPadW, CinPadW, beta);
+    } else {
+        int blocks = (total + 31) / 32;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, st, partial, dW, nsplit, taps, Cout, Cin, CoutPadW, CinPadW, beta);
+    }
+    return (int)hipGetLastError();
+}
 
 int rd_wgrad_dispatch(const rd_wgrad_t& p, int dtype, hipStream_t st) {
     return dtype == RD_BF16 ? dispatch_wgrad<bf16_t>(p, st) : dispatch_wgrad<float>(p, st);

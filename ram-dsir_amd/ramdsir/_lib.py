@@ -86,6 +86,10 @@ _SIGS = {
     'rd_conv': (C.c_int, [C.POINTER(RdConv), C.c_int, vp]),
     'rd_wgrad_workspace': (i64, [C.POINTER(RdWgrad), C.c_int]),
     'rd_wgrad': (C.c_int, [C.POINTER(RdWgrad), C.c_int, vp]),
+    'rd_conv_bwd_fused_ok': (C.c_int, [C.POINTER(RdConv), C.POINTER(RdWgrad), C.c_int]),
+    'rd_conv_bwd_fused_workspace': (i64, [C.POINTER(RdConv), C.POINTER(RdWgrad), C.c_int]),
+    'rd_conv_bwd_fused': (C.c_int, [C.POINTER(RdConv), C.POINTER(RdWgrad), C.c_int, vp]),
+    'rd_conv_bwd_fused_reduce': (C.c_int, [C.POINTER(RdConv), C.POINTER(RdWgrad), C.c_int, vp]),
     'rd_pack_weights': (C.c_int, [fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rd_packed_elems': (i64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'rd_bn_finalize_fwd': (C.c_int, [C.POINTER(RdBnFwd), vp]),

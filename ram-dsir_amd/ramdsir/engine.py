@@ -273,6 +273,7 @@ class Plan:
         self.conv_cus = 0               # >0: compute-unit budget of this plan's persistent conv launches (a side-lane plan)
         self.materialize_min_c = None   # channels from which BN+ReLU outputs are stored once (rd_bn_apply)
         self.materialize_dz_min_c = None  # ... and from which the BN-backward gradients dz are
+        self.fused_bwd = bool(T.options()['fused_bwd'])   # small-channel 3x3 convs: dgrad + weight gradient in one launch
         self._unit = {}
         self.nodes = []
         self.keep = []
@@ -488,7 +489,7 @@ class Plan:
                     o.dt_buf = self.alloc_act((N, H, W, o.C))
                     self.bwd.append((lib.rd_up_bwd, (o.grad_buf().data_ptr(), o.buf.data_ptr(), o.dt_buf.data_ptr(), o.P.data_ptr(),
                                                      o.Q.data_ptr(), o.R.data_ptr(), N, H, W, o.C, self.G, self.gs_arr, dt)))
-            # wgrad
+            # wgrad descriptor (launched below: fused with the dgrad where the pair qualifies)
             wg = L.RdWgrad()
             for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
                 wg.a[i] = self._src(a, mode, n_off, g_fixed)
@@ -499,7 +500,6 @@ class Plan:
             wg.dW = self.bank.g(node.mname, node.name + '.weight').data_ptr()
             wg.beta = 0.0
             wg.cu_limit = int(self.side_cus)
-            ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
             self.keep.append(wg)
             node.wg = wg
             # algorithmic work of the weight gradient (SURVEY.md 8d convention): the conv's logical input read once + the
@@ -507,15 +507,8 @@ class Plan:
             esz = 2 if self.dtype == torch.bfloat16 else 4
             dz_ops = 2 if wg.dz.mode == L.SRC_BNBWD else 1
             dz_c = o.gCs if o.norm is None else o.C
-            node.side_meta = [dict(kernel='wgrad', side=True, side_idx=0, layer='%s.%s' % (node.mname, node.name),
-                                   bytes=N * H * W * (node.Cin + dz_ops * dz_c) * esz, flops=2 * N * H * W * node.Cin * node.Cout * node.taps)]
-            self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt), node.side_meta[0]))
-            if node.has_bias_grad:
-                node.bias_ws = self.alloc_f32(8192)
-                node.side_meta.append(dict(kernel='colsum', side=True, side_idx=0))
-                self.bwd.append((lib.rd_colsum, (o.grad_buf().data_ptr(), self.bank.g(node.mname, node.name + '.bias').data_ptr(),
-                                                 node.bias_ws.data_ptr(), N * H * W, o.C, o.gCs, 0.0, dt), node.side_meta[1]))
-            # dgrad (skipped when no input needs a gradient, i.e. the first conv on the image)
+            wg_bytes, wg_flops = N * H * W * (node.Cin + dz_ops * dz_c) * esz, 2 * N * H * W * node.Cin * node.Cout * node.taps
+            # dgrad descriptor (none when no input needs a gradient, i.e. the first conv on the image)
             dsts = []
             for (a, mode, n_off, g_fixed) in node.inputs:
                 d = L.RdDst()
@@ -540,27 +533,49 @@ class Plan:
                         one, zero = self.unit_coef(a.C)
                         d.z, d.scale, d.shift, d.slope, d.g_fixed = a.buf.data_ptr(), one.data_ptr(), zero.data_ptr(), 1.0, 0
                 dsts.append(d)
-            if all(d.kind == L.DST_NONE for d in dsts):
-                continue
-            p = L.RdConv()
-            p.cu_limit = int(self.conv_cus)
-            p.src[0] = self._dz_src(node)
-            p.nsrc, p.taps = 1, node.taps
-            p.w = wpack.ptr(node.mname, node.name, True)
-            p.bias = None
-            p.CinPad, p.CoutPad = wpack.pads(node.Cin, node.Cout)       # roles swapped: K = Cout, N = Cin
-            p.N, p.H, p.W, p.Cin, p.Cout = N, H, W, node.Cout, node.Cin
-            p.G, p.gstart = self.G, self.gs_arr
-            p.emode = 1
-            p.dst[0] = dsts[0]
-            if len(dsts) == 2:
-                p.dst[1] = dsts[1]
-                p.c_split = node.inputs[0][0].C
+            p = None
+            if not all(d.kind == L.DST_NONE for d in dsts):
+                p = L.RdConv()
+                p.cu_limit = int(self.conv_cus)
+                p.src[0] = self._dz_src(node)
+                p.nsrc, p.taps = 1, node.taps
+                p.w = wpack.ptr(node.mname, node.name, True)
+                p.bias = None
+                p.CinPad, p.CoutPad = wpack.pads(node.Cin, node.Cout)       # roles swapped: K = Cout, N = Cin
+                p.N, p.H, p.W, p.Cin, p.Cout = N, H, W, node.Cout, node.Cin
+                p.G, p.gstart = self.G, self.gs_arr
+                p.emode = 1
+                p.dst[0] = dsts[0]
+                if len(dsts) == 2:
+                    p.dst[1] = dsts[1]
+                    p.c_split = node.inputs[0][0].C
+                else:
+                    p.dst[1].kind = L.DST_NONE
+                    p.c_split = node.Cin
+                self.keep.append(p)
+            dmeta = self._conv_meta(node, N, H, W, node.Cout, node.Cin, 'dgrad') if p is not None else None
+            node.fused = bool(p is not None and self.fused_bwd and lib.rd_conv_bwd_fused_ok(C.byref(p), C.byref(wg), dt))
+            if node.fused:
+                # small-channel 3x3 conv: dgrad + weight gradient in ONE launch on the dgrad chain (csrc/conv_fused.hip: both are
+                # HBM-bound and read the same tensors); its per-workgroup dW sums are reduced on the weight-gradient lane, from a
+                # buffer of this layer's own (the next fused launch of the chain must not overwrite sums still to be reduced)
+                node.fused_ws = self.alloc_f32(max(lib.rd_conv_bwd_fused_workspace(C.byref(p), C.byref(wg), dt) // 4, 1))
+                wg.partial = node.fused_ws.data_ptr()
+                fmeta = dict(dmeta, kernel='conv_small_bwd_fused', what='dgrad+wgrad', bytes=dmeta['bytes'] + wg_bytes, flops=dmeta['flops'] + wg_flops)
+                self.bwd.append((lib.rd_conv_bwd_fused, (C.byref(p), C.byref(wg), dt), fmeta))
+                node.side_meta = [dict(kernel='wgrad_reduce', side=True, side_idx=0, layer='%s.%s' % (node.mname, node.name))]
+                self.bwd.append((lib.rd_conv_bwd_fused_reduce, (C.byref(p), C.byref(wg), dt), node.side_meta[0]))
             else:
-                p.dst[1].kind = L.DST_NONE
-                p.c_split = node.Cin
-            self.keep.append(p)
-            self.bwd.append((lib.rd_conv, (C.byref(p), dt), self._conv_meta(node, N, H, W, node.Cout, node.Cin, 'dgrad')))
+                ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
+                node.side_meta = [dict(kernel='wgrad', side=True, side_idx=0, layer='%s.%s' % (node.mname, node.name), bytes=wg_bytes, flops=wg_flops)]
+                self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt), node.side_meta[0]))
+            if node.has_bias_grad:
+                node.bias_ws = self.alloc_f32(8192)
+                node.side_meta.append(dict(kernel='colsum', side=True, side_idx=0))
+                self.bwd.append((lib.rd_colsum, (o.grad_buf().data_ptr(), self.bank.g(node.mname, node.name + '.bias').data_ptr(),
+                                                 node.bias_ws.data_ptr(), N * H * W, o.C, o.gCs, 0.0, dt), node.side_meta[-1]))
+            if p is not None and not node.fused:
+                self.bwd.append((lib.rd_conv, (C.byref(p), dt), dmeta))
         self.ws_bytes = ws_need
 
     def _conv_meta(self, node, N, H, W, Cin, Cout, what):
@@ -590,7 +605,8 @@ class Plan:
         k = 0
         for node in reversed(self.nodes):                 # backward order = launch order
             if hasattr(node, 'wg'):
-                node.wg.partial = wss[k % len(wss)].data_ptr()
+                if not getattr(node, 'fused', False):            # fused layers keep their own per-layer buffer
+                    node.wg.partial = wss[k % len(wss)].data_ptr()
                 for m in node.side_meta:
                     m['side_idx'] = k % len(wss)
                 k += 1

@@ -38,6 +38,7 @@ class TrainStep:
         self.seg = E.Plan(bank, dtype, 2 * B, [0, B, 2 * B], slope=slope)
         self.seg.pad_narrow = self.seg.materialize_up = True
         self.seg.materialize_pool = bool(opt['pool_mat'])
+        self.seg.fused_bwd = bool(opt['fused_bwd'])
         # lane budgets are tuned for the bf16 kernels (in fp32 the weight gradients are several times heavier and the side lane
         # itself becomes the critical path when it is narrowed: 315 -> 268 images/s)
         budget = bool(opt['fork']) and dtype == torch.bfloat16
@@ -54,6 +55,7 @@ class TrainStep:
         self.rec = E.Plan(bank, dtype, B, gs, slope=slope)
         self.rec.pad_narrow = self.rec.materialize_up = True
         self.rec.materialize_pool = self.seg.materialize_pool
+        self.rec.fused_bwd = self.seg.fused_bwd
         lane = bool(budget and opt['rec_lane'])
         self.rec.side_cus = T.cu_budget(opt['rec_cus'], dev) if lane else 0    # its weight gradients run inline on its own lane
         self.rec.conv_cus = T.cu_budget(opt['rec_cus'], dev) if lane else 0

@@ -61,13 +61,13 @@ def main(args):
     with torch.no_grad():
         val_dice, total_hd, total_asd = evaluate_domain(lambda v: seg_decoder(encoder(v.cuda())), data_dir, domain_name,
                                                         args.batch_size, with_surface=True)
-    print('''\\n==>val_dice : %.2f''' % (100 * val_dice))
-    print('''\\n==>average_hd : %.2f''' % total_hd)
-    print('''\\n==>average_asd : %.2f''' % total_asd)
+    print('''\n==>val_dice : %.2f''' % (100 * val_dice))
+    print('''\n==>average_hd : %.2f''' % total_hd)
+    print('''\n==>average_asd : %.2f''' % total_asd)
     with open(osp.join(output_path, '../test' + str(args.datasetTest) + '_log.csv'), 'a') as f:
         log = [['batch-size: '] + [args.batch_size] + [args.model_file] + ['dice coefficence: '] + [val_dice] +
                ['average_hd: '] + [total_hd] + ['average_asd: '] + [total_asd]]
-        f.write(','.join(map(str, log)) + '\\n')
+        f.write(','.join(map(str, log)) + '\n')
     return val_dice, total_hd, total_asd
 
 

@@ -172,3 +172,66 @@ def test_evaluate_domain_reads_nifti_pairs(tmp_path):
     dice, hd, sd = P.evaluate_domain(_threshold_forward([]), str(tmp_path / 'prostate'), 'BIDMC', 2, with_surface=True)
     assert dice == pytest.approx(1.0) and hd == 0.0 and sd == 0.0
     assert P.DOMAIN_LIST[4] == 'BIDMC' and len(P.DOMAIN_LIST) == 6
+
+
+# ------------------------------------------------------------------------------------------------ NIfTI-1, byte level
+def _nifti1_header(endian, dims_xyz, datatype, bitpix, vox_offset, slope, inter, pixdim=(1.0, 0.5, 0.5, 3.0)):
+    """348 header bytes laid out field by field from the published nifti1.h (NOT through utils/nifti.write_volume):
+    sizeof_hdr int32 @0 | dim[8] int16 @40 | datatype int16 @70 | bitpix int16 @72 | pixdim[8] float32 @76 |
+    vox_offset float32 @108 | scl_slope float32 @112 | scl_inter float32 @116 | qform_code / sform_code int16 @252/254 |
+    magic char[4] @344."""
+    h = bytearray(348)
+    struct.pack_into(endian + 'i', h, 0, 348)
+    struct.pack_into(endian + '8h', h, 40, len(dims_xyz), *(list(dims_xyz) + [1] * (7 - len(dims_xyz))))
+    struct.pack_into(endian + 'h', h, 70, datatype)
+    struct.pack_into(endian + 'h', h, 72, bitpix)
+    struct.pack_into(endian + '8f', h, 76, *(list(pixdim) + [0.0] * (8 - len(pixdim))))
+    struct.pack_into(endian + 'f', h, 108, float(vox_offset))
+    struct.pack_into(endian + 'f', h, 112, slope)
+    struct.pack_into(endian + 'f', h, 116, inter)
+    struct.pack_into(endian + '2h', h, 252, 1, 1)
+    h[344:348] = b'n+1\x00'
+    return bytes(h)
+
+
+def test_nifti_reader_on_hand_built_files(tmp_path):
+    """Files assembled byte by byte, as a scanner export / another library would write them: a big-endian int16 volume with
+    scl_slope / scl_inter set and a header extension in front of the voxels (vox_offset 368), gzip-compressed; and a plain
+    little-endian uint8 label volume.  Expected arrays follow from the format alone: x runs fastest in the file, and
+    sitk.GetArrayFromImage hands numpy (z, y, x)."""
+    nx, ny, nz = 5, 4, 3
+    vox = np.arange(nx * ny * nz, dtype=np.int16) * 7 - 100              # file order: x fastest, then y, then z
+    hdr = _nifti1_header('>', (nx, ny, nz), 4, 16, 368, 2.0, -1.0)
+    ext = bytes([1, 0, 0, 0]) + struct.pack('>2i', 16, 4) + b'comment\x00'   # extender + one 16-byte extension (esize, ecode, 8 data bytes)
+    assert len(hdr) + len(ext) == 368
+    p = str(tmp_path / 'be.nii.gz')
+    with gzip.open(p, 'wb') as f:
+        f.write(hdr + ext + vox.astype('>i2').tobytes())
+    arr = N.read_volume(p)
+    assert arr.shape == (nz, ny, nx)
+    want = vox.astype(np.float64).reshape(nz, ny, nx) * 2.0 - 1.0       # ITK applies slope / intercept
+    np.testing.assert_array_equal(arr, want)
+    assert arr[1, 2, 3] == (3 + nx * (2 + ny * 1)) * 7 * 2.0 - 100 * 2.0 - 1.0
+    h = N.read_header(gzip.open(p, 'rb').read())
+    assert h['endian'] == '>' and h['shape'] == (nx, ny, nz) and h['vox_offset'] == 368 and tuple(h['pixdim']) == (0.5, 0.5, 3.0)
+
+    lab = (np.arange(nx * ny * nz) % 3).astype(np.uint8)
+    p2 = str(tmp_path / 'le.nii')
+    with open(p2, 'wb') as f:
+        f.write(_nifti1_header('<', (nx, ny, nz), 2, 8, 352, 0.0, 0.0) + bytes(4) + lab.tobytes())      # slope 0: "do not scale"
+    arr2 = N.read_volume(p2)
+    assert arr2.dtype == np.uint8 and arr2.shape == (nz, ny, nx)
+    np.testing.assert_array_equal(arr2, lab.reshape(nz, ny, nx))
+    # 4-D file with a trailing singleton time axis (common in exports): squeezed like SimpleITK's 3-D read of it
+    p3 = str(tmp_path / 'le4d.nii')
+    with open(p3, 'wb') as f:
+        f.write(_nifti1_header('<', (nx, ny, nz, 1), 16, 32, 352, 1.0, 0.0) + bytes(4) + np.arange(60, dtype='<f4').tobytes())
+    arr3 = N.read_volume(p3)
+    assert arr3.shape == (nz, ny, nx) and arr3.dtype == np.float32 and arr3[2, 3, 4] == 59.0
+    # and the repo's own writer produces a header this layout reads back (cross-check of write_volume against the field table)
+    p4 = str(tmp_path / 'w.nii')
+    N.write_volume(p4, lab.reshape(nz, ny, nx), pixdim=(0.5, 0.5, 3.0))
+    raw = open(p4, 'rb').read()
+    assert struct.unpack('<i', raw[0:4])[0] == 348 and struct.unpack('<8h', raw[40:56])[:4] == (3, nx, ny, nz)
+    assert struct.unpack('<2h', raw[70:74]) == (2, 8) and struct.unpack('<f', raw[108:112])[0] == 352.0 and raw[344:348] == b'n+1\x00'
+    assert raw[352:] == lab.tobytes()

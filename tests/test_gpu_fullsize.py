@@ -81,9 +81,12 @@ def test_fullsize_fp32_step_matches_oracle(name):
     assert FU.rel_l2(_flat(got['grads'], keys), _flat(ref['grads'], keys)) < 6e-3
 
 
-def test_fullsize_bf16_step_against_the_rounding_model_oracle():
-    cfg, (src, trg, lam, mask), states, (img, frq), ref32 = _case('C2')
-    _, _, _, _, refb = _case('C2', rounded=True)
+@pytest.mark.parametrize('name', ['C2', 'C3', 'C5'])
+def test_fullsize_bf16_step_against_the_rounding_model_oracle(name):
+    """bf16 -- the dtype of the bench line -- at every BASELINE.json shape: C2, C3 (softmax / CE / dice_loss_multi, five
+    single-pair DSBN groups at 384x384) and C5 (512x512, four domains)."""
+    cfg, (src, trg, lam, mask), states, (img, frq), ref32 = _case(name)
+    _, _, _, _, refb = _case(name, rounded=True)
     ts, bank, got = FU.hip_step(cfg, states, src, trg, lam, mask, torch.bfloat16)
     np.testing.assert_allclose(got['losses'], refb['losses'], rtol=2e-3)
     np.testing.assert_allclose(got['rec'], refb['rec'], rtol=2e-3)
