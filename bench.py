@@ -26,14 +26,21 @@ for p in (ROOT, os.path.join(ROOT, 'ram-dsir_amd')):
 import numpy as np
 import torch
 
-# Kernel families of the step with their share of the summed kernel time in profiles/r01_bench_kernel_stats.csv (rocprofv3
-# --stats of this command): weight gradients (wgrad_tr / wgrad_c16_tr / wgrad_t + their split reduce) 37 %, small-channel
-# convs 20 %, 3x3 convs on 64-wide output-channel tiles 16 %.  `roofline` is the weight-gradient family (one launch =
-# one rd_wgrad call = MFMA kernel + split reduction); `roofline_conv64` keeps the previous rounds' family for continuity.
-DOMINANT = 'wgrad'
-DOMINANT_SYMBOLS = ('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel')   # mangled-name fragments (profiles/)
-CONV64 = 'conv_kernel<bf16,9,2>'         # conv_ws_kernel + conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> (pooled sources) + conv_pp_kernel
-CONV64_SYMBOLS = ('conv_ws_kernel', 'conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel')
+# Kernel families of the step (one entry = one op kind of the launch list, ramdsir/engine.py meta['kernel'], with the kernel
+# symbols rocprofv3 reports for it).  `roofline` is the family with the largest share of the summed kernel time in the
+# committed profile of this command (profiles/r03_bench_kernel_stats.csv; scripts/pmc_traffic.py prints the shares), the
+# other families are reported beside it as roofline_<name>:
+#   bwd_fused  round 3: dgrad + weight gradient of the <= 32-channel 3x3 convs in one launch (csrc/conv_fused.hip), HBM-bound
+#   conv64     3x3 convs on 64-wide output-channel tiles (conv_ws_kernel + conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> + conv_pp_kernel), MFMA-bound
+#   wgrad      the remaining stand-alone weight gradients (>= 64-channel layers, 1x1 convs, the first conv): MFMA kernel + split reduce
+FAMILIES = {
+    'bwd_fused': dict(kernel='conv_small_bwd_fused', symbols=('conv_small_bwd_fused_kernel',), count=None),
+    'conv64': dict(kernel='conv_kernel<bf16,9,2>',
+                   symbols=('conv_ws_kernel', 'conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel'), count=None),
+    'wgrad': dict(kernel='wgrad', symbols=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel'),
+                  count=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel')),
+}
+DOMINANT = 'conv64'
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF (no sparsity)
 
@@ -76,11 +83,12 @@ def init_weights(bank):
             v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * bound).to(v.device))
 
 
-def kernel_roofline(ts, family, eager=True):
+def kernel_roofline(ts, fam, eager=True):
     """One more step, launched exactly like the timed ones (eager: weight-gradient kernels on the side stream and the
     restoration-decoder branch on its own stream, so the timed launches see the same contention), with HIP events
     recorded on the stream each launch goes to around every launch of the dominant kernel family; the algorithmic
     bytes / flops of each launch come from its descriptor (engine.Plan._conv_meta)."""
+    family = FAMILIES[fam]['kernel']
     main = torch.cuda.current_stream()
     ts.zero()
     evs, acc = [], dict(nbytes=0, flops=0)
@@ -117,18 +125,33 @@ def kernel_roofline(ts, family, eager=True):
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        tj = tj.get(family, tj) if isinstance(tj.get(family, None), dict) else tj
-        if tj.get('family', family) == family and 'traffic_bytes_per_launch' in tj:
+        collected = tj.get('collected', 'rocprofv3 PMC, offline')
+        tj = tj.get(fam, {})
+        if tj.get('family') == fam and 'traffic_bytes_per_launch' in tj:
             traffic = int(tj['traffic_bytes_per_launch'])
-            traffic_source = 'profiles/dominant_kernel_pmc.json (%s)' % tj.get('collected', 'rocprofv3 PMC, offline')
+            traffic_source = 'profiles/dominant_kernel_pmc.json (%s)' % collected
     if intensity >= ridge:
         out = dict(bound='mfma', achieved=round(tfs, 1), peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tfs / MFMA_PEAK_TFLOPS, 4))
     else:
         out = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
-    out.update(traffic=traffic, traffic_source=traffic_source, kernel=family, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
+    out.update(traffic=traffic, traffic_source=traffic_source, kernel=family, family=fam, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
                avg_algorithmic_bytes=int(nbytes / n), avg_flops=int(flops / n), flop_per_byte=round(intensity, 1),
                achieved_gbs=round(gbs, 1), achieved_tflops=round(tfs, 1))
     return out
+
+
+def mfma_busy(fam):
+    """MFMA utilisation of a kernel family from the committed SQ-counter summary (scripts/pmc_step.py + scripts/pmc_agg.py ->
+    profiles/r03_mfma_busy.json): SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles).  Like `traffic`: collected with rocprofv3
+    around this workload, not inside this run."""
+    path = os.path.join(ROOT, 'profiles', 'r03_mfma_busy.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        j = json.load(f)
+    if fam not in j:
+        return None
+    return dict(mfma_busy=j[fam]['mfma_busy'], mfma_busy_source='profiles/r03_mfma_busy.json (%s)' % j.get('collected', 'rocprofv3 SQ counters, offline'))
 
 
 def cpu_baseline(host_inputs, bs):
@@ -324,14 +347,17 @@ def main():
         }
         out['roofline_step'] = whole_step_roofline(B, Sz, out['ms_per_step'], args.dtype)
         if args.dtype == 'bf16':
-            out['roofline'] = kernel_roofline(ts, DOMINANT, eager=not args.graph)
-            out['roofline_conv64'] = kernel_roofline(ts, CONV64, eager=not args.graph)
-            if not args.graph:
-                # the same launches on ONE stream (nothing beside them): what the kernels do when they have the GPU to
-                # themselves, next to the headline figures above, which are measured under the step's three-stream contention
-                for key, fam in (('roofline', DOMINANT), ('roofline_conv64', CONV64)):
+            for fam in FAMILIES:
+                key = 'roofline' if fam == DOMINANT else 'roofline_' + fam
+                out[key] = kernel_roofline(ts, fam, eager=not args.graph)
+                if not args.graph:
+                    # the same launches on ONE stream (nothing beside them): what the kernels do when they have the GPU to
+                    # themselves, next to the headline figures above, which are measured under the step's three-stream contention
                     a = kernel_roofline(ts, fam, eager=False)
                     out[key]['alone'] = {k: a[k] for k in ('achieved', 'unit', 'frac', 'avg_launch_us')}
+            mb = mfma_busy('conv64')
+            if mb is not None:
+                out['roofline' if DOMINANT == 'conv64' else 'roofline_conv64'].update(mb)
         if world == 1 and args.dtype == 'bf16' and not args.no_fp32_leg:
             out['extra'] = {'fp32': fp32_leg(params0, bs, Sz, dev, src, trg, lam, mask)}
         if world == 1 and not args.no_cpu_baseline:

@@ -21,6 +21,10 @@ for _, key, m, n in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 40]:
     wc = m.get('SQ_WAVE_CYCLES', 0) or 1
     print('   ' + '  '.join('%s=%.3g' % (c.replace('SQ_', ''), v) for c, v in sorted(m.items())))
     if 'SQ_WAIT_ANY' in m:
-        print('   frac of wave cycles: wait_any %.2f  wait_inst_any %.2f  active_inst_any %.2f  wait_inst_lds %.2f ; mfma_busy/(4*busy_cycles) %.3f'
+        # MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs) / (1024 SIMDs x kernel cycles), kernel cycles =
+        # GRBM_GUI_ACTIVE / 8 (summed over the 8 XCDs).  (Round 2 printed mfma_busy / (4 * SQ_BUSY_CYCLES), which exceeds 1:
+        # SQ_BUSY_CYCLES is not a per-SIMD time base.)
+        kc = max(m.get('GRBM_GUI_ACTIVE', 0) / 8.0, 1.0)
+        print('   frac of wave cycles: wait_any %.2f  wait_inst_any %.2f  active_inst_any %.2f  wait_inst_lds %.2f ; mfma_busy (chip) %.3f'
               % (m['SQ_WAIT_ANY'] / wc, m['SQ_WAIT_INST_ANY'] / wc, m['SQ_ACTIVE_INST_ANY'] / wc, m.get('SQ_WAIT_INST_LDS', 0) / wc,
-                 m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(m.get('SQ_BUSY_CYCLES', 1), 1) / 4))
+                 m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (1024.0 * kc)))

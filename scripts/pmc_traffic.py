@@ -1,6 +1,6 @@
 """Turn gpurun_out/profiles_run/ (scripts/collect_profiles.sh) into the committed files under profiles/:
-<tag>_bench.json, <tag>_bench_kernel_stats.csv and dominant_kernel_pmc.json -- per kernel family of bench.py (the
-weight-gradient family = `roofline`, the 64-wide 3x3 conv family = `roofline_conv64`): rocprofv3's average launch
+<tag>_bench.json, <tag>_bench_kernel_stats.csv and dominant_kernel_pmc.json -- per kernel family of bench.py (bench.FAMILIES:
+the fused small-channel backward, the 64-wide 3x3 convs, the stand-alone weight gradients): rocprofv3's average launch
 duration and the HBM bytes per launch from the PMC passes, corrected as MI355X_MICROARCH.md prescribes:
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  One weight-gradient launch = one rd_wgrad call = its MFMA kernel + its
 split-reduction kernel: times and bytes of both are summed and divided by the number of MFMA-kernel launches."""
@@ -9,13 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 run = os.path.join(ROOT, 'gpurun_out', 'profiles_run')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-FAMILIES = {          # == bench.DOMINANT_SYMBOLS / bench.CONV64_SYMBOLS; 'count' = which symbols count as one launch
-    'wgrad': dict(frags=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel'),
-                  count=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel'),
-                  name='rd_wgrad: wgrad_ws_kernel / wgrad_tr_kernel / wgrad_c16_tr_kernel / wgrad_kernel + wgrad_reduce_kernel'),
-    'conv_kernel<bf16,9,2>': dict(frags=('conv_ws_kernel', 'conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel'), count=None,
-                                  name='conv_ws_kernel + conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> + conv_pp_kernel'),
-}
+import importlib.util
+_spec = importlib.util.spec_from_file_location('rd_bench', os.path.join(ROOT, 'bench.py'))
+_bench = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_bench)
+# the family table of bench.py ('count' = which symbols count as one launch: a weight-gradient launch = MFMA kernel + its reduce)
+FAMILIES = {fam: dict(frags=v['symbols'], count=v['count'], name=' + '.join(v['symbols'])) for fam, v in _bench.FAMILIES.items()}
 
 line = [l for l in open(os.path.join(run, 'bench.json')) if l.startswith('{')][-1]
 open(os.path.join(ROOT, 'profiles', tag + '_bench.json'), 'w').write(line)
@@ -48,6 +47,8 @@ for fam, spec in FAMILIES.items():
         'fetch_size_kb_per_launch': fk, 'write_size_kb_per_launch': wk, 'traffic_bytes_per_launch': (2 * fk + wk) * 1024,
         'rocprof_avg_launch_us': tot / calls / 1e3, 'rocprof_launches': calls, 'rocprof_share_percent': 100.0 * tot / total_ns,
     }
+out['collected'] = 'rocprofv3 PMC passes of scripts/collect_profiles.sh, tag %s' % tag
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'dominant_kernel_pmc.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
+print('shares of the summed kernel time:', {f: round(out[f]['rocprof_share_percent'], 1) for f in FAMILIES})
 print(line)

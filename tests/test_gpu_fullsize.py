@@ -133,7 +133,10 @@ def test_bf16_and_fp32_loss_trajectories_track_the_oracle():
         # already shows as several % (three bf16 runs of this test gave 1.9e-2, 3.4e-2 and 8.0e-2 at step 6)
         assert abs(hist[0] / ref[0] - 1) <= (1e-5 if dt == torch.float32 else 5e-3), (str(dt), hist[0], ref[0])
         logr = [abs(float(np.log(hist[it] / ref[it]))) for it in range(nsteps)]
-        assert max(logr) <= 0.25, (str(dt), logr)
-        assert float(np.mean(logr)) <= 0.07, (str(dt), float(np.mean(logr)))
+        # run-to-run spread of these two numbers, four runs each (scripts/traj_spread.py, profiles/r03_traj_spread.txt): bf16 mean
+        # 0.046-0.080 / max 0.13-0.22, fp32 mean 0.028-0.053 / max 0.07-0.13 -- with and without the fused backward alike (the
+        # summation order of the BatchNorm atomics differs from run to run and Adam's early sign-like updates amplify it)
+        assert max(logr) <= 0.30, (str(dt), logr)
+        assert float(np.mean(logr)) <= (0.11 if dt == torch.bfloat16 else 0.08), (str(dt), float(np.mean(logr)))
         assert hist[-1] < 0.05 * hist[0]
         del ts, bank

@@ -102,7 +102,10 @@ def test_step_fp32_matches_reference_fixture(golden_dir, name):
             n8 = int(min(8, ref[3]))
             if kind == 'param':
                 assert np.abs(v[:n8].numpy() - ref[4:4 + n8]).max() <= 2.1 * lr, key
-                np.testing.assert_allclose(float(v.norm()), np.sqrt(ref[2]), rtol=1e-2, err_msg=key)
+                # a 16..64-element BatchNorm vector moves by exactly lr per element: ONE element whose gradient is noise in the
+                # reference and an exact zero here (a channel dead behind its ReLU) changes the norm by 1 - sqrt(1 - 1/n) =
+                # 1.6 % at n = 32 (seen once in ~10 runs of the fundus_mse fixture, convu2.bn2.bias: 0.011162 vs 0.011314)
+                np.testing.assert_allclose(float(v.norm()), np.sqrt(ref[2]), rtol=1e-2 if v.numel() > 128 else 3.5e-2, err_msg=key)
             else:
                 np.testing.assert_allclose(v[:n8].numpy(), ref[4:4 + n8], rtol=1e-3, atol=1e-6, err_msg=key)
     assert int(ts.iter) == 1
