@@ -393,7 +393,9 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
 // at one wave per SIMD (SQ counters: 47% of the wave cycles issuing, 20% issue-stalled: profiles/r02_sq_counters.txt).
 // LDS tiles are 4 rows x 32 pixels (half of the single-role kernel's) so that two buffers fit: 2 x 48 KB.
 template <int NQZ>
-__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+// xp: timing experiments of the debug build (RD_WGWS_EXP bits; wrong results when set): 1 no MFMA phase, 2 loader issues no global loads,
+// 4 loader does not transform / write LDS
+__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles, int xp) {
     typedef bf16_t T;
     constexpr int S = 8, TAPS = 9;
     constexpr int THW = 4;
@@ -449,16 +451,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             igz.px[b] = (short)(pix % TW);
             igz.lds[b] = pix * PZ + slz * 16;
         }
-        uint4 raw_a[NITA][1], raw_z[NITZ][NQZ];
-        auto issue = [&](int tile) {
+        // TWO register sets: the tiles after the next are in flight while the next one is transformed.  (With one set the
+        // request went out right before the barrier and was consumed right behind it: as the loader is the slower role the
+        // barrier wait is ~0 and every tile paid a full memory latency -- timing builds, RD_WGWS_EXP: 153 us with, 108 us
+        // without the loads on dec.convu3.conv3.)
+        uint4 raw_aA[NITA][1], raw_zA[NITZ][NQZ], raw_aB[NITA][1], raw_zB[NITZ][NQZ];
+        auto issue = [&](uint4 (&ra)[NITA][1], uint4 (&rz)[NITZ][NQZ], int tile) {
             int n, y0, x0;
             coords(tile, n, y0, x0);
-            if (live_a) pfu_issue<T, NITA>(raw_a, psa, iga, n, H, W, y0 - 1, x0 - 1);
-            if (live_z) pfu_issue<T, NITZ>(raw_z, psz, igz, n, H, W, y0, x0);
+            if (live_a) pfu_issue<T, NITA>(ra, psa, iga, n, H, W, y0 - 1, x0 - 1);
+            if (live_z) pfu_issue<T, NITZ>(rz, psz, igz, n, H, W, y0, x0);
         };
-        int g_ctx = -1, it = 0;
-        if ((int)blockIdx.x < total_tiles) issue(blockIdx.x);
-        for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
+        const bool z_raw = p.dz.mode == RD_SRC_RAW;             // a stored dz / dlogits: copied, not transformed
+        int g_ctx = -1;
+        const int stride = gridDim.x;
+        auto fill = [&](uint4 (&ra)[NITA][1], uint4 (&rz)[NITZ][NQZ], int tile, int it) {
             int n, y0, x0;
             coords(tile, n, y0, x0);
             const int g = group_of(gm, n);
@@ -469,14 +476,34 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             }
             char* s_a = smem + (it & 1) * BUF;
             char* s_z = s_a + A_BYTES;
-            if (live_a)
-                pfu_consume<T, NITA, 1>(raw_a, psa, iga, H, W, y0 - 1, x0 - 1,
+            if (live_a && !(xp & 4))
+                pfu_consume<T, NITA, 1>(ra, psa, iga, H, W, y0 - 1, x0 - 1,
                                         [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
-            if (live_z)
-                pfu_consume<T, NITZ, NQZ>(raw_z, psz, igz, H, W, y0, x0,
-                                          [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_z + l) = u; });
-            if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
+            if (live_z && !(xp & 4)) {
+                if (z_raw && NQZ == 1) {
+#pragma unroll
+                    for (int b = 0; b < NITZ; ++b) {
+                        const int y = y0 + igz.py[b], x = x0 + igz.px[b];
+                        *reinterpret_cast<uint4*>(s_z + igz.lds[b]) = (y < H && x < W) ? rz[b][0] : make_uint4(0, 0, 0, 0);
+                    }
+                } else {
+                    pfu_consume<T, NITZ, NQZ>(rz, psz, igz, H, W, y0, x0,
+                                              [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_z + l) = u; });
+                }
+            }
+            if (tile + 2 * stride < total_tiles && !(xp & 2)) issue(ra, rz, tile + 2 * stride);
+        };
+        const int t0 = blockIdx.x;
+        if (t0 < total_tiles) issue(raw_aA, raw_zA, t0);
+        if (t0 + stride < total_tiles) issue(raw_aB, raw_zB, t0 + stride);
+        int it = 0;
+        for (int tile = t0; tile < total_tiles; tile += 2 * stride, it += 2) {
+            fill(raw_aA, raw_zA, tile, it);
             __syncthreads();               // tile `it` is in its buffer; the MFMA waves are done with the other one
+            if (tile + stride < total_tiles) {
+                fill(raw_aB, raw_zB, tile + stride, it + 1);
+                __syncthreads();
+            }
         }
         return;
     }
@@ -495,6 +522,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
     int it = 0;
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
         __syncthreads();
+        if (xp & 1) continue;
         const char* s_a = smem + (it & 1) * BUF;
         const char* s_z = s_a + A_BYTES;
 #pragma unroll
@@ -851,9 +879,9 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
             }
             const int tiles_ws = p.N * ((p.H + 3) / 4) * ((p.W + TW - 1) / TW);
             if (p.dz.mode == RD_SRC_BNBWD)
-                hipLaunchKernelGGL(wgrad_ws_kernel<2>, grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws);
+                hipLaunchKernelGGL(wgrad_ws_kernel<2>, grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws, rd_switch("RD_WGWS_EXP", 0));
             else
-                hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws);
+                hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws, rd_switch("RD_WGWS_EXP", 0));
             return (int)hipGetLastError();
         }
     }
