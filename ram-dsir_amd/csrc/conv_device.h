@@ -10,6 +10,32 @@ namespace {
 
 constexpr int TH = 8, TW = 32;
 
+// Output-tile shapes of the 256-pixel conv tiles.  A workgroup's four waves own 8 M-blocks of 32 pixels; shape 0 maps M-block
+// m, lane li to tile pixel (row m, column li) of an 8 x 32 rectangle.  On images whose side is not a multiple of 32 that leaves
+// 22-39 % of the MFMA lanes on pixels outside the image (100 -> 4 x 32 columns, 50 -> 2 x 32, 25 -> 32).  Shape 1 flattens the
+// 256 lanes over a 10 x 25 rectangle (pixel j = 32 m + li -> row j / 25, column j % 25; 250 of 256 lanes live): sides 25, 50, 100
+// and 200 are covered exactly in x and within 0-20 % in y, with a halo tile (12 x 27) that is no larger than shape 0's (10 x 34).
+template <int TS> struct TileGeo { static constexpr int H = 8, W = 32; };
+template <> struct TileGeo<1> { static constexpr int H = 10, W = 25; };
+
+template <int TS>
+__device__ __forceinline__ void tile_pixel(int mblock, int li, int& r, int& c, bool& live) {
+    if constexpr (TS == 0) {
+        r = mblock; c = li; live = true;
+    } else {
+        const int j = mblock * 32 + li;
+        r = j / TileGeo<TS>::W;
+        c = j - r * TileGeo<TS>::W;
+        live = j < TileGeo<TS>::H * TileGeo<TS>::W;
+    }
+}
+
+// share of a launch's MFMA lanes that land on image pixels under a tile shape (host side: picks the shape)
+inline double tile_efficiency(int H, int W, int th, int tw) {
+    const long tiles = (long)((H + th - 1) / th) * ((W + tw - 1) / tw);
+    return (double)H * W / (double)(tiles * 256);
+}
+
 // ------------------------------------------------------------------------------------ tile loader
 template <typename T>
 __device__ __forceinline__ void load_vec(const T* p, int cvalid, bool vec_ok, float* f) {

@@ -122,7 +122,7 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
 // are stored / combined with the destination tensors as whole 16-byte NHWC slots.  ~1/3 of the instructions of the
 // LDS-staged conv_epilogue above.  EP 1 = forward (+bias, BatchNorm sums), EP 2 = gradient into plain destinations.
 // s_epi: [NT] bias (EP 1) or [2][NT] producer scale / shift of the destination channels (EP 2), staged by the caller.
-template <typename T, int NB, int EP>
+template <typename T, int NB, int EP, int TS = 0>
 __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&acc)[2][NB], float* s_red, const float* s_epi,
                                                    int tid, int n, int g, int y0, int x0, int n0, int slot) {
     static_assert(sizeof(T) == 2 && (EP == 1 || EP == 2), "bf16, forward or plain-gradient");
@@ -140,8 +140,11 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
             for (int e = 0; e < S; ++e) sa[nb][v][e] = sb[nb][v][e] = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-        const int y = y0 + wave * 2 + mb, x = x0 + li;
-        const bool valid = y < H && x < W;
+        int pr, pc;
+        bool live;
+        tile_pixel<TS>(wave * 2 + mb, li, pr, pc, live);
+        const int y = y0 + pr, x = x0 + pc;
+        const bool valid = live && y < H && x < W;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll

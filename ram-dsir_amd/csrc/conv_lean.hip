@@ -8,24 +8,44 @@
 
 namespace {
 
-template <int TAPS, int NB>
+template <int TAPS, int NB, int TS>
 int launch_lean(const rd_conv_t& p, int ep, int nq, hipStream_t st) {
     typedef bf16_t T;
-    const size_t lds = conv_pf_lds<TAPS, NB>(p);
+    const size_t lds = conv_pf_lds<TAPS, NB, TS>(p);
     if (lds > (size_t)72 * 1024) return RD_CONV_PP_NA;
-    dim3 grid(((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), p.CoutPad / (NB * 32), p.N);
+    constexpr int THt = TileGeo<TS>::H, TWt = TileGeo<TS>::W;
+    dim3 grid(((p.W + TWt - 1) / TWt) * ((p.H + THt - 1) / THt), p.CoutPad / (NB * 32), p.N);
     static bool attr = false;
     if (!attr) {
         const int lds_max = 72 * 1024;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pf_kernel<T, TAPS, NB, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pf_kernel<T, TAPS, NB, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pf_kernel<T, TAPS, NB, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pf_kernel<T, TAPS, NB, 1, 1, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pf_kernel<T, TAPS, NB, 1, 2, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pf_kernel<T, TAPS, NB, 2, 2, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         attr = true;
     }
-    if (ep == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1, 1>), grid, dim3(256), lds, st, p);
-    else if (nq == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1, 2>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 2, 2>), grid, dim3(256), lds, st, p);
+    if (ep == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1, 1, TS>), grid, dim3(256), lds, st, p);
+    else if (nq == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1, 2, TS>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 2, 2, TS>), grid, dim3(256), lds, st, p);
     return (int)hipGetLastError();
+}
+
+// 10 x 25 tiles where they put clearly more of the MFMA lanes on image pixels (sides 25 / 50 / 100 / 200: 0.61-0.89 -> 0.81-0.98).
+// conv_pf_kernel launches run in rounds of the resident workgroups (two per CU), so ALONE fewer tiles only help when they remove
+// a round (scripts/layer_bench.py, RD_CONV_FLAT_TILES 0 / 1: dec.convu4.conv3 dgrad 104 -> 95 us, enc.convd3.* 52-56 -> 48-52,
+// dec.convu3.conv1 72 -> 68, others +-5 %: the sum over the family is unchanged) -- but in the STEP every workgroup not launched
+// is CU time the other two lanes get: 5.07-5.08 ms with 8 x 32 only, 5.06 with the whole-round rule (mode 2), 5.03 with mode 1
+// (scripts/sweep_opts.sh, alternating).  The persistent conv_ws_kernel keeps 8 x 32 tiles for now.
+template <int NB>
+inline bool flat_tiles(const rd_conv_t& p) {
+    const int mode = rd_switch("RD_CONV_FLAT_TILES", 1);       // 0 never, 1 whenever more lanes are live, 2 only when a round goes away
+    if (mode == 0) return false;
+    const double e1 = tile_efficiency(p.H, p.W, TileGeo<1>::H, TileGeo<1>::W), e0 = tile_efficiency(p.H, p.W, TH, TW);
+    if (e1 <= 1.04 * e0) return false;
+    if (mode == 1) return true;
+    const long nblk = p.CoutPad / (NB * 32), slots = 2L * rd_num_cus();
+    const long w0 = (long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * nblk;
+    const long w1 = (long)((p.W + TileGeo<1>::W - 1) / TileGeo<1>::W) * ((p.H + TileGeo<1>::H - 1) / TileGeo<1>::H) * p.N * nblk;
+    return (w1 + slots - 1) / slots < (w0 + slots - 1) / slots;
 }
 
 }  // namespace
@@ -35,6 +55,9 @@ int rd_conv_pf_lean_dispatch(const rd_conv_t& p, bool nb2, hipStream_t st) {
     if (!nq) return RD_CONV_PP_NA;
     const int ep = rd_conv_lean_mode(p, nb2 ? 64 : 32);
     if (!ep || (ep == 1 && nq != 1)) return RD_CONV_PP_NA;
-    if (p.taps == 9) return nb2 ? launch_lean<9, 2>(p, ep, nq, st) : launch_lean<9, 1>(p, ep, nq, st);
-    return nb2 ? launch_lean<1, 2>(p, ep, nq, st) : launch_lean<1, 1>(p, ep, nq, st);
+    if (p.taps == 9) {
+        if (nb2 ? flat_tiles<2>(p) : flat_tiles<1>(p)) return nb2 ? launch_lean<9, 2, 1>(p, ep, nq, st) : launch_lean<9, 1, 1>(p, ep, nq, st);
+        return nb2 ? launch_lean<9, 2, 0>(p, ep, nq, st) : launch_lean<9, 1, 0>(p, ep, nq, st);
+    }
+    return nb2 ? launch_lean<1, 2, 0>(p, ep, nq, st) : launch_lean<1, 1, 0>(p, ep, nq, st);
 }

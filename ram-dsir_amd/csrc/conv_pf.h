@@ -8,17 +8,23 @@ namespace {
 
 // MFMA phase of one input-channel chunk: s_in [halo pixel][4 slots], s_w [tap][n][4 slots], both XOR-swizzled
 // SWAP: A = weights, B = pixels (accumulator rows = output channels: the register epilogues)
-template <typename T, int TAPS, int NB, bool SWAP = false>
+template <typename T, int TAPS, int NB, bool SWAP = false, int TS = 0>
 __device__ __forceinline__ void conv_mma_chunk(const uint4* s_in, const uint4* s_w, int wave, int li, int h, f32x16 (&acc)[2][NB]) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    constexpr int PW = TW + 2 * HALO;
+    constexpr int PW = TileGeo<TS>::W + 2 * HALO;
     constexpr int NT = NB * 32;
+    int pr[2], pc[2];                                      // this lane's tile pixel of its two M-blocks
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        bool live;
+        tile_pixel<TS>(wave * 2 + mb, li, pr[mb], pc[mb], live);
+    }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
         const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-            const int pix = (wave * 2 + mb + kh) * PW + li + kw;
+            const int pix = (pr[mb] + kh) * PW + pc[mb] + kw;
             const uint4* a_rec = s_in + pix * 4;
             const int a_sw = (pix >> 2) & 3;
 #pragma unroll
@@ -54,11 +60,14 @@ int conv_pf_kind(const rd_conv_t& p) {
 // chunk c's MFMA phase instead of in front of chunk c+1's (the generic kernel is ~55% stalled on exactly that).
 // NQ = 2: the dgrad form, two operands per item (g and z of the BN backward; a raw dz aliases z to g, q = 0).
 // EP: 0 = LDS-staged epilogue (conv_epilogue), 1 / 2 = register epilogue forward / plain gradient (conv_epilogue_lean)
-template <typename T, int TAPS, int NB, int NQ, int EP = 0>
+// TS: output-tile shape (conv_device.h TileGeo; the LDS-staged epilogue EP 0 knows shape 0 only)
+template <typename T, int TAPS, int NB, int NQ, int EP = 0, int TS = 0>
 __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
+    static_assert(TS == 0 || EP != 0, "tile shapes other than 8x32 need a register epilogue");
     constexpr int S = Slot<T>::N;
     constexpr int CK = 4 * S;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int TH = TileGeo<TS>::H, TW = TileGeo<TS>::W;     // (shadow the 8 x 32 globals)
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
     constexpr int NT = NB * 32;
     constexpr int NIT = (PH * PW + 63) / 64;               // halo pixels per thread (fixed channel slot tid & 3)
@@ -201,18 +210,19 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
         }
         __syncthreads();
         if (c0 + CK < p.CinPad) issue(c0 + CK);
-        conv_mma_chunk<T, TAPS, NB, EP != 0>(s_in, s_w, wave, li, h, acc);
+        conv_mma_chunk<T, TAPS, NB, EP != 0, TS>(s_in, s_w, wave, li, h, acc);
     }
     __syncthreads();
     if constexpr (EP == 0) conv_epilogue<T, NB>(p, acc, smem, tid, n, g, y0, x0, n0, slot);
-    else conv_epilogue_lean<T, NB, EP>(p, acc, reinterpret_cast<float*>(smem), s_epi, tid, n, g, y0, x0, n0, slot);
+    else conv_epilogue_lean<T, NB, EP, TS>(p, acc, reinterpret_cast<float*>(smem), s_epi, tid, n, g, y0, x0, n0, slot);
 }
 
 
 // dynamic LDS of conv_pf_kernel: halo tile + weight chunk + BN coefficient rows + (register epilogues) bias / producer rows
-template <int TAPS, int NB>
+template <int TAPS, int NB, int TS = 0>
 inline size_t conv_pf_lds(const rd_conv_t& p) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int TH = TileGeo<TS>::H, TW = TileGeo<TS>::W;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
     size_t lds = (size_t)(PH * PW * 4 + TAPS * NB * 32 * 4) * sizeof(uint4) + (size_t)3 * p.CinPad * sizeof(float) + (size_t)2 * NB * 32 * sizeof(float);
     const size_t lds_epi = (size_t)(TH * TW * 32 + 64) * sizeof(float);

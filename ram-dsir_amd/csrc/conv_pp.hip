@@ -832,8 +832,11 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     //              64->64 @100x100 43 -> 38: every forward launch gains;
     //   gradient:  64->64 @200x200 153 -> 137, 128->128 @100x100 129 -> 122, but 128->128 @50x50 40 -> 52, 64->64 @100x100
     //              55 -> 62: with few tiles per CU the two-workgroup conv_pf_kernel streams the materialised dz better, so
-    //              gradient launches need >= RD_CONV_WS_MIN2 tiles (default 1536 = 6 per CU).
-    static const int ws = rd_switch("RD_CONV_WS", 3), ws_min2 = rd_switch("RD_CONV_WS_MIN2", 1536);
+    //              gradient launches need >= RD_CONV_WS_MIN2 tiles (round 2 default: 1536 = 6 per CU).
+    //   Round 3, in the STEP (scripts/sweep_opts.sh, alternating): threshold 1536 5.06-5.07 ms, 800: 5.19, 400: 5.22, never: 5.01-5.02 --
+    //   a gradient launch that takes whole CUs (512 threads, 154 KB LDS) keeps the weight-gradient lane's kernels off them for its
+    //   whole duration; the two-workgroup conv_pf_kernel shares.  Default: never for gradients (the kernel mode stays, tests force it).
+    static const int ws = rd_switch("RD_CONV_WS", 3), ws_min2 = rd_switch("RD_CONV_WS_MIN2", 1 << 30);
     const int mode = rd_conv_lean_mode(p, PP_NT);
     const size_t tab = (size_t)(mode == 1 ? 1 : 2 * p.G) * p.CoutPad * sizeof(float);
     if (mode && (ws & mode) && (mode == 1 || tiles >= ws_min2) && tab <= (size_t)PP_EPI_BYTES) {

@@ -65,6 +65,8 @@ FWD_CASES = [
     ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, [0, 1, 2], 0.0),
     ('out16_3', 9, [(L.SRC_AFFACT, 16)], 3, 3, 8, 32, [0, 1, 2, 3], 0.0),
     ('c256_256', 9, [(L.SRC_AFFACT, 256)], 256, 2, 6, 7, [0, 1, 2], 0.0),
+    ('c64_64_50x50', 9, [(L.SRC_AFFACT, 64)], 64, 2, 50, 50, [0, 1, 2], 0.0),          # 10 x 25 tiles: 5 x 2 per image, every lane but 6 live
+    ('c128_64_23x100', 9, [(L.SRC_AFFACT, 128)], 64, 2, 23, 100, [0, 2], 0.0),          # ... a ragged last tile row
     ('k1_128_64', 1, [(L.SRC_AFFACT, 128)], 64, 2, 10, 34, [0, 1, 2], 0.0),
     ('k1_16_16', 1, [(L.SRC_AFFACT, 16)], 16, 2, 20, 20, [0, 2], 0.0),
 ]
@@ -119,6 +121,8 @@ GRAD_CASES = [
     ('cat64_plain64_acc', 9, [(L.DST_PLAIN, 64, 1), (L.DST_PLAIN, 64, 1)], 128, 2, 10, 12, [0, 1, 2], 0.0, 1),
     ('k1_plain128', 1, [(L.DST_PLAIN, 128, 1)], 64, 2, 10, 34, [0, 1, 2], 0.0, 0),
     ('from_out2', 9, [(L.DST_PLAIN, 32, 1)], 2, 2, 16, 33, [0, 1, 2], 0.0, 0),
+    ('plain64_50x50_acc', 9, [(L.DST_PLAIN, 64, 1)], 64, 2, 50, 50, [0, 1, 2], 0.0, 1),             # 10 x 25 tiles
+    ('cat64_plain64_27x100', 9, [(L.DST_PLAIN, 64, 1), (L.DST_PLAIN, 64, 1)], 128, 2, 27, 100, [0, 2], 0.0, 0),
 ]
 
 
@@ -778,9 +782,10 @@ def test_layout_boundary_kernels(dtype):
     {'RD_CONV_WS': '3', 'RD_CONV_WS_MIN2': '0', 'RD_CONV_NB1_BELOW': '0'},          # conv_ws_kernel: forward AND gradient launches
     {'RD_CONV_WS': '0', 'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0'},           # conv_pp_kernel (LDS-staged epilogue) everywhere
     {'RD_CONV_PP_OFF': '1', 'RD_CONV_NB1_BELOW': '0'},                              # conv_pf_kernel with the register epilogues
+    {'RD_CONV_PP_OFF': '1', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_FLAT_TILES': '0'},   # ... on 8 x 32 tiles only (default: 10 x 25 where more lanes are live)
     {'RD_CONV_PP_OFF': '1', 'RD_CONV_PF_LEAN_OFF': '1', 'RD_CONV_NB1_BELOW': '0'},  # conv_pf_kernel with the LDS-staged epilogue
     {'RD_CONV_NB1_BELOW': '100000'},                                                # 32-wide tiles for every 64-wide launch
-], ids=['ws_fwd_bwd', 'pp_staged', 'pf_lean', 'pf_staged', 'nb1_everywhere'])
+], ids=['ws_fwd_bwd', 'pp_staged', 'pf_lean', 'pf_lean_8x32', 'pf_staged', 'nb1_everywhere'])
 def test_conv_kernels_under_forced_dispatch(env):
     """Which kernel a 64-wide launch takes depends on its size (csrc/conv_pp.hip, conv_big.hip), and the cases above are small.
     The dispatch switches (debug build of the library only) are read once per process: re-run the conv parity tests in a child
