@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
         const T* ap[NV];
         T* gp[NV];
         int Cd[NV], cd[NV];
-        bool live[NV], accum[NV], masked[NV];
+        bool live[NV], accum[NV], masked[NV], relu[NV];
         float slp[NV];                                       // activation slope of a = act(.) (1: none): one destination per vector
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -281,6 +281,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
             accum[v] = live[v] && d.accumulate;
             masked[v] = live[v] && d.act && d.z;
             slp[v] = (live[v] && as.mode == RD_SRC_AFFACT) ? as.slope : 1.f;
+            relu[v] = masked[v] && as.mode == RD_SRC_AFFACT && as.slope == 0.f && d.slope == 0.f;
             ap[v] = reinterpret_cast<const T*>(as.ptr) + (size_t)(n + as.n_off) * H * W * as.C + cd[v];
             gp[v] = reinterpret_cast<T*>(d.g) + (size_t)(n + d.n_off) * H * W * d.Cd + cd[v];
         }
@@ -311,19 +312,26 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
             if (it < nt) {
                 const uint4* s_in = reinterpret_cast<const uint4*>(s_inb + (it % 3) * FZ_IN_BYTES);
                 char* s_aw = s_ab + (it & 1) * FZ_A_BYTES;
+                // dgrad MFMAs of the wave's two tile rows (weights x pixels roles), INTERLEAVED: a row has one accumulator block, so
+                // its 18 MFMAs are one dependent chain (64 cycles each instead of 32); two chains side by side hide that
+                f32x16 accs[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accs[mb][r] = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    if (xp & 2) break;
+                    const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const int pix = (wave * 2 + mb + kh) * FZ_PW + li + kw;
+                        Mma<T>::chunk(s_w + (tap * NT + li) * 4, (li >> 2) & 3, s_in + pix * 4, ((li + kw) >> 2) & 3, h, accs[mb], nks);
+                    }
+                }
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
-                    // dgrad MFMAs of one tile row (weights x pixels roles)
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        if (xp & 2) break;
-                        const int kh = tap / 3, kw = tap % 3;
-                        const int pix = (wave * 2 + mb + kh) * FZ_PW + li + kw;
-                        Mma<T>::chunk(s_w + (tap * NT + li) * 4, (li >> 2) & 3, s_in + pix * 4, ((li + kw) >> 2) & 3, h, acc, nks);
-                    }
+                    const f32x16& acc = accs[mb];
                     // register epilogue of the row
                     const int y = y0 + wave * 2 + mb, x = x0 + li;
                     const bool valid = y < H && x < W;
@@ -342,15 +350,28 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
                         }
                         Slot<T>::unpack(araw[mb][v], xr);
                         const bool on = valid && live[v];
+                        if (relu[v]) {
+                            // BN + ReLU producer (every layer but ConvD.bn1 / raw inputs): a = max(y, 0), g = y > 0 ? da : 0
 #pragma unroll
-                        for (int e = 0; e < S; ++e) {
-                            const float yv = xr[e] * s_dsc[cb + e] + s_dsh[cb + e];
-                            av[e] = act_fn(yv, slp[v]);
-                            const float m = masked[v] ? act_grad(yv, p.dst[0].slope) : 1.f;
-                            const float gn = on ? vec[e] * m : 0.f;
-                            sa[v][e] += gn;
-                            sb[v][e] += gn * xr[e];
-                            go[e] = gn;
+                            for (int e = 0; e < S; ++e) {
+                                const float yv = xr[e] * s_dsc[cb + e] + s_dsh[cb + e];
+                                av[e] = fmaxf(yv, 0.f);
+                                const float gn = (on && yv > 0.f) ? vec[e] : 0.f;
+                                sa[v][e] += gn;
+                                sb[v][e] += gn * xr[e];
+                                go[e] = gn;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < S; ++e) {
+                                const float yv = xr[e] * s_dsc[cb + e] + s_dsh[cb + e];
+                                av[e] = act_fn(yv, slp[v]);
+                                const float m = masked[v] ? act_grad(yv, p.dst[0].slope) : 1.f;
+                                const float gn = on ? vec[e] * m : 0.f;
+                                sa[v][e] += gn;
+                                sb[v][e] += gn * xr[e];
+                                go[e] = gn;
+                            }
                         }
                         if (accum[v]) {                      // the old gradient of a second consumer (rare among these layers: not prefetched)
                             float gold[S];
