@@ -68,6 +68,7 @@ struct PpStage {            // wave-uniform position in the step stream
 struct PpGeo {
     int ncb, tiles_x, tiles_xy, nch, tile_end;
     int cb_slow, n_img;     // cb_slow: channel block is the slowest tile coordinate (register-resident BN sums)
+    int th, tw;             // pixel tile (conv_device.h TileGeo: 8 x 32, or 10 x 25 flattened onto the 256 MFMA rows)
 };
 
 // what a thread needs to know about its 16-byte channel slot of chunk c (one row per (chunk, slot), built once in LDS
@@ -90,8 +91,8 @@ __device__ __forceinline__ void pp_decode(PpStage& s, const PpGeo& q, const Grou
     const int r = q.cb_slow ? s.tile % per_cb : s.tile / q.ncb;
     s.txy = r % q.tiles_xy;
     s.n = r / q.tiles_xy;
-    s.y0 = (s.txy / q.tiles_x) * TH;
-    s.x0 = (s.txy % q.tiles_x) * TW;
+    s.y0 = (s.txy / q.tiles_x) * q.th;
+    s.x0 = (s.txy % q.tiles_x) * q.tw;
     s.n0 = cb * PP_NT;
     s.g = group_of(gm, s.n);
 }
@@ -125,6 +126,8 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
     q.nch = p.CinPad / 32;
     q.cb_slow = 0;
     q.n_img = p.N;
+    q.th = TH;
+    q.tw = TW;
     const int tile_begin = (int)((long long)blockIdx.x * tiles_total / gridDim.x);
     q.tile_end = (int)((long long)(blockIdx.x + 1) * tiles_total / gridDim.x);
     const int nsteps = (q.tile_end - tile_begin) * q.nch;
@@ -335,11 +338,15 @@ __device__ unsigned long long ws_trace[2][64][4];          // [role][step][event
 #define WS_EXP(bit) false
 #endif
 
-template <int MODE>
+template <int MODE, int TS>
 __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int tiles_total) {
     typedef bf16_t T;
     constexpr int S = 8;
     static_assert(MODE == 1 || MODE == 2, "register epilogues only");
+    // TS 1: 10 x 25 pixel tiles, flattened row-major onto the 256 MFMA rows (250 live); the 12 x 27 halo tile fits the planes of
+    // the 10 x 34 one, only the per-lane pixel of an MFMA row and the halo row pitch change
+    constexpr int THt = TileGeo<TS>::H, TWt = TileGeo<TS>::W, PWt = TWt + 2, NPIXt = (THt + 2) * PWt;
+    static_assert(NPIXt <= PP_NPIX && 64 * PP_NIT >= NPIXt, "halo tile must fit the LDS planes");
     // who stages the weight chunk of the next step: the MFMA waves in the forward mode (they have ~1.5 issue slots per MFMA
     // gap to spare and 36 registers of headroom; the loader's nine weight vectors cost 1000-3000 cycles per step on top of
     // its ~3000 for the halo items against ~3300 of MFMAs: traces in profiles/r02_ws_trace.txt), the loader waves in the
@@ -359,11 +366,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
 #endif
     PpGeo q;
     q.ncb = p.CoutPad / PP_NT;
-    q.tiles_x = (W + TW - 1) / TW;
-    q.tiles_xy = q.tiles_x * ((H + TH - 1) / TH);
+    q.tiles_x = (W + TWt - 1) / TWt;
+    q.tiles_xy = q.tiles_x * ((H + THt - 1) / THt);
     q.nch = p.CinPad / 32;
     q.cb_slow = 1;
     q.n_img = p.N;
+    q.th = THt;
+    q.tw = TWt;
     const int tile_begin = (int)((long long)blockIdx.x * tiles_total / gridDim.x);
     q.tile_end = (int)((long long)(blockIdx.x + 1) * tiles_total / gridDim.x);
     const int nsteps = (q.tile_end - tile_begin) * q.nch;
@@ -415,9 +424,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
 #pragma unroll
         for (int b = 0; b < PP_NIT; ++b) {
             const int pix = (tid >> 2) + 64 * b;
-            const int py = pix / PP_PW;
-            it_yx[b] = (py << 16) | (pix - py * PP_PW);
-            it_lds[b] = sw * PP_PLANE_A + (pix < PP_NPIX ? pix : PP_NPIX) * 16;
+            const int py = pix / PWt;
+            it_yx[b] = (py << 16) | (pix - py * PWt);
+            it_lds[b] = sw * PP_PLANE_A + (pix < NPIXt ? pix : PP_NPIX) * 16;
         }
         const int w_lds = PP_W0 + sw * PP_PLANE_W + nn_w * 16;
         const T* wbase = reinterpret_cast<const T*>(p.w) + nn_w * 32 + sw * S;
@@ -548,7 +557,14 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     }
 
     // =================================================================================== MFMA waves
-    const int a_base = h * PP_PLANE_A + (wave * 2 * PP_PW + li) * 16;
+    // this lane's pixel of the wave's two MFMA row blocks: tile row / column, LDS offset of its halo origin
+    int px_r[2], px_c[2], a_off[2];
+    bool px_live[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        tile_pixel<TS>(wave * 2 + mb, li, px_r[mb], px_c[mb], px_live[mb]);
+        a_off[mb] = h * PP_PLANE_A + (px_r[mb] * PWt + px_c[mb]) * 16;
+    }
     const int b_base = PP_W0 + h * PP_PLANE_W + li * 16;
     const float* tab = reinterpret_cast<const float*>(smem + WS_TAB);
     PpStage M;
@@ -581,10 +597,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     auto load_group = [&](int grp, int par, Frag& f) {
         const int tap = grp >> 1, ks = grp & 1;
         const int kh = tap / 3, kw = tap - 3 * kh;
-        const char* s_a = smem + par * PP_IN_BYTES + a_base + ks * 2 * PP_PLANE_A;
+        const char* s_a = smem + par * PP_IN_BYTES + ks * 2 * PP_PLANE_A;
         const char* s_b = smem + par * PP_W_BYTES + b_base + ks * 2 * PP_PLANE_W;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) f.a[mb] = *reinterpret_cast<const uint4*>(s_a + ((mb + kh) * PP_PW + kw) * 16);
+        for (int mb = 0; mb < 2; ++mb) f.a[mb] = *reinterpret_cast<const uint4*>(s_a + a_off[mb] + (kh * PWt + kw) * 16);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) f.b[nb] = *reinterpret_cast<const uint4*>(s_b + (tap * PP_NT + nb * 32) * 16);
     };
@@ -652,7 +668,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     auto dgrad_prefetch = [&]() {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-            const int y = min(M.y0 + wave * 2 + mb, H - 1), x = min(M.x0 + li, W - 1);
+            const int y = min(M.y0 + px_r[mb], H - 1), x = min(M.x0 + px_c[mb], W - 1);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -720,9 +736,16 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                 cur_n0 = M.n0;
                 cur_g = M.g;
             }
-            const int y0r = M.y0 + wave * 2, x = M.x0 + li;
+            int py[2], pxx[2];
+            bool pin[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                py[mb] = M.y0 + px_r[mb];
+                pxx[mb] = M.x0 + px_c[mb];
+                pin[mb] = px_live[mb] && py[mb] < H && pxx[mb] < W;
+            }
             if constexpr (MODE == 1) {
-                T* out = reinterpret_cast<T*>(p.out) + ((size_t)(M.n * H + y0r) * W + x) * p.Cout + M.n0 + 8 * h;
+                T* out = reinterpret_cast<T*>(p.out) + (size_t)M.n * H * W * p.Cout + M.n0 + 8 * h;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -735,7 +758,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                         for (int mb = 0; mb < 2; ++mb) {
                             float o[S];
                             regroup(acc[mb][nb], v, o);
-                            if (y0r + mb < H && x < W) {
+                            if (pin[mb]) {
 #pragma unroll
                                 for (int e = 0; e < S; ++e) {
                                     if (!WS_EXP(32)) {
@@ -744,7 +767,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                                     }
                                     o[e] += bs[e];
                                 }
-                                if (!WS_EXP(16)) *reinterpret_cast<uint4*>(out + (size_t)mb * W * p.Cout + nb * 32 + 16 * v) = Slot<T>::pack(o);
+                                if (!WS_EXP(16)) *reinterpret_cast<uint4*>(out + (size_t)(py[mb] * W + pxx[mb]) * p.Cout + nb * 32 + 16 * v) = Slot<T>::pack(o);
                             }
                         }
                     }
@@ -766,8 +789,8 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                         for (int mb = 0; mb < 2; ++mb) {
                             float da[S];
                             regroup(acc[mb][nb], v, da);
-                            if (!(y0r + mb < H && x < W)) continue;
-                            T* gp = reinterpret_cast<T*>(d.g) + dst_index(d, di, nb, v, y0r + mb, x);
+                            if (!pin[mb]) continue;
+                            T* gp = reinterpret_cast<T*>(d.g) + dst_index(d, di, nb, v, py[mb], pxx[mb]);
                             float z[S], gw[S];
                             Slot<T>::unpack(zq[mb][nb][v], z);
                             Slot<T>::unpack(d.accumulate ? ld16(gp) : make_uint4(0, 0, 0, 0), gw);
@@ -820,8 +843,10 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     if (!n_cu) {
         n_cu = rd_num_cus();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / PP_NT);
     const int cus = (p.cu_limit > 0 && p.cu_limit < n_cu) ? p.cu_limit : n_cu;     // a side lane's budget (ramdsir.h)
@@ -843,9 +868,19 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         // debug build only: RD_CONV_WS_EXP = timing experiments (-DRD_WS_EXP), RD_CONV_WS_TRACE_MIN = launches with at least
         // that many tiles record the s_memtime trace (scripts/ws_trace.py); both ride in the high bits of the tile count
         static const int ws_exp = rd_switch("RD_CONV_WS_EXP", 0), ws_trace_min = rd_switch("RD_CONV_WS_TRACE_MIN", 1 << 30);
-        const int arg = tiles | (ws_exp << 26) | (tiles >= ws_trace_min ? 1 << 25 : 0);
-        if (mode == 1) hipLaunchKernelGGL(conv_ws_kernel<1>, dim3(grid), dim3(512), PP_LDS, st, p, arg);
-        else hipLaunchKernelGGL(conv_ws_kernel<2>, dim3(grid), dim3(512), PP_LDS, st, p, arg);
+        // 10 x 25 tiles where they put more of the MFMA rows on image pixels (sides 25 / 50 / 100 / 200: fewer tiles per CU)
+        static const int ws_flat = rd_switch("RD_CONV_WS_FLAT", 1);
+        const int tiles1 = ((p.W + TileGeo<1>::W - 1) / TileGeo<1>::W) * ((p.H + TileGeo<1>::H - 1) / TileGeo<1>::H) * p.N * (p.CoutPad / PP_NT);
+        const bool flat = ws_flat && tiles1 * 1.04 < tiles;
+        const int nt = flat ? tiles1 : tiles, grid_ws = nt < cus ? nt : cus;
+        const int arg = nt | (ws_exp << 26) | (tiles >= ws_trace_min ? 1 << 25 : 0);
+        if (mode == 1) {
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1>), dim3(grid_ws), dim3(512), PP_LDS, st, p, arg);
+            else hipLaunchKernelGGL((conv_ws_kernel<1, 0>), dim3(grid_ws), dim3(512), PP_LDS, st, p, arg);
+        } else {
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1>), dim3(grid_ws), dim3(512), PP_LDS, st, p, arg);
+            else hipLaunchKernelGGL((conv_ws_kernel<2, 0>), dim3(grid_ws), dim3(512), PP_LDS, st, p, arg);
+        }
         return (int)hipGetLastError();
     }
     // conv_pp_kernel (LDS-staged epilogue, any destination): measured (gpurun_out/lb_pp*.txt) 1.06-1.2x over conv_pf_kernel

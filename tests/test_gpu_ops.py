@@ -780,12 +780,13 @@ def test_layout_boundary_kernels(dtype):
 # ------------------------------------------------------------------------------------ every 64-wide conv kernel
 @pytest.mark.parametrize('env', [
     {'RD_CONV_WS': '3', 'RD_CONV_WS_MIN2': '0', 'RD_CONV_NB1_BELOW': '0'},          # conv_ws_kernel: forward AND gradient launches
+    {'RD_CONV_WS': '3', 'RD_CONV_WS_MIN2': '0', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_WS_FLAT': '0'},   # ... on 8 x 32 tiles only
     {'RD_CONV_WS': '0', 'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0'},           # conv_pp_kernel (LDS-staged epilogue) everywhere
     {'RD_CONV_PP_OFF': '1', 'RD_CONV_NB1_BELOW': '0'},                              # conv_pf_kernel with the register epilogues
     {'RD_CONV_PP_OFF': '1', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_FLAT_TILES': '0'},   # ... on 8 x 32 tiles only (default: 10 x 25 where more lanes are live)
     {'RD_CONV_PP_OFF': '1', 'RD_CONV_PF_LEAN_OFF': '1', 'RD_CONV_NB1_BELOW': '0'},  # conv_pf_kernel with the LDS-staged epilogue
     {'RD_CONV_NB1_BELOW': '100000'},                                                # 32-wide tiles for every 64-wide launch
-], ids=['ws_fwd_bwd', 'pp_staged', 'pf_lean', 'pf_lean_8x32', 'pf_staged', 'nb1_everywhere'])
+], ids=['ws_fwd_bwd', 'ws_fwd_bwd_8x32', 'pp_staged', 'pf_lean', 'pf_lean_8x32', 'pf_staged', 'nb1_everywhere'])
 def test_conv_kernels_under_forced_dispatch(env):
     """Which kernel a 64-wide launch takes depends on its size (csrc/conv_pp.hip, conv_big.hip), and the cases above are small.
     The dispatch switches (debug build of the library only) are read once per process: re-run the conv parity tests in a child
