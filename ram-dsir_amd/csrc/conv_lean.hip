@@ -34,7 +34,7 @@ int launch_lean(const rd_conv_t& p, int ep, int nq, hipStream_t st) {
 // a round (scripts/layer_bench.py, RD_CONV_FLAT_TILES 0 / 1: dec.convu4.conv3 dgrad 104 -> 95 us, enc.convd3.* 52-56 -> 48-52,
 // dec.convu3.conv1 72 -> 68, others +-5 %: the sum over the family is unchanged) -- but in the STEP every workgroup not launched
 // is CU time the other two lanes get: 5.07-5.08 ms with 8 x 32 only, 5.06 with the whole-round rule (mode 2), 5.03 with mode 1
-// (scripts/sweep_opts.sh, alternating).  The persistent conv_ws_kernel keeps 8 x 32 tiles for now.
+// (scripts/sweep_opts.sh, alternating).  The persistent conv_ws_kernel has the same choice (conv_pp.hip, RD_CONV_WS_FLAT).
 template <int NB>
 inline bool flat_tiles(const rd_conv_t& p) {
     const int mode = rd_switch("RD_CONV_FLAT_TILES", 1);       // 0 never, 1 whenever more lanes are live, 2 only when a round goes away

@@ -868,7 +868,10 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         // debug build only: RD_CONV_WS_EXP = timing experiments (-DRD_WS_EXP), RD_CONV_WS_TRACE_MIN = launches with at least
         // that many tiles record the s_memtime trace (scripts/ws_trace.py); both ride in the high bits of the tile count
         static const int ws_exp = rd_switch("RD_CONV_WS_EXP", 0), ws_trace_min = rd_switch("RD_CONV_WS_TRACE_MIN", 1 << 30);
-        // 10 x 25 tiles where they put more of the MFMA rows on image pixels (sides 25 / 50 / 100 / 200: fewer tiles per CU)
+        // 10 x 25 tiles where they put more of the MFMA rows on image pixels (sides 50 / 100 / 200: fewer tiles per CU).  The twelve
+        // forward launches of the step that come here, alone (scripts/layer_bench.py, RD_CONV_WS_FLAT 0 -> 1): 574 -> 513 us summed
+        // (dec.convu4.conv3 81 -> 66, dec.convu3.conv3 78 -> 65, dec.convu2.conv3 84 -> 73, the 50-pixel levels 32-37 -> 29-33);
+        // step 4.97 -> 4.92 ms (scripts/sweep_opts.sh, three alternating pairs)
         static const int ws_flat = rd_switch("RD_CONV_WS_FLAT", 1);
         const int tiles1 = ((p.W + TileGeo<1>::W - 1) / TileGeo<1>::W) * ((p.H + TileGeo<1>::H - 1) / TileGeo<1>::H) * p.N * (p.CoutPad / PP_NT);
         const bool flat = ws_flat && tiles1 * 1.04 < tiles;
