@@ -17,6 +17,8 @@ int rd_bwd_fused_reduce_dispatch(const rd_conv_t& dgrad, const rd_wgrad_t& wgrad
 // persistent software-pipelined 3x3 kernel for bf16 launches with CoutPad % 64 == 0 and plain sources (conv_pp.hip);
 // RD_CONV_PP_NA when the launch does not qualify (the caller falls back to conv_big's kernels)
 constexpr int RD_CONV_PP_NA = -1000;
+// forward kernel of the small-channel 3x3 convs with whole channel slots (conv_small_fwd.hip); RD_CONV_PP_NA when the launch does not qualify
+int rd_conv_small_fwd_dispatch(const rd_conv_t& p, int dtype, hipStream_t st);
 int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st);
 
 // Register ("lean") epilogues: accumulators leave as 16-byte NHWC vectors straight from registers (MFMA roles swapped:

@@ -560,6 +560,10 @@ int dispatch_conv_small(const rd_conv_t& p, hipStream_t st) {
 }  // namespace
 
 int rd_conv_small_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
+    if (dtype == RD_BF16 && p.taps == 9 && p.emode == 0) {                // forward launches: conv_small_fwd_kernel where it applies
+        const int r = rd_conv_small_fwd_dispatch(p, dtype, st);
+        if (r != RD_CONV_PP_NA) return r;
+    }
     if (dtype == RD_BF16) return p.taps == 9 ? dispatch_conv_small<bf16_t, 9>(p, st) : dispatch_conv_small<bf16_t, 1>(p, st);
     return p.taps == 9 ? dispatch_conv_small<float, 9>(p, st) : dispatch_conv_small<float, 1>(p, st);
 }

@@ -392,10 +392,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
 // `a`, the dz operand(s)) and keep the tile after that in flight.  The single-role kernel runs fill and MFMAs back to back
 // at one wave per SIMD (SQ counters: 47% of the wave cycles issuing, 20% issue-stalled: profiles/r02_sq_counters.txt).
 // LDS tiles are 4 rows x 32 pixels (half of the single-role kernel's) so that two buffers fit: 2 x 48 KB.
-template <int NQZ>
-// xp: timing experiments of the debug build (RD_WGWS_EXP bits; wrong results when set): 1 no MFMA phase, 2 loader issues no global loads,
-// 4 loader does not transform / write LDS
-__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles, int xp) {
+// XP: timing experiments of the debug build, compile-time so that they do not change the code around them (RD_WGWS_EXP; wrong results
+// when set): 1 no MFMA phase, 4 loader does not transform / write LDS
+template <int NQZ, int XP>
+__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
     typedef bf16_t T;
     constexpr int S = 8, TAPS = 9;
     constexpr int THW = 4;
@@ -405,6 +405,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
     constexpr int NITA = (NPIX * NSA + 255) / 256, NITZ = (THW * TW * NSZ) / 256;
     constexpr int A_BYTES = (NPIX + 4) * PA, Z_BYTES = THW * TW * PZ, BUF = A_BYTES + Z_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_coef = reinterpret_cast<float*>(smem + 2 * BUF);           // [G][a, z][sc, sh, q][64]: the loader's coefficients
 
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // 0: MFMA waves, 1: loader waves
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -420,11 +421,34 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
     {
         uint4* z4 = reinterpret_cast<uint4*>(smem);
         for (int i = threadIdx.x; i < 2 * BUF / 16; i += 512) z4[i] = make_uint4(0, 0, 0, 0);
+        // BatchNorm coefficients of this workgroup's 64 input / 64 gradient channels, every image group: read from global memory
+        // HERE, once -- a coefficient load inside the tile loop (when the group changes) would be a conditional vector-memory load,
+        // and with one of those anywhere in the loop the compiler can no longer count the loads in flight (see the loader below)
+        for (int i = threadIdx.x; i < p.G * 2 * 64; i += 512) {
+            const int c = i & 63, which = (i >> 6) & 1, g = i >> 7;
+            const int c_abs = (which ? nbase : cbase) + c;
+            const int si = (which || p.na == 1 || c_abs < p.a[0].C) ? 0 : 1;
+            const rd_src_t sd = which ? p.dz : select_src(p.a, si);
+            const int cc = c_abs - ((!which && si) ? p.a[0].C : 0);
+            const bool live = c_abs < (which ? p.Cout : p.Cin);
+            const bool raw = sd.mode == RD_SRC_RAW || !live, bwd = sd.mode == RD_SRC_BNBWD && live;
+            const int gs = sd.g_fixed >= 0 ? sd.g_fixed : g;
+            float* row = s_coef + (size_t)((g * 2 + which) * 3) * 64 + c;
+            row[0] = raw ? 1.f : sd.scale[gs * sd.C + cc];
+            row[64] = raw ? 0.f : sd.shift[gs * sd.C + cc];
+            row[128] = bwd ? sd.q[gs * sd.C + cc] : 0.f;
+        }
     }
     __syncthreads();
 
     if (role == 1) {
         // =============================================================================== loader waves
+        // BRANCH-FREE vector-memory traffic: the hardware counts a wave's outstanding loads in order (vmcnt) and the compiler can
+        // only wait for "all but the N youngest" when N is the same on every path that reaches the wait -- with ONE conditional
+        // load in the loop (a dead channel slot, the last tiles, a coefficient reload, a run-time experiment switch) every wait
+        // becomes vmcnt(0): the set requested a moment ago is waited for together with the one that is needed, and the second
+        // register set buys nothing.  So every thread always loads: channel slots beyond Cin / Cout read slot 0 and skip the LDS
+        // write, tiles past the end are GHOSTS (pixel (0, 0) of image 0: one cache line).
         const GroupMap gm = make_gm(p.gstart, p.G);
         const int sla = tid % NSA, slz = tid % NSZ;
         const int ca_abs = cbase + sla * S, cz_abs = nbase + slz * S;
@@ -442,14 +466,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             const int pix = tid / NSA + (256 / NSA) * b, py = pix / PW, px = pix - py * PW;
             iga.py[b] = (short)py;
             iga.px[b] = (short)px;
-            iga.lds[b] = pix < NPIX ? pix * PA + sla * 16 : -1;
+            iga.lds[b] = (pix < NPIX && live_a) ? pix * PA + sla * 16 : -1;
         }
 #pragma unroll
         for (int b = 0; b < NITZ; ++b) {
             const int pix = tid / NSZ + (256 / NSZ) * b;
             igz.py[b] = (short)(pix / TW);
             igz.px[b] = (short)(pix % TW);
-            igz.lds[b] = pix * PZ + slz * 16;
+            igz.lds[b] = live_z ? pix * PZ + slz * 16 : -1;
         }
         // TWO register sets: the tiles after the next are in flight while the next one is transformed.  (With one set the
         // request went out right before the barrier and was consumed right behind it: as the loader is the slower role the
@@ -459,8 +483,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
         auto issue = [&](uint4 (&ra)[NITA][1], uint4 (&rz)[NITZ][NQZ], int tile) {
             int n, y0, x0;
             coords(tile, n, y0, x0);
-            if (live_a) pfu_issue<T, NITA>(ra, psa, iga, n, H, W, y0 - 1, x0 - 1);
-            if (live_z) pfu_issue<T, NITZ>(rz, psz, igz, n, H, W, y0, x0);
+            const bool ghost = tile >= total_tiles;
+            n = ghost ? 0 : n;
+            y0 = ghost ? -(1 << 20) : y0;
+            x0 = ghost ? -(1 << 20) : x0;
+            pfu_issue<T, NITA>(ra, psa, iga, n, H, W, y0 - 1, x0 - 1);
+            pfu_issue<T, NITZ>(rz, psz, igz, n, H, W, y0, x0);
         };
         const bool z_raw = p.dz.mode == RD_SRC_RAW;             // a stored dz / dlogits: copied, not transformed
         int g_ctx = -1;
@@ -468,42 +496,59 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
         auto fill = [&](uint4 (&ra)[NITA][1], uint4 (&rz)[NITZ][NQZ], int tile, int it) {
             int n, y0, x0;
             coords(tile, n, y0, x0);
+            const bool ghost = tile >= total_tiles;           // zeros into the buffer nobody reads any more
+            n = ghost ? 0 : n;
+            y0 = ghost ? -(1 << 20) : y0;
+            x0 = ghost ? -(1 << 20) : x0;
             const int g = group_of(gm, n);
-            if (g != g_ctx) {
-                if (live_a) plain_src_coef<T>(psa, sda, g, ca);
-                if (live_z) plain_src_coef<T>(psz, p.dz, g, cz_abs);
+            if (g != g_ctx) {                                 // LDS reads (lgkmcnt), not vector-memory loads
+                const float* ra_c = s_coef + (size_t)(g * 2 * 3) * 64 + sla * S;
+                const float* rz_c = s_coef + (size_t)((g * 2 + 1) * 3) * 64 + slz * S;
+#pragma unroll
+                for (int e = 0; e < S; ++e) {
+                    psa.sc[e] = ra_c[e];
+                    psa.sh[e] = ra_c[64 + e];
+                    psa.q[e] = ra_c[128 + e];
+                    psz.sc[e] = rz_c[e];
+                    psz.sh[e] = rz_c[64 + e];
+                    psz.q[e] = rz_c[128 + e];
+                }
                 g_ctx = g;
             }
             char* s_a = smem + (it & 1) * BUF;
             char* s_z = s_a + A_BYTES;
-            if (live_a && !(xp & 4))
+            if constexpr (!(XP & 4)) {
                 pfu_consume<T, NITA, 1>(ra, psa, iga, H, W, y0 - 1, x0 - 1,
                                         [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
-            if (live_z && !(xp & 4)) {
                 if (z_raw && NQZ == 1) {
 #pragma unroll
                     for (int b = 0; b < NITZ; ++b) {
                         const int y = y0 + igz.py[b], x = x0 + igz.px[b];
-                        *reinterpret_cast<uint4*>(s_z + igz.lds[b]) = (y < H && x < W) ? rz[b][0] : make_uint4(0, 0, 0, 0);
+                        if (igz.lds[b] >= 0) *reinterpret_cast<uint4*>(s_z + igz.lds[b]) = (y < H && x < W) ? rz[b][0] : make_uint4(0, 0, 0, 0);
                     }
                 } else {
                     pfu_consume<T, NITZ, NQZ>(rz, psz, igz, H, W, y0, x0,
                                               [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_z + l) = u; });
                 }
+            } else {
+                unsigned acc = 0;                               // wait for the set, touch nothing else
+#pragma unroll
+                for (int b = 0; b < NITA; ++b) acc ^= ra[b][0].x ^ ra[b][0].y ^ ra[b][0].z ^ ra[b][0].w;
+#pragma unroll
+                for (int b = 0; b < NITZ; ++b) acc ^= rz[b][0].x ^ rz[b][0].y ^ rz[b][0].z ^ rz[b][0].w;
+                if (acc == 0x12345678u) *reinterpret_cast<unsigned*>(s_a) = acc;
             }
-            if (tile + 2 * stride < total_tiles && !(xp & 2)) issue(ra, rz, tile + 2 * stride);
+            issue(ra, rz, tile + 2 * stride);                 // a ghost past the end
         };
         const int t0 = blockIdx.x;
-        if (t0 < total_tiles) issue(raw_aA, raw_zA, t0);
-        if (t0 + stride < total_tiles) issue(raw_aB, raw_zB, t0 + stride);
+        issue(raw_aA, raw_zA, t0);
+        issue(raw_aB, raw_zB, t0 + stride);
         int it = 0;
         for (int tile = t0; tile < total_tiles; tile += 2 * stride, it += 2) {
             fill(raw_aA, raw_zA, tile, it);
             __syncthreads();               // tile `it` is in its buffer; the MFMA waves are done with the other one
-            if (tile + stride < total_tiles) {
-                fill(raw_aB, raw_zB, tile + stride, it + 1);
-                __syncthreads();
-            }
+            fill(raw_aB, raw_zB, tile + stride, it + 1);
+            if (tile + stride < total_tiles) __syncthreads();
         }
         return;
     }
@@ -522,7 +567,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
     int it = 0;
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
         __syncthreads();
-        if (xp & 1) continue;
+        if constexpr ((XP & 1) != 0) continue;
         const char* s_a = smem + (it & 1) * BUF;
         const char* s_z = s_a + A_BYTES;
 #pragma unroll
@@ -870,19 +915,30 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
         // 64 x 64 blocks, plain sources: the warp-specialised kernel (4-row LDS tiles: twice the tile count)
         static const int ws = rd_switch("RD_WG_WS", 1);
         if (ws && wgrad_pf_ok(p)) {
-            static bool ws_attr = false;
-            constexpr int ws_lds = 2 * ((6 * PW + 4) * 144 + 4 * TW * 144);
-            if (!ws_attr) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds);
-                ws_attr = true;
-            }
+            const int ws_lds = 2 * ((6 * PW + 4) * 144 + 4 * TW * 144) + p.G * 2 * 3 * 64 * (int)sizeof(float);
             const int tiles_ws = p.N * ((p.H + 3) / 4) * ((p.W + TW - 1) / TW);
-            if (p.dz.mode == RD_SRC_BNBWD)
-                hipLaunchKernelGGL(wgrad_ws_kernel<2>, grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws, rd_switch("RD_WGWS_EXP", 0));
-            else
-                hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws, rd_switch("RD_WGWS_EXP", 0));
-            return (int)hipGetLastError();
+#define RD_WGWS_LAUNCH(NQZ, XP) do { \
+                static int attr_lds = 0; \
+                if (attr_lds < ws_lds) { \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<NQZ, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds); \
+                    attr_lds = ws_lds; \
+                } \
+                hipLaunchKernelGGL((wgrad_ws_kernel<NQZ, XP>), grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws); \
+                return (int)hipGetLastError(); \
+            } while (0)
+#ifdef RD_DEBUG_SWITCHES
+            if (p.dz.mode != RD_SRC_BNBWD) {
+                switch (rd_switch("RD_WGWS_EXP", 0)) {
+                case 1: RD_WGWS_LAUNCH(1, 1);
+                case 4: RD_WGWS_LAUNCH(1, 4);
+                case 5: RD_WGWS_LAUNCH(1, 5);
+                default: break;
+                }
+            }
+#endif
+            if (p.dz.mode == RD_SRC_BNBWD) RD_WGWS_LAUNCH(2, 0);
+            RD_WGWS_LAUNCH(1, 0);
+#undef RD_WGWS_LAUNCH
         }
     }
     if (!wgrad_pf_ok(p))

@@ -64,6 +64,11 @@ FWD_CASES = [
     ('raw128_64', 9, [(L.SRC_RAW, 128)], 64, 2, 9, 33, [0, 1, 2], 0.0),
     ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, [0, 1, 2], 0.0),
     ('out16_3', 9, [(L.SRC_AFFACT, 16)], 3, 3, 8, 32, [0, 1, 2, 3], 0.0),
+    # conv_small_fwd_kernel: many tiles per image (ragged right / bottom), 1 / 3-of-4 / 4 live channel slots
+    ('affact32_32_70x100', 9, [(L.SRC_AFFACT, 32)], 32, 2, 70, 100, [0, 1, 2], 0.0),
+    ('raw8_32_45x70', 9, [(L.SRC_RAW, 8)], 32, 2, 45, 70, [0, 2], 0.0),
+    ('aff24_16_33x65', 9, [(L.SRC_AFF, 24)], 16, 2, 33, 65, [0, 1, 2], 0.0),
+    ('cat16_aff8_32_41x64', 9, [(L.SRC_AFFACT, 16), (L.SRC_AFFACT, 8)], 32, 2, 41, 64, [0, 2], 0.0),
     ('c256_256', 9, [(L.SRC_AFFACT, 256)], 256, 2, 6, 7, [0, 1, 2], 0.0),
     ('c64_64_50x50', 9, [(L.SRC_AFFACT, 64)], 64, 2, 50, 50, [0, 1, 2], 0.0),          # 10 x 25 tiles: 5 x 2 per image, every lane but 6 live
     ('c128_64_23x100', 9, [(L.SRC_AFFACT, 128)], 64, 2, 23, 100, [0, 2], 0.0),          # ... a ragged last tile row
@@ -786,7 +791,10 @@ def test_layout_boundary_kernels(dtype):
     {'RD_CONV_PP_OFF': '1', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_FLAT_TILES': '0'},   # ... on 8 x 32 tiles only (default: 10 x 25 where more lanes are live)
     {'RD_CONV_PP_OFF': '1', 'RD_CONV_PF_LEAN_OFF': '1', 'RD_CONV_NB1_BELOW': '0'},  # conv_pf_kernel with the LDS-staged epilogue
     {'RD_CONV_NB1_BELOW': '100000'},                                                # 32-wide tiles for every 64-wide launch
-], ids=['ws_fwd_bwd', 'ws_fwd_bwd_8x32', 'pp_staged', 'pf_lean', 'pf_lean_8x32', 'pf_staged', 'nb1_everywhere'])
+    {'RD_SW_TPW': '5'},                                                             # conv_small_fwd_kernel: 5 tiles per workgroup (+ ghosts)
+    {'RD_SW_TPW': '2'},                                                             # ... fewer tiles than register sets
+    {'RD_CONV_SMALL_FWD': '0'},                                                      # conv_small_kernel for the forward launches
+], ids=['ws_fwd_bwd', 'ws_fwd_bwd_8x32', 'pp_staged', 'pf_lean', 'pf_lean_8x32', 'pf_staged', 'nb1_everywhere', 'small_fwd_tpw5', 'small_fwd_tpw2', 'small_fwd_off'])
 def test_conv_kernels_under_forced_dispatch(env):
     """Which kernel a 64-wide launch takes depends on its size (csrc/conv_pp.hip, conv_big.hip), and the cases above are small.
     The dispatch switches (debug build of the library only) are read once per process: re-run the conv parity tests in a child
