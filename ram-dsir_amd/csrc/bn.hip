@@ -158,8 +158,8 @@ __device__ __forceinline__ void reduce_stats_d(double (&A1)[S], double (&A2)[S],
     if (lane < SL) {
 #pragma unroll
         for (int e = 0; e < S; ++e) {
-            atomicAdd(&s_red[(sl * S + e) * 2 + 0], A1[e]);
-            atomicAdd(&s_red[(sl * S + e) * 2 + 1], A2[e]);
+            atomicAdd(&s_red[(sl * S + e) * 2 + 0], (double)A1[e]);
+            atomicAdd(&s_red[(sl * S + e) * 2 + 1], (double)A2[e]);
         }
     }
     __syncthreads();
@@ -508,9 +508,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void grad_in_kernel(const float* dy, const T* z, T* gout, const float* scale,
                                                       const float* shift, double* bstats, int act, float slope,
                                                       int accumulate, int C, int H, int W, GroupMap gm) {
-    extern __shared__ float s_red[];                       // [C][2]
+    extern __shared__ double s_red[];                      // [C][2]
     const int n = blockIdx.y, g = group_of(gm, n);
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_red[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_red[i] = 0.0;
     __syncthreads();
     const int HW = H * W;
     const int p0 = blockIdx.x * 64;
@@ -527,14 +527,14 @@ __global__ __launch_bounds__(256) void grad_in_kernel(const float* dy, const T* 
         }
         float a = wave_sum(gn), b = wave_sum(gn * zz);     // 64 lanes share channel c
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&s_red[c * 2 + 0], a);
-            atomicAdd(&s_red[c * 2 + 1], b);
+            atomicAdd(&s_red[c * 2 + 0], (double)a);
+            atomicAdd(&s_red[c * 2 + 1], (double)b);
         }
     }
     __syncthreads();
     if (bstats) {
         const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
-        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&bstats[((size_t)g * RD_STAT_SLOTS + slot) * C * 2 + i], (double)s_red[i]);
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&bstats[((size_t)g * RD_STAT_SLOTS + slot) * C * 2 + i], s_red[i]);
     }
 }
 
@@ -757,10 +757,10 @@ int rd_grad_in(const float* dy, const void* z, void* g, const float* scale, cons
     const GroupMap gm = host_gm(G, gstart_host);
     dim3 grid((H * W + 63) / 64, N);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(grad_in_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, dy, (const bf16_t*)z,
+        hipLaunchKernelGGL(grad_in_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, dy, (const bf16_t*)z,
                            (bf16_t*)g, scale, shift, bstats, act, slope, accumulate, C, H, W, gm);
     else
-        hipLaunchKernelGGL(grad_in_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, dy, (const float*)z,
+        hipLaunchKernelGGL(grad_in_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, dy, (const float*)z,
                            (float*)g, scale, shift, bstats, act, slope, accumulate, C, H, W, gm);
     return (int)hipGetLastError();
 }

@@ -567,7 +567,11 @@ __device__ __forceinline__ void grad_plain(const rd_dst_t& d, int n, int y, int 
 // sum b1/b2 over the lanes of a wave that own the same channel slot (lane % SL), then one LDS atomic per
 // wave and channel instead of one per thread (64-way same-address contention otherwise)
 template <int S, int SL>
-__device__ __forceinline__ void flush_bstats(float* s_red, int lane, int sl, float* b1, float* b2) {
+// The per-workgroup sums of the BatchNorm statistics are accumulated in FP64 in LDS (and in fp64 slots in global memory): the waves of a
+// workgroup arrive in a timing-dependent order, an fp32 accumulator would round differently from run to run, and every statistic is
+// amplified through the remaining layers (DESIGN.md Numerics).  A sum of fp32 values in fp64 is exact as long as the terms span fewer
+// than 2^(53-24) in magnitude and count, i.e. independent of the order: the step is reproducible run to run (scripts/repro_check.py).
+__device__ __forceinline__ void flush_bstats(double* s_red, int lane, int sl, float* b1, float* b2) {
 #pragma unroll
     for (int e = 0; e < S; ++e) {
 #pragma unroll
@@ -579,8 +583,8 @@ __device__ __forceinline__ void flush_bstats(float* s_red, int lane, int sl, flo
     if (lane < SL) {
 #pragma unroll
         for (int e = 0; e < S; ++e) {
-            atomicAdd(&s_red[(sl * S + e) * 2 + 0], b1[e]);
-            atomicAdd(&s_red[(sl * S + e) * 2 + 1], b2[e]);
+            atomicAdd(&s_red[(sl * S + e) * 2 + 0], (double)b1[e]);
+            atomicAdd(&s_red[(sl * S + e) * 2 + 1], (double)b2[e]);
         }
     }
 }

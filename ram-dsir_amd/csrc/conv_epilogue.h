@@ -20,13 +20,13 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
     // on 16-byte slots (coalesced stores; vector reads of z / old gradients in the backward epilogues).
     constexpr int SL = 32 / S;                             // slots per 32 channels
     float* s_out = reinterpret_cast<float*>(smem);         // [TH*TW][32]
-    float* s_red = s_out + TH * TW * 32;                   // [32][2]
+    double* s_red = reinterpret_cast<double*>(s_out + TH * TW * 32);   // [32][2]
     T* out = reinterpret_cast<T*>(p.out);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         __syncthreads();
         const int cb = n0 + nb * 32;
-        if (tid < 64) s_red[tid] = 0.f;
+        if (tid < 64) s_red[tid] = 0.0;
         {
             const int cch = cb + li;
             const bool cok = cch < p.Cout;
@@ -49,8 +49,8 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
                 if (h == 0 && cok) {
-                    atomicAdd(&s_red[li * 2 + 0], s1);
-                    atomicAdd(&s_red[li * 2 + 1], s2);
+                    atomicAdd(&s_red[li * 2 + 0], (double)s1);
+                    atomicAdd(&s_red[li * 2 + 1], (double)s2);
                 }
             }
         }
@@ -96,8 +96,8 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
             if (p.emode == 0) {
                 if (p.stats) {
                     const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + cb + tid) * 2;
-                    atomicAdd(&p.stats[so + 0], (double)s_red[tid * 2 + 0]);
-                    atomicAdd(&p.stats[so + 1], (double)s_red[tid * 2 + 1]);
+                    atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
                 }
             } else {
                 const int cch = cb + tid;
@@ -107,8 +107,8 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
                     const int cdd = cch - (dj ? p.c_split : 0);
                     const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
                     const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
-                    atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
-                    atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
+                    atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                    atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
                 }
             }
         }
@@ -123,13 +123,13 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
 // LDS-staged conv_epilogue above.  EP 1 = forward (+bias, BatchNorm sums), EP 2 = gradient into plain destinations.
 // s_epi: [NT] bias (EP 1) or [2][NT] producer scale / shift of the destination channels (EP 2), staged by the caller.
 template <typename T, int NB, int EP, int TS = 0>
-__device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&acc)[2][NB], float* s_red, const float* s_epi,
+__device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&acc)[2][NB], double* s_red, const float* s_epi,
                                                    int tid, int n, int g, int y0, int x0, int n0, int slot) {
     static_assert(sizeof(T) == 2 && (EP == 1 || EP == 2), "bf16, forward or plain-gradient");
     constexpr int S = 8, NT = NB * 32;
     const int lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
     const int H = p.H, W = p.W;
-    if (tid < NT * 2) s_red[tid] = 0.f;
+    if (tid < NT * 2) s_red[tid] = 0.0;
     __syncthreads();
     float sa[NB][2][S], sb[NB][2][S];
 #pragma unroll
@@ -208,8 +208,8 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
                 }
                 if (li == 0) {
                     const int cl = nb * 32 + 16 * v + 8 * h + e;
-                    atomicAdd(&s_red[cl * 2 + 0], a);
-                    atomicAdd(&s_red[cl * 2 + 1], b);
+                    atomicAdd(&s_red[cl * 2 + 0], (double)a);
+                    atomicAdd(&s_red[cl * 2 + 1], (double)b);
                 }
             }
     __syncthreads();
@@ -218,8 +218,8 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
         if constexpr (EP == 1) {
             if (p.stats) {
                 const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + cch) * 2;
-                atomicAdd(&p.stats[so + 0], (double)s_red[tid * 2 + 0]);
-                atomicAdd(&p.stats[so + 1], (double)s_red[tid * 2 + 1]);
+                atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
             }
         } else {
             const int dj = cch >= p.c_split ? 1 : 0;
@@ -227,8 +227,8 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
             if (dd.kind != RD_DST_NONE && dd.bstats) {
                 const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
                 const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cch - (dj ? p.c_split : 0)) * 2;
-                atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
-                atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
+                atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
             }
         }
     }

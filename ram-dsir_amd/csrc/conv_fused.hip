@@ -52,7 +52,7 @@ constexpr int FZ_PH = TH + 2, FZ_PW = TW + 2, FZ_NPIX = FZ_PH * FZ_PW;      // 1
 constexpr int FZ_IN_BYTES = FZ_NPIX * 64;                                    // one dz tile buffer
 constexpr int FZ_A_BYTES = TH * TW * 64;                                     // one `a` tile buffer
 constexpr int FZ_W_BYTES = 9 * 32 * 64;
-constexpr int FZ_LDS = 3 * FZ_IN_BYTES + 2 * FZ_A_BYTES + FZ_W_BYTES + (64 + 32 + 32) * 4;
+constexpr int FZ_LDS = 3 * FZ_IN_BYTES + 2 * FZ_A_BYTES + FZ_W_BYTES + 64 * 8 + (32 + 32) * 4;
 
 // xp: timing experiments of the debug build (RD_FZ_EXP bits; results are wrong when set): 1 no weight-gradient phase, 2 no dgrad MFMAs,
 // 4 no gradient stores, 8 loader issues no global loads, 16 no epilogue-operand loads, 32 no `a` tile writes
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
     char* s_inb = smem;                                                      // 3 x [NPIX][4 slots x 16 B]
     char* s_ab = smem + 3 * FZ_IN_BYTES;                                     // 2 x [256][4 x 16 B]
     uint4* s_w = reinterpret_cast<uint4*>(s_ab + 2 * FZ_A_BYTES);            // [9][32][4]
-    float* s_red = reinterpret_cast<float*>(reinterpret_cast<char*>(s_w) + FZ_W_BYTES);   // [32][2]
-    float* s_dsc = s_red + 64;                                               // [32] forward-input BN scale (1 for raw tensors)
+    double* s_red = reinterpret_cast<double*>(reinterpret_cast<char*>(s_w) + FZ_W_BYTES);   // [32][2], fp64 (conv_device.h flush_bstats)
+    float* s_dsc = reinterpret_cast<float*>(s_red + 64);                                              // [32] forward-input BN scale (1 for raw tensors)
     float* s_dsh = s_dsc + 32;                                               // [32] shift
 
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
             const int nn = rec % NT, tap = rec / NT;
             s_w[rec * 4 + (sw ^ ((nn >> 2) & 3))] = ld16(wbase + ((size_t)(tap * p.CoutPad + nn) * p.CinPad + sw * S));
         }
-        if (threadIdx.x < 64) s_red[threadIdx.x] = 0.f;
+        if (threadIdx.x < 64) s_red[threadIdx.x] = 0.0;
         if (threadIdx.x < 32) {
             const int c = threadIdx.x;
             const int dj = c >= p.c_split ? 1 : 0;
@@ -417,8 +417,8 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
                 const int cdd = tid - (dj ? p.c_split : 0);
                 const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
                 const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
-                atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
-                atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
+                atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
             }
         }
     }

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
     }
     __syncthreads();
     if constexpr (EP == 0) conv_epilogue<T, NB>(p, acc, smem, tid, n, g, y0, x0, n0, slot);
-    else conv_epilogue_lean<T, NB, EP, TS>(p, acc, reinterpret_cast<float*>(smem), s_epi, tid, n, g, y0, x0, n0, slot);
+    else conv_epilogue_lean<T, NB, EP, TS>(p, acc, reinterpret_cast<double*>(smem), s_epi, tid, n, g, y0, x0, n0, slot);
 }
 
 
@@ -225,7 +225,7 @@ inline size_t conv_pf_lds(const rd_conv_t& p) {
     constexpr int TH = TileGeo<TS>::H, TW = TileGeo<TS>::W;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
     size_t lds = (size_t)(PH * PW * 4 + TAPS * NB * 32 * 4) * sizeof(uint4) + (size_t)3 * p.CinPad * sizeof(float) + (size_t)2 * NB * 32 * sizeof(float);
-    const size_t lds_epi = (size_t)(TH * TW * 32 + 64) * sizeof(float);
+    const size_t lds_epi = (size_t)TH * TW * 32 * sizeof(float) + 64 * sizeof(double);
     return lds < lds_epi ? lds_epi : lds;
 }
 

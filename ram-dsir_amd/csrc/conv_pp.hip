@@ -37,7 +37,7 @@ constexpr int PP_PLANE_W = 9 * PP_NT * 16 + 32;
 constexpr int PP_IN_BYTES = 4 * PP_PLANE_A, PP_W_BYTES = 4 * PP_PLANE_W;
 constexpr int PP_W0 = 2 * PP_IN_BYTES;
 constexpr int PP_EPI = PP_W0 + 2 * PP_W_BYTES;
-constexpr int PP_EPI_BYTES = (TH * TW * 32 + 64) * 4;
+constexpr int PP_EPI_BYTES = TH * TW * 32 * 4 + 64 * 8;
 constexpr int PP_TAB = PP_EPI + PP_EPI_BYTES;
 constexpr int PP_MAX_CHUNKS = 16;                                          // CinPad <= 512
 constexpr int PP_LDS = PP_TAB + PP_MAX_CHUNKS * 4 * 48;                    // 154368 B of the CU's 160 KB

@@ -19,8 +19,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* s_in = reinterpret_cast<uint4*>(smem);          // [NPIX][4]
     uint4* s_w = s_in + NPIX * 4;                          // [TAPS][32][4]
-    float* s_red = reinterpret_cast<float*>(s_w + TAPS * NT * 4);   // [32][2]
-    float* s_dsc = s_red + 64;                             // [32] producer scale of the gradient destinations
+    double* s_red = reinterpret_cast<double*>(s_w + TAPS * NT * 4);  // [32][2], fp64: see conv_device.h flush_bstats
+    float* s_dsc = reinterpret_cast<float*>(s_red + 64);                             // [32] producer scale of the gradient destinations
     float* s_dsh = s_dsc + 32;                             // [32] producer shift
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
             if (idx < WTOT) s_w[rec * 4 + (sw ^ ((nn >> 2) & 3))] = wr[b];
         }
     }
-    if (tid < 64) s_red[tid] = 0.f;
+    if (tid < 64) s_red[tid] = 0.0;
     if constexpr (EPI > 0) {
         if (tid < 32) {
             const int dj = tid >= p.c_split ? 1 : 0;
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
         if constexpr (EPI == 0) {
             if (p.stats) {
                 const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + tid) * 2;
-                atomicAdd(&p.stats[so + 0], (double)s_red[tid * 2 + 0]);
-                atomicAdd(&p.stats[so + 1], (double)s_red[tid * 2 + 1]);
+                atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
             }
         } else {
             const int dj = tid >= p.c_split ? 1 : 0;
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
                 const int cdd = tid - (dj ? p.c_split : 0);
                 const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
                 const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
-                atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
-                atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
+                atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
             }
         }
     }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
     uint4* s_in = reinterpret_cast<uint4*>(smem);          // [PH*PW][4]
     uint4* s_w = s_in + PH * PW * 4;                       // [TAPS][32][4]
     float* s_out = reinterpret_cast<float*>(s_w + TAPS * NT * 4);   // [TH*TW][32]
-    float* s_red = s_out + TH * TW * 32;                   // [32][2]
+    double* s_red = reinterpret_cast<double*>(s_out + TH * TW * 32);   // [32][2]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
             if (idx < WTOT) s_w[rec * 4 + (sw ^ ((nn >> 2) & 3))] = wr[b];
         }
     }
-    if (tid < 64) s_red[tid] = 0.f;
+    if (tid < 64) s_red[tid] = 0.0;
 
     // ---- loader constants of this thread (its channel slot never changes)
     const int sslot = tid & 3;
@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (h == 0 && cok) {
-                atomicAdd(&s_red[li * 2 + 0], s1);
-                atomicAdd(&s_red[li * 2 + 1], s2);
+                atomicAdd(&s_red[li * 2 + 0], (double)s1);
+                atomicAdd(&s_red[li * 2 + 1], (double)s2);
             }
         }
     } else {
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
         if (p.emode == 0) {
             if (p.stats) {
                 const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + tid) * 2;
-                atomicAdd(&p.stats[so + 0], (double)s_red[tid * 2 + 0]);
-                atomicAdd(&p.stats[so + 1], (double)s_red[tid * 2 + 1]);
+                atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
             }
         } else {
             const int dj = tid >= p.c_split ? 1 : 0;
@@ -462,8 +462,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
                 const int cdd = tid - (dj ? p.c_split : 0);
                 const int gd = dd.g_fixed >= 0 ? dd.g_fixed : g;
                 const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * dd.Cd + cdd) * 2;
-                atomicAdd(&dd.bstats[so + 0], (double)s_red[tid * 2 + 0]);
-                atomicAdd(&dd.bstats[so + 1], (double)s_red[tid * 2 + 1]);
+                atomicAdd(&dd.bstats[so + 0], s_red[tid * 2 + 0]);
+                atomicAdd(&dd.bstats[so + 1], s_red[tid * 2 + 1]);
             }
         }
     }
@@ -475,7 +475,7 @@ int launch_conv_small(const rd_conv_t& p, hipStream_t st) {
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
     constexpr bool REG_EPI = !SRCG && EPI <= 1;            // register epilogue where it stays spill-free
     const size_t lds = (size_t)(PH * PW * 4 + TAPS * 32 * 4) * sizeof(uint4) +
-                       (REG_EPI ? (size_t)(64 + 64) * sizeof(float) : (size_t)(TH * TW * 32 + 64) * sizeof(float));
+                       (REG_EPI ? (size_t)64 * sizeof(double) + 64 * sizeof(float) : (size_t)TH * TW * 32 * sizeof(float) + 64 * sizeof(double));
     const int ntiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
     static int tpw_env = -1;
     if (tpw_env < 0) tpw_env = rd_switch("RD_TPW", 0);

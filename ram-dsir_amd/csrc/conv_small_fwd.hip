@@ -31,7 +31,7 @@ namespace {
 
 constexpr int SW_PH = TH + 2, SW_PW = TW + 2, SW_NPIX = SW_PH * SW_PW;      // 10 x 34 halo tile
 constexpr int SW_BUF_BYTES = SW_NPIX * 64 + 64;                             // + one dummy record (items that do not exist)
-constexpr int SW_LDS = 2 * SW_BUF_BYTES + (32 + 64) * 4;
+constexpr int SW_LDS = 2 * SW_BUF_BYTES + 64 * 8 + 32 * 4;
 constexpr int SW_NSET = 3;
 
 __device__ uint4 sw_trash[1024];                         // where the stores of lanes without an output pixel go
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     constexpr int NITV = (SW_NPIX * NSL + 511) / 512;    // loader items (halo pixel, live channel slot) per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_inb = smem;                                                      // 2 x [NPIX + 1][4 slots x 16 B]
-    float* s_bias = reinterpret_cast<float*>(smem + 2 * SW_BUF_BYTES);       // [32]
-    float* s_red = s_bias + 32;                                              // [32][2]
+    double* s_red = reinterpret_cast<double*>(smem + 2 * SW_BUF_BYTES);      // [32][2], fp64 (conv_device.h flush_bstats)
+    float* s_bias = reinterpret_cast<float*>(s_red + 64);                    // [32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;           // wave = tile row
     const int li = lane & 31, h = lane >> 5;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
         uint4* z4 = reinterpret_cast<uint4*>(smem);
         for (int i = tid; i < 2 * SW_BUF_BYTES / 16; i += 512) z4[i] = make_uint4(0, 0, 0, 0);
         if (tid < 32) s_bias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
-        if (tid < 64) s_red[tid] = 0.f;
+        if (tid < 64) s_red[tid] = 0.0;
     }
     // A operand of (tap, k-step): output channel li, input channels (2 ks + h) * 8 .. + 8
     uint4 wreg[9][NKS];
@@ -352,15 +352,15 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
                 b += __shfl_xor(b, o, 64);
             }
             if (li == 0) {
-                atomicAdd(&s_red[(16 * v + 8 * h + e) * 2 + 0], a);
-                atomicAdd(&s_red[(16 * v + 8 * h + e) * 2 + 1], b);
+                atomicAdd(&s_red[(16 * v + 8 * h + e) * 2 + 0], (double)a);
+                atomicAdd(&s_red[(16 * v + 8 * h + e) * 2 + 1], (double)b);
             }
         }
     __syncthreads();
     if (tid < 32 && tid < p.Cout && p.stats) {
         const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + tid) * 2;
-        atomicAdd(&p.stats[so + 0], (double)s_red[tid * 2 + 0]);
-        atomicAdd(&p.stats[so + 1], (double)s_red[tid * 2 + 1]);
+        atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
+        atomicAdd(&p.stats[so + 1], s_red[tid * 2 + 1]);
     }
 }
 

@@ -214,7 +214,60 @@ def test_step_bf16_loss_band_and_graph_replay(golden_dir):
     np.testing.assert_allclose(got2, got, rtol=1e-2)
     assert int(ts2.iter) == 1
     rel = float((bank2.params - bank.params).abs().max())
-    assert rel < 5e-3            # Adam moves every weight by ~lr; eager and replay agree up to atomics order
+    assert rel < 5e-3            # Adam moves every weight by ~lr; eager (lane budgets) and replay (none) group the per-workgroup sums differently
+
+
+@pytest.mark.parametrize('dtype,dataset,bs,S', [(torch.float32, 'fundus', [2, 3, 3], 128), (torch.bfloat16, 'fundus', [2, 3, 3], 400),
+                                                (torch.bfloat16, 'prostate', [2, 2, 2, 2, 2], 384)])
+def test_step_is_bitwise_reproducible(dtype, dataset, bs, S):
+    """The same parameters, optimizer state and inputs give the same BITS, run after run, on three streams: every reduction whose
+    order depends on timing (waves arriving at a workgroup's BatchNorm sums, workgroups arriving at the statistic slots) accumulates
+    fp32 terms in fp64, where the sum is exact and therefore order-independent (csrc/conv_device.h flush_bstats); the weight-gradient
+    splits are summed in a fixed order.  Reference: train.py:608-614 (--deterministic gives cuDNN-deterministic runs there).
+    Before this held (round 2) two identical fp32 runs differed by up to 8e-3 in a gradient tensor, bf16 runs by 13 %."""
+    torch.manual_seed(0)
+    B = sum(bs)
+    bank, mods = S_.make_bank(DEV, 3, 16, 2, len(bs))
+    g = torch.Generator().manual_seed(1)
+    for (m, k), (off, shape) in bank.index.items():
+        v = bank.p(m, k)
+        if len(shape) == 4:
+            v.copy_((torch.randn(shape, generator=g) * (2.0 / (shape[0] * shape[2] * shape[3])) ** 0.5).to(DEV))
+        elif '.bn' in k and k.endswith('weight'):
+            v.fill_(1.0)
+    ts = S_.TrainStep(bank, mods, dtype, bs, S, S, dataset=dataset, consistency='kd', lr=1e-3, total_iters=100, ram=True)
+    ts.wpack.refresh()
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    if dataset == 'fundus':
+        src = torch.rand(B, S, S, 3, device=DEV, generator=gen) * 255
+        trg = torch.rand(B, S, S, 3, device=DEV, generator=gen) * 255
+        tgt = (torch.rand(B, 2, S, S, device=DEV, generator=gen) > 0.5).float()
+    else:
+        src = torch.rand(B, S, S, 3, device=DEV, generator=gen) * 2 - 1
+        trg = torch.rand(B, S, S, 3, device=DEV, generator=gen) * 2 - 1
+        tgt = (torch.rand(B, S, S, device=DEV, generator=gen) > 0.7).long()
+    lam = torch.tensor([0.1 * (1 + i % 9) for i in range(B)], device=DEV)
+    ts.load_raw(src, trg, lam)
+    ts.load_target(tgt)
+    ts.step()                                                        # away from the initial state (Adam moments, running statistics)
+    torch.cuda.synchronize()
+    saved = ts._snapshot()
+    runs = []
+    for _ in range(3):
+        ts._restore(saved)
+        ts.load_raw(src, trg, lam)
+        ts.load_target(tgt)
+        ts.step()
+        ts.step()                                                    # two steps: the second one starts from the first one's bits
+        torch.cuda.synchronize()
+        runs.append((bank.grads.clone(), bank.params.clone(), ts.losses.clone(), ts.rec_mse.clone(),
+                     {k: v.clone() for k, v in bank.buffers.items()}))
+    for r in runs[1:]:
+        for a, b in zip(r[:4], runs[0][:4]):
+            assert torch.equal(a, b)
+        for k in r[4]:
+            assert torch.equal(r[4][k], runs[0][4][k]), k
+    assert float(runs[0][0].abs().max()) > 0 and torch.isfinite(runs[0][0]).all()
 
 
 @pytest.mark.parametrize('dataset,bs,S', [('fundus', [2, 3, 3], 400), ('prostate', [2, 2, 2, 2, 2], 384), ('fundus', [2, 2, 2, 2], 512)])
