@@ -26,7 +26,7 @@ extern "C" {
 
 #define RD_F32 0
 #define RD_BF16 1
-#define RD_MAX_GROUPS_C 8
+#define RD_MAX_GROUPS_C 16
 /* BatchNorm sums are accumulated with atomics; to keep thousands of workgroups off the same few addresses
  * every statistics buffer has RD_STAT_SLOTS copies, [G][RD_STAT_SLOTS][C][2]; a workgroup adds into slot
  * (its tile index mod RD_STAT_SLOTS) and the finalize kernels sum the slots.
@@ -204,8 +204,23 @@ typedef struct {
     float* P; float* Q; float* R;     /* [G][C] out */
     float count[RD_MAX_GROUPS_C];
     int32_t C, G;
+    /* rd_gn_finalize_bwd only (NULL / ignored for BatchNorm, where the bias of a conv in front of the normalisation has an identically
+     * zero gradient): GroupNorm pools the mean over the channels, so the conv bias has a gradient, sum over the pixels of dz =
+     * P * sum g + Q * sum z + R * count, formed here from the forward sums */
+    const double* fstats;   /* [G][RD_STAT_SLOTS][C][2] the forward statistics of this site */
+    const float* conv_bias; /* [C] as in rd_bn_fwd_t (NULL: the forward sums already contain it) */
+    float* dbias;           /* [C] += */
 } rd_bn_bwd_t;
 int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream);
+
+/* nn.GroupNorm(1, planes) (code/networks/unet.py:20-21, normalization(norm='gn')): every image is its own group (gstart = 0, 1, .., N;
+ * N <= RD_MAX_GROUPS_C), mean / variance pooled over (C, H, W) of the image; the descriptors and outputs are those of the BatchNorm
+ * finalize launches above (running-statistics pointers are ignored, `training` is irrelevant: the statistics are always the input's),
+ * gamma / beta / dgamma / dbeta of group 0 are the layer's (shared by all images; dgamma / dbeta += in image order).
+ * nn.InstanceNorm2d (unet.py:22-23, norm='in') needs no entry point of its own: rd_bn_finalize_fwd / _bwd with one group per image,
+ * gamma -> ones, beta -> zeros, running_* = num_batches_tracked = dgamma = dbeta = NULL, training = 1. */
+int rd_gn_finalize_fwd(const rd_bn_fwd_t* p, void* stream);
+int rd_gn_finalize_bwd(const rd_bn_bwd_t* p, void* stream);
 
 /* statistics of y = bilinear_x2(t) (nn.Upsample(scale_factor=2, 'bilinear', align_corners=False),
  * unet.py:84): stats[G][slot][C][2] += (sum y, sum y^2) (each thread sums deviations from the first value it sees and

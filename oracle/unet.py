@@ -81,9 +81,15 @@ def _conv_entry(sd, name, cin, cout, k, gen):
     sd[name + '.bias'] = b
 
 
-def _bn_entry(sd, name, c):
+def _bn_entry(sd, name, c, norm='bn'):
+    """normalization(planes, norm) (unet.py:17-28): 'bn' nn.BatchNorm2d, 'gn' nn.GroupNorm(1, planes) (weight, bias only), 'in'
+    nn.InstanceNorm2d(planes) (no state at all)."""
+    if norm == 'in':
+        return
     sd[name + '.weight'] = torch.ones(c)
     sd[name + '.bias'] = torch.zeros(c)
+    if norm == 'gn':
+        return
     sd[name + '.running_mean'] = torch.zeros(c)
     sd[name + '.running_var'] = torch.ones(c)
     sd[name + '.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
@@ -97,7 +103,7 @@ def _norm_entry(sd, name, c, num_domains):
             _bn_entry(sd, '%s.bns.%d' % (name, d), c)
 
 
-def encoder_state(c=3, n=16, seed=0):
+def encoder_state(c=3, n=16, seed=0, norm='bn'):
     gen = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     chans = [c, n, 2 * n, 4 * n, 8 * n, 16 * n]
@@ -106,22 +112,22 @@ def encoder_state(c=3, n=16, seed=0):
         cin, co = chans[l - 1], chans[l]
         for j, ci in ((1, cin), (2, co), (3, co)):
             _conv_entry(sd, '%s.conv%d' % (p, j), ci, co, 3, gen)
-            _bn_entry(sd, '%s.bn%d' % (p, j), co)
+            _bn_entry(sd, '%s.bn%d' % (p, j), co, norm)
     return sd
 
 
-def decoder_state(n=16, num_classes=2, seed=1):
+def decoder_state(n=16, num_classes=2, seed=1, norm='bn'):
     gen = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     for l, planes, first in ((4, 16 * n, True), (3, 8 * n, False), (2, 4 * n, False), (1, 2 * n, False)):
         p = 'convu%d' % l
         if not first:
             _conv_entry(sd, p + '.conv1', 2 * planes, planes, 3, gen)
-            _bn_entry(sd, p + '.bn1', planes)
+            _bn_entry(sd, p + '.bn1', planes, norm)
         _conv_entry(sd, p + '.conv2', planes, planes // 2, 1, gen)
-        _bn_entry(sd, p + '.bn2', planes // 2)
+        _bn_entry(sd, p + '.bn2', planes // 2, norm)
         _conv_entry(sd, p + '.conv3', planes, planes, 3, gen)
-        _bn_entry(sd, p + '.bn3', planes)
+        _bn_entry(sd, p + '.bn3', planes, norm)
     _conv_entry(sd, 'out1', 2 * n, num_classes, 3, gen)
     return sd
 
@@ -164,6 +170,13 @@ def _bn(x, sd, name, training, domain=None, stats_from_stored=False):
     momentum 0.1) or DomainSpecificBatchNorm2d with ``domain`` = domain_label[0] (dsbn.py:26)."""
     if domain is not None:
         name = '%s.bns.%d' % (name, int(domain))
+    if name + '.running_mean' not in sd:
+        # what the state holds says which normalization() this is: weight + bias only = nn.GroupNorm(1, planes) (unet.py:20-21),
+        # nothing = nn.InstanceNorm2d(planes) (unet.py:22-23); both normalise with the statistics of the input in train and eval mode
+        assert ROUND is None, 'the bf16 rounding model covers bn / dsbn only'
+        if name + '.weight' in sd:
+            return F.group_norm(x, 1, sd[name + '.weight'], sd[name + '.bias'], EPS)
+        return F.instance_norm(x, eps=EPS)
     if training:
         sd[name + '.num_batches_tracked'] += 1
     if ROUND is not None:

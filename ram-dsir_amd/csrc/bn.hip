@@ -130,6 +130,115 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_bwd_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------ GroupNorm(1, C)
+// nn.GroupNorm(1, planes) (code/networks/unet.py:20-21: ONE group = all channels of a sample): every image is its own statistics
+// group g (the launch lists are built with gstart = 0, 1, ..., N), and what differs from BatchNorm is only which sums are pooled:
+// mean / variance over (C, H, W) of the image.  Same descriptor, same outputs as the BatchNorm finalize kernels (per-(group, channel)
+// scale / shift, resp. the P, Q, R of dz = P*g + Q*z + R), so every conv / weight-gradient kernel is unchanged.
+// (nn.InstanceNorm2d = BatchNorm statistics per (image, channel) without affine or running statistics: the BatchNorm kernels with one
+// group per image, gamma = 1, beta = 0 and null running-statistics pointers.)
+__device__ __forceinline__ double block_sum_d(double v, double* s_tmp) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += s_tmp[i];      // fixed order
+    return r;
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(const rd_bn_fwd_t p) {
+    __shared__ double s_tmp[4];
+    const int g = blockIdx.x;
+    const double cnt = (double)p.count[g];                  // pixels per channel of this image
+    double S1 = 0.0, S2 = 0.0;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < RD_STAT_SLOTS; ++k) {
+            s1 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
+            s2 += p.stats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
+        }
+        const double b = p.conv_bias ? (double)p.conv_bias[c] : 0.0;   // the sums are those of (conv result - bias)
+        S1 += s1 + cnt * b;
+        S2 += s2 + 2.0 * b * s1 + cnt * b * b;
+    }
+    S1 = block_sum_d(S1, s_tmp);
+    S2 = block_sum_d(S2, s_tmp);
+    const double n = cnt * (double)p.C;
+    const double m = S1 / n;
+    double vard = S2 / n - m * m;
+    if (vard < 0.0) vard = 0.0;
+    const float mean = (float)m, invstd = 1.0f / sqrtf((float)vard + p.eps);
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        const float sc = p.gamma[g][c] * invstd;
+        p.scale[g * p.C + c] = sc;
+        p.shift[g * p.C + c] = p.beta[g][c] - mean * sc;
+        p.mean[g * p.C + c] = mean;
+        p.invstd[g * p.C + c] = invstd;
+    }
+}
+
+// one workgroup walks the images in order, so that dgamma / dbeta (shared by all images) accumulate in a fixed order
+__global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(const rd_bn_bwd_t p) {
+    __shared__ double s_tmp[4];
+    constexpr int CPT = 4;                                  // channels per thread: C <= 1024
+    float dg[CPT], db[CPT], dcb[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) dg[j] = db[j] = dcb[j] = 0.f;
+    for (int g = 0; g < p.G; ++g) {
+        const float mu = p.mean[g * p.C], is = p.invstd[g * p.C];          // the same for every channel of the image
+        double b1[CPT], b2[CPT];
+        double A = 0.0, B = 0.0;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = threadIdx.x + j * blockDim.x;
+            b1[j] = b2[j] = 0.0;
+            if (c < p.C) {
+                for (int k = 0; k < RD_STAT_SLOTS; ++k) {
+                    b1[j] += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
+                    b2[j] += p.bstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 1];
+                }
+                const double gam = (double)p.gamma[g][c];
+                b2[j] = (double)is * (b2[j] - (double)mu * b1[j]);     // sum over the pixels of g * zhat, channel c
+                A += gam * b1[j];
+                B += gam * b2[j];
+            }
+        }
+        A = block_sum_d(A, s_tmp);
+        B = block_sum_d(B, s_tmp);
+        const double n = (double)p.count[g] * (double)p.C;
+        const float Q = (float)(-(double)is * (double)is * B / n);
+        const float R = (float)(-(double)is * A / n) - Q * mu;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = threadIdx.x + j * blockDim.x;
+            if (c < p.C) {
+                const float P = p.gamma[g][c] * is;
+                p.P[g * p.C + c] = P;
+                p.Q[g * p.C + c] = Q;
+                p.R[g * p.C + c] = R;
+                dg[j] += (float)b2[j];
+                db[j] += (float)b1[j];
+                if (p.dbias) {                                  // sum over the pixels of dz = P g + Q z + R
+                    double sz = 0.0;
+                    for (int k = 0; k < RD_STAT_SLOTS; ++k) sz += p.fstats[((size_t)(g * RD_STAT_SLOTS + k) * p.C + c) * 2 + 0];
+                    if (p.conv_bias) sz += (double)p.count[g] * (double)p.conv_bias[c];
+                    dcb[j] += (float)((double)P * b1[j] + (double)Q * sz + (double)R * (double)p.count[g]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = threadIdx.x + j * blockDim.x;
+        if (c < p.C) {
+            if (p.dgamma[0]) p.dgamma[0][c] += dg[j];
+            if (p.dbeta[0]) p.dbeta[0][c] += db[j];
+            if (p.dbias) p.dbias[c] += dcb[j];
+        }
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void ldv(const T* p, float* f) {
     Slot<T>::unpack(*reinterpret_cast<const uint4*>(p), f);
@@ -627,6 +736,18 @@ int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream) {
 int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
     if (!p || p->G < 1 || p->G > RD_MAX_GROUPS) return -1;
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(p->C), dim3(64 * p->G), 0, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+
+int rd_gn_finalize_fwd(const rd_bn_fwd_t* p, void* stream) {
+    if (!p || p->G < 1 || p->G > RD_MAX_GROUPS || p->C < 1) return -1;
+    hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(p->G), dim3(256), 0, (hipStream_t)stream, *p);
+    return (int)hipGetLastError();
+}
+
+int rd_gn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
+    if (!p || p->G < 1 || p->G > RD_MAX_GROUPS || p->C < 1 || p->C > 1024) return -1;
+    hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 

@@ -9,7 +9,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-#define RD_MAX_GROUPS 8
+#define RD_MAX_GROUPS 16
 
 #define RD_CHECK(expr)                                                                      \
     do {                                                                                    \

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libramdsir_hip_dbg.so' if os.environ.get('RAMDSIR_DEBUG_LIB') == '1' else 'libramdsir_hip.so')
 
 RD_F32, RD_BF16 = 0, 1
-MAXG = 8
+MAXG = 16
 STAT_SLOTS = 64
 SRC_RAW, SRC_AFF, SRC_AFFACT, SRC_POOL, SRC_UP, SRC_BNBWD = range(6)
 DST_PLAIN, DST_POOL, DST_UPY, DST_NONE = range(4)
@@ -49,7 +49,8 @@ class RdBnFwd(C.Structure):
 
 class RdBnBwd(C.Structure):
     _fields_ = [('bstats', fp), ('mean', fp), ('invstd', fp), ('gamma', fp * MAXG), ('dgamma', fp * MAXG),
-                ('dbeta', fp * MAXG), ('P', fp), ('Q', fp), ('R', fp), ('count', f32 * MAXG), ('C', i32), ('G', i32)]
+                ('dbeta', fp * MAXG), ('P', fp), ('Q', fp), ('R', fp), ('count', f32 * MAXG), ('C', i32), ('G', i32),
+                ('fstats', fp), ('conv_bias', fp), ('dbias', fp)]
 
 
 class RdSegLoss(C.Structure):
@@ -94,6 +95,8 @@ _SIGS = {
     'rd_packed_elems': (i64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'rd_bn_finalize_fwd': (C.c_int, [C.POINTER(RdBnFwd), vp]),
     'rd_bn_finalize_bwd': (C.c_int, [C.POINTER(RdBnBwd), vp]),
+    'rd_gn_finalize_fwd': (C.c_int, [C.POINTER(RdBnFwd), vp]),
+    'rd_gn_finalize_bwd': (C.c_int, [C.POINTER(RdBnBwd), vp]),
     'rd_bn_apply': (C.c_int, [vp, vp, vp, fp, fp, fp, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
     'rd_up_stats': (C.c_int, [vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
     'rd_bn_stats': (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),

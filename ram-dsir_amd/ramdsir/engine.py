@@ -41,9 +41,15 @@ def _conv_spec(out, name, cin, cout, k):
     out.append((name + '.bias', (cout,), 'param', torch.float32))
 
 
-def _bn_spec(out, name, c):
+def _bn_spec(out, name, c, norm='bn'):
+    """state_dict entries of one normalization(planes, norm) site (unet.py:17-28): nn.BatchNorm2d has weight, bias and three buffers,
+    nn.GroupNorm(1, planes) weight and bias, nn.InstanceNorm2d(planes) (affine=False, no running statistics) nothing."""
+    if norm == 'in':
+        return
     out.append((name + '.weight', (c,), 'param', torch.float32))
     out.append((name + '.bias', (c,), 'param', torch.float32))
+    if norm == 'gn':
+        return
     out.append((name + '.running_mean', (c,), 'buffer', torch.float32))
     out.append((name + '.running_var', (c,), 'buffer', torch.float32))
     out.append((name + '.num_batches_tracked', (), 'buffer', torch.int64))
@@ -57,25 +63,25 @@ def _norm_spec(out, name, c, num_domains):
             _bn_spec(out, '%s.bns.%d' % (name, d), c)
 
 
-def convd_specs(cin, cout, prefix='', out=None):
+def convd_specs(cin, cout, prefix='', out=None, norm='bn'):
     """networks.unet.ConvD (unet.py:32-50): conv1,bn1,conv2,bn2,conv3,bn3.  prefix '' = the block on its own."""
     out = [] if out is None else out
     for j, ci in ((1, cin), (2, cout), (3, cout)):
         _conv_spec(out, '%sconv%d' % (prefix, j), ci, cout, 3)
-        _bn_spec(out, '%sbn%d' % (prefix, j), cout)
+        _bn_spec(out, '%sbn%d' % (prefix, j), cout, norm)
     return out
 
 
-def convu_specs(planes, first, prefix='', out=None):
+def convu_specs(planes, first, prefix='', out=None, norm='bn'):
     """networks.unet.ConvU (unet.py:75-94)."""
     out = [] if out is None else out
     if not first:
         _conv_spec(out, prefix + 'conv1', 2 * planes, planes, 3)
-        _bn_spec(out, prefix + 'bn1', planes)
+        _bn_spec(out, prefix + 'bn1', planes, norm)
     _conv_spec(out, prefix + 'conv2', planes, planes // 2, 1)
-    _bn_spec(out, prefix + 'bn2', planes // 2)
+    _bn_spec(out, prefix + 'bn2', planes // 2, norm)
     _conv_spec(out, prefix + 'conv3', planes, planes, 3)
-    _bn_spec(out, prefix + 'bn3', planes)
+    _bn_spec(out, prefix + 'bn3', planes, norm)
     return out
 
 
@@ -92,20 +98,20 @@ def convu_rec_specs(planes, num_domains, prefix='', out=None):
     return out
 
 
-def encoder_specs(c=3, n=16):
-    """state_dict layout of networks.unet.Encoder (unet.py:248-255): 105 entries at n=16."""
+def encoder_specs(c=3, n=16, norm='bn'):
+    """state_dict layout of networks.unet.Encoder (unet.py:248-255): 105 entries at n=16 (norm='bn')."""
     out = []
     ch = [c, n, 2 * n, 4 * n, 8 * n, 16 * n]
     for l in range(1, 6):
-        convd_specs(ch[l - 1], ch[l], 'convd%d.' % l, out)
+        convd_specs(ch[l - 1], ch[l], 'convd%d.' % l, out, norm)
     return out
 
 
-def decoder_specs(n=16, num_classes=2):
+def decoder_specs(n=16, num_classes=2, norm='bn'):
     """networks.unet.Decoder (unet.py:273-281)."""
     out = []
     for l, planes, first in ((4, 16 * n, True), (3, 8 * n, False), (2, 4 * n, False), (1, 2 * n, False)):
-        convu_specs(planes, first, 'convu%d.' % l, out)
+        convu_specs(planes, first, 'convu%d.' % l, out, norm)
     _conv_spec(out, 'out1', 2 * n, num_classes, 3)
     return out
 
@@ -183,9 +189,13 @@ class Norm:
     """One normalisation site: per-group parameter views (DSBN: one BN per group; shared BN: the same
     views in every group)."""
 
-    def __init__(self, bank, mname, name, groups_to_domain=None):
+    def __init__(self, bank, mname, name, groups_to_domain=None, kind='bn'):
         self.bank, self.mname, self.name = bank, mname, name
         self.groups_to_domain = groups_to_domain      # None: plain BN shared by all groups
+        # 'bn': BatchNorm statistics per group of images; 'gn' / 'in' (unet.py:20-23): the plan has ONE GROUP PER IMAGE and the
+        # statistics are pooled over (C, H, W) resp. (H, W) of the image -- rd_gn_finalize_* resp. rd_bn_finalize_* with constant
+        # gamma = 1 / beta = 0; neither has running statistics, 'in' has no parameters at all
+        self.kind = kind
 
     def key(self, g, leaf):
         if self.groups_to_domain is None:
@@ -200,6 +210,19 @@ class Norm:
 
     def buf(self, g, leaf):
         return self.bank.b(self.mname, self.key(g, leaf))
+
+    # device pointers for the finalize descriptors (None where the normalisation has no such tensor)
+    def gamma_ptr(self, plan, g, C):
+        return plan.const_f32(1.0, C).data_ptr() if self.kind == 'in' else self.param(g, 'weight').data_ptr()
+
+    def beta_ptr(self, plan, g, C):
+        return plan.const_f32(0.0, C).data_ptr() if self.kind == 'in' else self.param(g, 'bias').data_ptr()
+
+    def buf_ptr(self, g, leaf):
+        return self.buf(g, leaf).data_ptr() if self.kind == 'bn' else None
+
+    def grad_ptr(self, g, leaf):
+        return None if self.kind == 'in' else self.grad(g, leaf).data_ptr()
 
 
 class Act:
@@ -280,9 +303,18 @@ class Plan:
         self._stat_chunks = []
         self.fwd, self.bwd = [], []
         self.ws_bytes = 0
+        if self.G > L.MAXG:
+            raise ValueError('%d statistics groups (gn / in: one per image), the kernels take at most %d' % (self.G, L.MAXG))
         self.gs_arr = L.gstart_array(self.gstart)
+        self._consts = {}
 
     # ---- allocation
+    def const_f32(self, value, n):
+        key = (float(value), int(n))
+        if key not in self._consts:
+            self._consts[key] = torch.full((n,), float(value), dtype=torch.float32, device=self.device)
+        return self._consts[key]
+
     def alloc_act(self, shape):
         t = torch.zeros(shape, dtype=self.dtype, device=self.device)
         self.keep.append(t)
@@ -430,17 +462,21 @@ class Plan:
                 b.conv_bias = None if o.up else self.bank.p(node.mname, node.name + '.bias').data_ptr()
                 b.scale, b.shift, b.mean, b.invstd = o.scale.data_ptr(), o.shift.data_ptr(), o.mean.data_ptr(), o.invstd.data_ptr()
                 hw = (4 if o.up else 1) * H * W
+                kind = o.norm.kind
+                if kind != 'bn' and any(self.gstart[g + 1] - self.gstart[g] != 1 for g in range(self.G)):
+                    raise ValueError('norm=%r needs a launch plan with one statistics group per image (gstart = 0..N)' % kind)
                 for g in range(self.G):
-                    b.gamma[g] = o.norm.param(g, 'weight').data_ptr()
-                    b.beta[g] = o.norm.param(g, 'bias').data_ptr()
-                    b.running_mean[g] = o.norm.buf(g, 'running_mean').data_ptr()
-                    b.running_var[g] = o.norm.buf(g, 'running_var').data_ptr()
-                    b.num_batches_tracked[g] = o.norm.buf(g, 'num_batches_tracked').data_ptr()
+                    b.gamma[g] = o.norm.gamma_ptr(self, g, o.C)
+                    b.beta[g] = o.norm.beta_ptr(self, g, o.C)
+                    b.running_mean[g] = o.norm.buf_ptr(g, 'running_mean')
+                    b.running_var[g] = o.norm.buf_ptr(g, 'running_var')
+                    b.num_batches_tracked[g] = o.norm.buf_ptr(g, 'num_batches_tracked')
                     b.count[g] = float((self.gstart[g + 1] - self.gstart[g]) * hw)
-                b.C, b.G, b.eps, b.momentum, b.training = o.C, self.G, EPS, MOMENTUM, 1 if self.training else 0
+                # gn / in always normalise with the statistics of the input itself (nn.GroupNorm / nn.InstanceNorm2d in eval mode too)
+                b.C, b.G, b.eps, b.momentum, b.training = o.C, self.G, EPS, MOMENTUM, 1 if (self.training or kind != 'bn') else 0
                 self.keep.append(b)
                 o.bn_desc = b
-                self.fwd.append((lib.rd_bn_finalize_fwd, (C.byref(b),)))
+                self.fwd.append((lib.rd_gn_finalize_fwd if kind == 'gn' else lib.rd_bn_finalize_fwd, (C.byref(b),)))
                 if o.a_buf is not None:
                     src = o.y_buf if o.up else o.buf
                     Hh, Ww = (2 * H, 2 * W) if o.up else (H, W)
@@ -474,13 +510,17 @@ class Plan:
                 q.P, q.Q, q.R = o.P.data_ptr(), o.Q.data_ptr(), o.R.data_ptr()
                 hw = (4 if o.up else 1) * H * W
                 for g in range(self.G):
-                    q.gamma[g] = o.norm.param(g, 'weight').data_ptr()
-                    q.dgamma[g] = o.norm.grad(g, 'weight').data_ptr()
-                    q.dbeta[g] = o.norm.grad(g, 'bias').data_ptr()
+                    q.gamma[g] = o.norm.gamma_ptr(self, g, o.C)
+                    q.dgamma[g] = o.norm.grad_ptr(g, 'weight')
+                    q.dbeta[g] = o.norm.grad_ptr(g, 'bias')
                     q.count[g] = float((self.gstart[g + 1] - self.gstart[g]) * hw)
                 q.C, q.G = o.C, self.G
+                if o.norm.kind == 'gn':                        # GroupNorm: the conv bias in front of it has a gradient (ramdsir.h)
+                    q.fstats = o.plan.stat_ptr(o.stats)
+                    q.conv_bias = None if o.up else self.bank.p(node.mname, node.name + '.bias').data_ptr()
+                    q.dbias = self.bank.g(node.mname, node.name + '.bias').data_ptr()
                 self.keep.append(q)
-                self.bwd.append((lib.rd_bn_finalize_bwd, (C.byref(q),)))
+                self.bwd.append((lib.rd_gn_finalize_bwd if o.norm.kind == 'gn' else lib.rd_bn_finalize_bwd, (C.byref(q),)))
                 if (not o.up and self.materialize_dz_min_c is not None and o.C >= self.materialize_dz_min_c):
                     o.dz_buf = self.alloc_act((N, H, W, o.C))
                     self.bwd.append((lib.rd_bn_apply, (o.grad_buf().data_ptr(), o.buf.data_ptr(), o.dz_buf.data_ptr(), o.P.data_ptr(),
@@ -750,22 +790,22 @@ class WeightPack:
 
 
 # ------------------------------------------------------------------------------------------------ network builders
-def build_convd(plan, x, mode, cout, prefix, mname):
+def build_convd(plan, x, mode, cout, prefix, mname, norm='bn'):
     """ConvD.forward (unet.py:52-72): [maxpool] conv3-bn / conv3-bn-act / conv3-bn-act.  x: source Act read in `mode`
     (RD_SRC_POOL = the 2x2 max-pool of levels 2-5 fused into the read).  Returns the Act of conv3 (BN3+act pending)."""
     bank = plan.bank
     H, W = (x.H // 2, x.W // 2) if mode == L.SRC_POOL else (x.H, x.W)
-    z1 = plan.conv(mname, prefix + 'conv1', [(x, mode, 0, -1)], cout, 9, Norm(bank, mname, prefix + 'bn1'), act=False, H=H, W=W)
-    z2 = plan.conv(mname, prefix + 'conv2', [(z1, L.SRC_AFF, 0, -1)], cout, 9, Norm(bank, mname, prefix + 'bn2'), act=True, H=H, W=W)
-    return plan.conv(mname, prefix + 'conv3', [(z2, L.SRC_AFFACT, 0, -1)], cout, 9, Norm(bank, mname, prefix + 'bn3'), act=True, H=H, W=W)
+    z1 = plan.conv(mname, prefix + 'conv1', [(x, mode, 0, -1)], cout, 9, Norm(bank, mname, prefix + 'bn1', kind=norm), act=False, H=H, W=W)
+    z2 = plan.conv(mname, prefix + 'conv2', [(z1, L.SRC_AFF, 0, -1)], cout, 9, Norm(bank, mname, prefix + 'bn2', kind=norm), act=True, H=H, W=W)
+    return plan.conv(mname, prefix + 'conv3', [(z2, L.SRC_AFFACT, 0, -1)], cout, 9, Norm(bank, mname, prefix + 'bn3', kind=norm), act=True, H=H, W=W)
 
 
-def build_encoder(plan, x_act, n=16, mname='enc'):
+def build_encoder(plan, x_act, n=16, mname='enc', norm='bn'):
     """Encoder.forward (unet.py:264-271).  x_act: Act of the image batch (no norm).  Returns [z3_1..z3_5]."""
     feats = []
     prev, prev_mode = x_act, L.SRC_RAW
     for l in range(1, 6):
-        z3 = build_convd(plan, prev, prev_mode, n * (1 << (l - 1)), 'convd%d.' % l, mname)
+        z3 = build_convd(plan, prev, prev_mode, n * (1 << (l - 1)), 'convd%d.' % l, mname, norm)
         feats.append(z3)
         prev, prev_mode = z3, L.SRC_POOL
     return feats
@@ -775,25 +815,25 @@ def _feat_mode(a):
     return L.SRC_AFFACT if a.norm is not None else L.SRC_RAW
 
 
-def build_convu(plan, x, skip, planes, first, prefix, mname):
+def build_convu(plan, x, skip, planes, first, prefix, mname, norm='bn'):
     """ConvU.forward (unet.py:96-117): [conv3-bn-act] up2 conv1-bn-act cat[skip, .] conv3-bn-act."""
     bank = plan.bank
     if not first:
-        x = plan.conv(mname, prefix + 'conv1', [(x, _feat_mode(x), 0, -1)], planes, 9, Norm(bank, mname, prefix + 'bn1'), act=True,
+        x = plan.conv(mname, prefix + 'conv1', [(x, _feat_mode(x), 0, -1)], planes, 9, Norm(bank, mname, prefix + 'bn1', kind=norm), act=True,
                       H=x.H, W=x.W)
     # 1x1 conv below the upsample (commutes with bilinear interpolation); BN2 statistics on up(t)
-    t = plan.conv(mname, prefix + 'conv2', [(x, _feat_mode(x), 0, -1)], planes // 2, 1, Norm(bank, mname, prefix + 'bn2'), act=True,
+    t = plan.conv(mname, prefix + 'conv2', [(x, _feat_mode(x), 0, -1)], planes // 2, 1, Norm(bank, mname, prefix + 'bn2', kind=norm), act=True,
                   up_out=True, H=x.H, W=x.W)
     return plan.conv(mname, prefix + 'conv3', [(skip, _feat_mode(skip), 0, -1), (t, L.SRC_UP, 0, -1)], planes, 9,
-                     Norm(bank, mname, prefix + 'bn3'), act=True, H=skip.H, W=skip.W)
+                     Norm(bank, mname, prefix + 'bn3', kind=norm), act=True, H=skip.H, W=skip.W)
 
 
-def build_decoder(plan, feats, n=16, num_classes=2, mname='dec'):
+def build_decoder(plan, feats, n=16, num_classes=2, mname='dec', norm='bn'):
     """Decoder.forward (unet.py:290-296).  feats: 5 Acts (raw+pending BN, or materialised RAW inputs)."""
     x = feats[4]
     for l, planes, first, skip in ((4, 16 * n, True, feats[3]), (3, 8 * n, False, feats[2]), (2, 4 * n, False, feats[1]),
                                    (1, 2 * n, False, feats[0])):
-        x = build_convu(plan, x, skip, planes, first, 'convu%d.' % l, mname)
+        x = build_convu(plan, x, skip, planes, first, 'convu%d.' % l, mname, norm)
     return plan.conv(mname, 'out1', [(x, L.SRC_AFFACT, 0, -1)], num_classes, 9, None, H=x.H, W=x.W)
 
 

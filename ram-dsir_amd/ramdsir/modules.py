@@ -41,6 +41,32 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         return BatchNormFn.apply(x, self.weight, self.bias, self)
 
 
+class FusedGroupNorm(nn.GroupNorm):
+    """The nn.GroupNorm(1, planes) slot of normalization(planes, 'gn') (code/networks/unet.py:20-21): holds weight / bias under the
+    reference's state_dict keys; the arithmetic runs inside the launch list of the parent block (one statistics group per image,
+    rd_gn_finalize_fwd / _bwd)."""
+
+    def forward(self, x):
+        raise NotImplementedError('this GroupNorm is executed inside the fused HIP graph of its parent module')
+
+
+class FusedInstanceNorm2d(nn.InstanceNorm2d):
+    """The nn.InstanceNorm2d(planes) slot of normalization(planes, 'in') (unet.py:22-23; affine=False, no running statistics: no
+    state_dict entries); runs inside the parent block's launch list as BatchNorm statistics with one group per image."""
+
+    def forward(self, x):
+        raise NotImplementedError('this InstanceNorm is executed inside the fused HIP graph of its parent module')
+
+
+def group_starts(norm, N):
+    """gstart of a module-level launch plan: one BatchNorm group for the whole batch, one group per image for gn / in."""
+    if norm in ('gn', 'in'):
+        if N > L.MAXG:
+            raise ValueError('norm=%r keeps one statistics group per image: at most %d images per call, got %d' % (norm, L.MAXG, N))
+        return list(range(N + 1))
+    return [0, N]
+
+
 class BatchNormFn(torch.autograd.Function):
     """Standalone BatchNorm2d forward/backward on the HIP kernels (one group: the whole batch shares the statistics)."""
 
@@ -171,7 +197,7 @@ class FusedModule(nn.Module):
             self._plans = {}
 
     def _bn_training(self):
-        flags = [m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        flags = [m.training for m in self.modules() if isinstance(m, (nn.BatchNorm2d, nn.GroupNorm, nn.InstanceNorm2d))]
         return any(flags)
 
     def _acquire_plan(self, key, builder):

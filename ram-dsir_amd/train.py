@@ -226,6 +226,11 @@ def main(args):
             max_len, max_id = len(dl), idx
     loaders[max_id] = raw[max_id]
 
+    if args.norm != 'bn':
+        # gn / in exist in the drop-in modules (networks/unet.py: a reference-style loop over Encoder / Decoder works with them), but the
+        # FUSED step below keeps the statistics groups of the shared BatchNorms and of the restoration decoder's DSBN in one launch list
+        raise NotImplementedError('train.py runs the fused HIP step, which implements --norm bn (dsbn in the restoration decoder); '
+                                  'norm=%r is available through the modules of networks/unet.py' % args.norm)
     encoder = Encoder(c=args.in_channels, norm=args.norm, activation=args.activation).cuda()
     seg_decoder = Decoder(num_classes=args.num_classes, norm=args.norm, activation=args.activation).cuda()
     rec_decoder = Rec_Decoder(num_classes=args.in_channels, norm='dsbn', activation=args.activation,

@@ -162,6 +162,49 @@ def gen_modules(RU):
     print('state_manifest.json')
 
 
+def gen_modules_norm(RU):
+    """normalization(planes, 'gn' / 'in') (unet.py:20-23): the reference's Encoder + Decoder built with --norm gn / in, train-mode
+    forward and backward (nn.GroupNorm / nn.InstanceNorm2d behave the same in eval mode), non-trivial affine for gn."""
+    out = {}
+    B, S = 3, 32
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(B, 3, S, S, generator=g)
+    out['x'] = x.numpy()
+    for norm in ('gn', 'in'):
+        enc_sd, dec_sd = OU.encoder_state(n=8, seed=20, norm=norm), OU.decoder_state(n=8, seed=21, norm=norm)
+        for sd in (enc_sd, dec_sd):
+            for k in sd:
+                if ('.bn' in k) and k.endswith('.weight'):
+                    sd[k] = 1.0 + 0.2 * torch.randn(sd[k].shape, generator=g)
+                if ('.bn' in k) and k.endswith('.bias'):
+                    sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        out['%s.chk.enc' % norm], out['%s.chk.dec' % norm] = state_checksum(enc_sd), state_checksum(dec_sd)
+        for nm, sd in (('enc', enc_sd), ('dec', dec_sd)):
+            for k, v in sd.items():
+                if '.bn' in k:
+                    out['%s.sd.%s.%s' % (norm, nm, k)] = v.numpy().copy()
+        enc = load_ref(RU.Encoder(n=8, norm=norm), OU.clone_state(enc_sd))
+        dec = load_ref(RU.Decoder(n=8, num_classes=2, norm=norm), OU.clone_state(dec_sd))
+        enc.train(); dec.train()
+        xin = x.clone().requires_grad_(True)
+        feats = enc(xin)
+        logits = dec(feats)
+        for i, f in enumerate(feats):
+            out['%s.feat%d' % (norm, i + 1)] = f.detach().numpy()
+        out['%s.logits' % norm] = logits.detach().numpy()
+        wl = torch.randn(logits.shape, generator=g)
+        wf = torch.randn(feats[2].shape, generator=g)                     # a second consumer of an encoder feature
+        out['%s.wl' % norm], out['%s.wf' % norm] = wl.numpy(), wf.numpy()
+        ((logits * wl).sum() + (feats[2] * wf).sum()).backward()
+        out['%s.dx' % norm] = xin.grad.numpy()
+        pack_grads('%s.genc' % norm, [(k, p.grad) for k, p in enc.named_parameters()], out, full_limit=1 << 14)
+        pack_grads('%s.gdec' % norm, [(k, p.grad) for k, p in dec.named_parameters()], out, full_limit=1 << 14)
+        out['%s.keys.enc' % norm] = np.array(list(enc.state_dict().keys()))
+        out['%s.keys.dec' % norm] = np.array(list(dec.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, 'modules_norm.npz'), **out)
+    print('modules_norm.npz', len(out), 'arrays')
+
+
 # ------------------------------------------------------------------------------------------ single blocks
 def gen_blocks(RU):
     """ConvD / ConvU / ConvU_Rec forward + backward on tiny shapes (module-local goldens, weights stored)."""
@@ -541,7 +584,7 @@ def gen_metrics(ref_root):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
-    ap.add_argument('--only', default='', help='comma list of fixture groups (ram,masks,losses,blocks,modules,steps,steps64,sampling,metrics,dsbn)')
+    ap.add_argument('--only', default='', help='comma list of fixture groups (ram,masks,losses,blocks,modules,modules_norm,steps,steps64,sampling,metrics,dsbn)')
     args = ap.parse_args()
     only = set(filter(None, args.only.split(',')))
     sys.path.insert(0, os.path.join(args.ref, 'code'))
@@ -562,6 +605,8 @@ def main():
         gen_blocks(RU)
     if want('modules'):
         gen_modules(RU)
+    if want('modules_norm'):
+        gen_modules_norm(RU)
     if want('steps') or want('steps64'):
         gen_steps(RU, ref_losses, only64=not want('steps'))
     if want('sampling'):

@@ -67,3 +67,14 @@ def bn_shadowed_bias(key):
 def assert_noise_level(g, weight_sig, name=''):
     wrms = np.sqrt(weight_sig[2] / max(weight_sig[3], 1))
     assert float(g.detach().abs().max()) <= 1e-3 * (wrms + 1.0) + 1e-6, name
+
+
+def modules_norm_states(M, norm):
+    """The states tests/golden/make_golden.py:gen_modules_norm loaded into the reference's Encoder(n=8, norm) / Decoder(n=8, norm):
+    generated conv weights (same seeds), the affine parameters of the fixture."""
+    enc_sd, dec_sd = OU.encoder_state(n=8, seed=20, norm=norm), OU.decoder_state(n=8, seed=21, norm=norm)
+    for nm, sd in (('enc', enc_sd), ('dec', dec_sd)):
+        for k in sd:
+            if '.bn' in k:
+                sd[k] = torch.from_numpy(M['%s.sd.%s.%s' % (norm, nm, k)]).clone()
+    return enc_sd, dec_sd

@@ -63,6 +63,9 @@ class _pfx(dict):
     def __setitem__(self, k, v):
         self.sd[k[2:]] = v
 
+    def __contains__(self, k):
+        return k[2:] in self.sd
+
 
 def test_convu_blocks(B):
     _run_block(B, 'convu_first', lambda i, sd: OU.convu(i[0], i[1], _pfx(sd), 'm', True, True))
