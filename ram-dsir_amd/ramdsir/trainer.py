@@ -69,3 +69,74 @@ class FusedTrainer:
 
     def lr(self):
         return float(self.ts.hyper[0])
+
+
+class ModuleTrainer:
+    """The reference's own training step (code/train.py:246-296 fundus, 412-465 prostate) over the drop-in modules of networks/unet.py
+    -- torch autograd between the modules, torch's losses and torch.optim.Adam, the poly schedule of train.py:289-293 -- with the
+    FusedTrainer interface.  train.py takes this path for --norm gn / in: the fused step keeps the statistics groups of the shared
+    BatchNorms and of the restoration decoder's DSBN in one launch list and implements `bn` only, the modules implement all of
+    normalization().  The convolutions / normalisations are the HIP launch lists of the modules, RAM is rd_ram_mix; single process."""
+
+    def __init__(self, encoder, seg_decoder, rec_decoder, batch_sizes, H, W, dataset='fundus', consistency='kd', lambda_rec=0.1,
+                 lr=2e-3, total_iters=1, dtype=torch.bfloat16, **_):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            raise NotImplementedError('norm gn / in: the module-level training loop runs in one process (no gradient exchange)')
+        from torch.optim import Adam
+        self.enc, self.dec, self.rec = encoder, seg_decoder, rec_decoder
+        self.bs, self.dataset, self.cons, self.lambda_rec = list(batch_sizes), dataset, consistency, lambda_rec
+        self.base_lr, self.total_iters, self.iter_num = lr, total_iters, 0
+        self.num_classes = seg_decoder._k
+        self.opt = Adam([{'params': encoder.parameters(), 'lr': lr / 2}, {'params': seg_decoder.parameters(), 'lr': lr},
+                         {'params': rec_decoder.parameters(), 'lr': lr}], lr=lr, betas=(0.9, 0.999))                 # train.py:573-576
+        self._last = None
+
+    def step(self, src_nhwc, trg_nhwc, lam, target):
+        import torch.nn.functional as F
+        from ramdsir.ram import source_to_target_freq_batch
+        from utils.losses import dice_loss, dice_loss_multi
+        img, img_freq = source_to_target_freq_batch(src_nhwc, trg_nhwc, lam, self.dataset)
+        fundus = self.dataset == 'fundus'
+
+        def seg(feats):
+            logits = self.dec(feats)
+            if fundus:
+                soft = torch.sigmoid(logits)
+                return soft, F.binary_cross_entropy(soft, target), dice_loss(soft, target)
+            soft = torch.softmax(logits, dim=1)
+            return soft, F.cross_entropy(logits, target), dice_loss_multi(soft, target, num_classes=self.num_classes, ignore_index=0)
+
+        soft1, seg1, dice1 = seg(self.enc(img))
+        feats2 = self.enc(img_freq)
+        soft2, seg2, dice2 = seg(feats2)
+        zero = torch.zeros((), device=img.device)
+        if self.cons == 'kd':                                                                   # train.py:85-88 KD(pred_soft_2, pred_soft_1)
+            consistency = F.kl_div(soft2.log(), soft1, reduction='mean') + F.kl_div(soft1.log(), soft2, reduction='mean')
+        elif self.cons == 'mse':
+            consistency = F.mse_loss(soft2, soft1)
+        else:
+            consistency = zero
+        loss, left, rec_l = 0, 0, []
+        for d, b in enumerate(self.bs):                                                         # train.py:265-276
+            rec_soft = torch.tanh(self.rec(feats2[-1][left:left + b], domain_label=d * torch.ones(b, dtype=torch.long)))
+            l = F.mse_loss(rec_soft, img[left:left + b])
+            loss = loss + self.lambda_rec * l
+            rec_l.append(l)
+            left += b
+        loss = loss + seg1 + seg2 + dice1 + dice2 + 0.5 * consistency
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        lr = self.base_lr * (1 - self.iter_num / self.total_iters) ** 0.9                       # train.py:289-293
+        self.opt.param_groups[0]['lr'], self.opt.param_groups[1]['lr'], self.opt.param_groups[2]['lr'] = lr / 2, lr, lr
+        self.iter_num += 1
+        self._last = (seg1, dice1, seg2, dice2, consistency, loss, rec_l)
+
+    def losses(self):
+        seg1, dice1, seg2, dice2, cons, loss, rec_l = self._last
+        s = 'bce' if self.dataset == 'fundus' else 'ce'
+        return {'loss_%s_1' % s: float(seg1), 'loss_dice_1': float(dice1), 'loss_%s_2' % s: float(seg2), 'loss_dice_2': float(dice2),
+                'loss_consistency': float(cons), 'rec': [float(r) for r in rec_l], 'loss': float(loss)}
+
+    def lr(self):
+        return float(self.opt.param_groups[1]['lr'])

@@ -226,11 +226,6 @@ def main(args):
             max_len, max_id = len(dl), idx
     loaders[max_id] = raw[max_id]
 
-    if args.norm != 'bn':
-        # gn / in exist in the drop-in modules (networks/unet.py: a reference-style loop over Encoder / Decoder works with them), but the
-        # FUSED step below keeps the statistics groups of the shared BatchNorms and of the restoration decoder's DSBN in one launch list
-        raise NotImplementedError('train.py runs the fused HIP step, which implements --norm bn (dsbn in the restoration decoder); '
-                                  'norm=%r is available through the modules of networks/unet.py' % args.norm)
     encoder = Encoder(c=args.in_channels, norm=args.norm, activation=args.activation).cuda()
     seg_decoder = Decoder(num_classes=args.num_classes, norm=args.norm, activation=args.activation).cuda()
     rec_decoder = Rec_Decoder(num_classes=args.in_channels, norm='dsbn', activation=args.activation,
@@ -239,13 +234,18 @@ def main(args):
     print('\nSeg Decoder Params: %.3fM' % count_params(seg_decoder))
     print('\nRec Decoder Params: %.3fM' % count_params(rec_decoder))
 
-    from ramdsir.trainer import FusedTrainer
+    from ramdsir.trainer import FusedTrainer, ModuleTrainer
     sample = next(iter(raw[0]))
     H, W = sample[0].shape[1:3]
     total_iters = max_len * args.epochs
     cons = args.consistency_type if args.consistency else None
     assert cons in (None, 'mse', 'kd'), args.consistency_type
-    trainer = FusedTrainer(encoder, seg_decoder, rec_decoder, bsl[:len(domain_idx_list)], H, W, dataset=args.dataset,
+    # --norm bn (the reference's default): the fused HIP step.  gn / in: the reference's own loop over the drop-in modules (the fused step
+    # keeps the statistics groups of the shared BatchNorms and of the restoration decoder's DSBN in one launch list: bn only)
+    Trainer = FusedTrainer if args.norm == 'bn' else ModuleTrainer
+    if args.norm != 'bn' and rank == 0:
+        print('norm=%s: module-level training loop (torch autograd between the HIP modules)' % args.norm)
+    trainer = Trainer(encoder, seg_decoder, rec_decoder, bsl[:len(domain_idx_list)], H, W, dataset=args.dataset,
                            consistency=cons, lambda_rec=args.lambda_rec, lr=args.lr, total_iters=total_iters,
                            dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
 
