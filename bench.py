@@ -42,6 +42,7 @@ FAMILIES = {
 }
 DOMINANT = 'wgrad'
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_COPY_GBS = 5300.0                    # what a plain torch copy (read + write) sustains on this part: profiles/r03_hbm_ceiling.txt
 MFMA_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF (no sparsity)
 
 
@@ -133,7 +134,8 @@ def kernel_roofline(ts, fam, eager=True):
     if intensity >= ridge:
         out = dict(bound='mfma', achieved=round(tfs, 1), peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tfs / MFMA_PEAK_TFLOPS, 4))
     else:
-        out = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
+        out = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
+                   frac_of_copy_rate=round(gbs / HBM_COPY_GBS, 4))    # beside the spec: the rate streaming kernels reach in practice
     out.update(traffic=traffic, traffic_source=traffic_source, kernel=family, family=fam, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
                avg_algorithmic_bytes=int(nbytes / n), avg_flops=int(flops / n), flop_per_byte=round(intensity, 1),
                achieved_gbs=round(gbs, 1), achieved_tflops=round(tfs, 1))
