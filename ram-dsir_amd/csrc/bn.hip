@@ -18,6 +18,13 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_fwd_kernel(con
     __shared__ float s_mean[RD_MAX_GROUPS], s_unb[RD_MAX_GROUPS], s_rm[RD_MAX_GROUPS], s_rv[RD_MAX_GROUPS];
     const int c = blockIdx.x, lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the counters thread 0 of channel 0 bumps at the very end are requested NOW, beside the statistics loads: read there they would be a
+    // second memory round trip at the tail of the one workgroup every launch waits for (38 launches: 302 -> 270 us alone)
+    long long nbt_v[RD_MAX_GROUPS];
+    if (c == 0 && threadIdx.x == 0 && p.training) {
+#pragma unroll
+        for (int i = 0; i < RD_MAX_GROUPS; ++i) nbt_v[i] = (i < p.G && p.num_batches_tracked[i]) ? *p.num_batches_tracked[i] : 0;
+    }
     double s1 = 0.0, s2 = 0.0;
     if (p.training) {
         for (int k = lane; k < RD_STAT_SLOTS; k += 64) {
@@ -77,7 +84,10 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_fwd_kernel(con
             if (!first) continue;
             int n = 0;
             for (int j = i; j < p.G; ++j) n += p.num_batches_tracked[j] == p.num_batches_tracked[i] ? 1 : 0;
-            *p.num_batches_tracked[i] += n;
+            long long v = 0;
+#pragma unroll
+            for (int j = 0; j < RD_MAX_GROUPS; ++j) v = j == i ? nbt_v[j] : v;       // static indexing: nbt_v stays in registers
+            *p.num_batches_tracked[i] = v + n;
         }
     }
 }
@@ -106,28 +116,25 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_bwd_kernel(con
         s_s1[g] = s1; s_s2[g] = s2;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    // dgamma / dbeta: groups on one BatchNorm add into the same element, in group order
-    for (int i = 0; i < p.G; ++i) {
-        if (p.dgamma[i]) {
-            bool first = true;
-            for (int j = 0; j < i; ++j) first = first && p.dgamma[j] != p.dgamma[i];
-            if (first) {
-                float v = p.dgamma[i][c];
-                for (int j = i; j < p.G; ++j) if (p.dgamma[j] == p.dgamma[i]) v += s_s2[j];
-                p.dgamma[i][c] = v;
-            }
-        }
-        if (p.dbeta[i]) {
-            bool first = true;
-            for (int j = 0; j < i; ++j) first = first && p.dbeta[j] != p.dbeta[i];
-            if (first) {
-                float v = p.dbeta[i][c];
-                for (int j = i; j < p.G; ++j) if (p.dbeta[j] == p.dbeta[i]) v += s_s1[j];
-                p.dbeta[i][c] = v;
-            }
-        }
+    // dgamma / dbeta: groups on one BatchNorm add into the same element, in group order.  Lane i handles group i (the first group of
+    // every distinct pointer writes): the two read-modify-writes of a lane have both loads in flight together -- thread 0 walking the
+    // groups made two dependent memory round trips at the tail of every workgroup
+    if ((int)threadIdx.x >= p.G) return;
+    const int i = threadIdx.x;
+    float* dgp = p.dgamma[i];
+    float* dbp = p.dbeta[i];
+    bool fg = dgp != nullptr, fb = dbp != nullptr;
+    for (int j = 0; j < i; ++j) {
+        fg = fg && p.dgamma[j] != dgp;
+        fb = fb && p.dbeta[j] != dbp;
     }
+    float a = fg ? dgp[c] : 0.f, b = fb ? dbp[c] : 0.f;
+    for (int j = i; j < p.G; ++j) {
+        if (p.dgamma[j] == dgp) a += s_s2[j];
+        if (p.dbeta[j] == dbp) b += s_s1[j];
+    }
+    if (fg) dgp[c] = a;
+    if (fb) dbp[c] = b;
 }
 
 // ------------------------------------------------------------------------------------ GroupNorm(1, C)
