@@ -104,6 +104,10 @@ typedef struct {
     int32_t cu_limit;    /* >0: compute-unit budget of the launch where the kernel is persistent (the small-channel kernel, the
                           * warp-specialised 64-wide kernel): a conv of a side lane leaves the rest of the GPU to the main
                           * chain; 0: the whole device */
+    int32_t w_tap_rows;  /* rows per tap of the packed array `w` points into when that is MORE than CoutPad: a launch over a 32-row
+                          * block of a wider pack (w = pack + first_row * CK elements; honoured by the small-channel kernels, which is
+                          * where such launches go); 0: CoutPad */
+    int32_t pad_;
 } rd_conv_t;
 
 int rd_conv(const rd_conv_t* p, int dtype, void* stream);

@@ -118,6 +118,7 @@ int rd_conv(const rd_conv_t* p, int dtype, void* stream) {
     const int ck = dtype == RD_BF16 ? 32 : 16;
     if (p->CinPad % ck || p->CoutPad % 32 || p->CinPad < p->Cin || p->CoutPad < p->Cout) return -2;
     hipStream_t st = (hipStream_t)stream;
+    if (p->w_tap_rows && !(p->CinPad == ck && p->CoutPad == 32 && p->emode == 1 && p->w_tap_rows >= p->CoutPad)) return -2;   // ramdsir.h
     if (p->CinPad == ck && p->CoutPad == 32) return rd_conv_small_dispatch(*p, dtype, st);   // one K chunk, one N block
     return rd_conv_big_dispatch(*p, dtype, st);
 }

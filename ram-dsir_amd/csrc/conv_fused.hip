@@ -432,6 +432,7 @@ inline bool aligned16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 bool rd_bwd_fused_ok(const rd_conv_t& p, const rd_wgrad_t& w, int dtype) {
     if (dtype != RD_BF16 || rd_switch("RD_FUSED_BWD", 1) == 0) return false;
     if (p.taps != 9 || w.taps != 9 || p.emode != 1 || p.nsrc != 1) return false;
+    if (p.w_tap_rows) return false;                        // a launch over a row block of a wider pack: conv_small_kernel only
     if (p.CinPad != 32 || p.CoutPad != 32 || p.Cin > 32 || p.Cout > 32) return false;
     const rd_src_t& s = p.src[0];
     if (!(s.mode == RD_SRC_RAW || s.mode == RD_SRC_BNBWD) || s.C % 8 || s.C < p.Cin || !aligned16(s.ptr)) return false;

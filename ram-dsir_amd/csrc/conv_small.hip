@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
             const int idx = tid + b * 256;
             const int sw = idx & 3, rec = idx >> 2;
             const int nn = rec % NT, tap = rec / NT;
-            wr[b] = ld16(wbase + ((size_t)(min(tap, TAPS - 1) * p.CoutPad + nn) * p.CinPad + sw * S));
+            wr[b] = ld16(wbase + ((size_t)(min(tap, TAPS - 1) * (p.w_tap_rows ? p.w_tap_rows : p.CoutPad) + nn) * p.CinPad + sw * S));
         }
 #pragma unroll
         for (int b = 0; b < WIT; ++b) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
             const int idx = tid + b * 256;
             const int sw = idx & 3, rec = idx >> 2;
             const int nn = rec % NT, tap = rec / NT;
-            wr[b] = ld16(wbase + ((size_t)(min(tap, TAPS - 1) * p.CoutPad + nn) * p.CinPad + sw * S));
+            wr[b] = ld16(wbase + ((size_t)(min(tap, TAPS - 1) * (p.w_tap_rows ? p.w_tap_rows : p.CoutPad) + nn) * p.CinPad + sw * S));
         }
 #pragma unroll
         for (int b = 0; b < WIT; ++b) {

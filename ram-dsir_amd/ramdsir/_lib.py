@@ -31,7 +31,7 @@ class RdConv(C.Structure):
     _fields_ = [('src', RdSrc * 2), ('nsrc', i32), ('taps', i32), ('w', vp), ('bias', fp), ('CinPad', i32),
                 ('CoutPad', i32), ('N', i32), ('H', i32), ('W', i32), ('Cin', i32), ('Cout', i32), ('G', i32),
                 ('gstart', i32 * (MAXG + 1)), ('emode', i32), ('out', vp), ('stats', fp), ('dst', RdDst * 2),
-                ('c_split', i32), ('cu_limit', i32)]
+                ('c_split', i32), ('cu_limit', i32), ('w_tap_rows', i32), ('pad_', i32)]
 
 
 class RdWgrad(C.Structure):

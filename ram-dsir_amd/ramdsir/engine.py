@@ -297,6 +297,7 @@ class Plan:
         self.materialize_min_c = None   # channels from which BN+ReLU outputs are stored once (rd_bn_apply)
         self.materialize_dz_min_c = None  # ... and from which the BN-backward gradients dz are
         self.fused_bwd = bool(T.options()['fused_bwd'])   # small-channel 3x3 convs: dgrad + weight gradient in one launch
+        self.split_wide_dgrad = bool(T.options()['split_wide_dgrad'])   # _dgrad_halves below
         self._unit = {}
         self.nodes = []
         self.keep = []
@@ -615,8 +616,44 @@ class Plan:
                 self.bwd.append((lib.rd_colsum, (o.grad_buf().data_ptr(), self.bank.g(node.mname, node.name + '.bias').data_ptr(),
                                                  node.bias_ws.data_ptr(), N * H * W, o.C, o.gCs, 0.0, dt), node.side_meta[-1]))
             if p is not None and not node.fused:
-                self.bwd.append((lib.rd_conv, (C.byref(p), dt), dmeta))
+                halves = self._dgrad_halves(p) if self.split_wide_dgrad else None
+                if halves is not None:
+                    for q in halves:
+                        self.bwd.append((lib.rd_conv, (C.byref(q), dt), dict(dmeta, kernel='conv_small_kernel<bf16,9,*>', bytes=dmeta['bytes'] // 2,
+                                                                               flops=dmeta['flops'] // 2)))
+                else:
+                    self.bwd.append((lib.rd_conv, (C.byref(p), dt), dmeta))
         self.ws_bytes = ws_need
+
+    def _dgrad_halves(self, p):
+        """A gradient launch with ONE input chunk (<= 32 channels of dz) and 33..64 output channels into one plain tensor -- in the
+        U-Net: dec.convu1.conv1 -- as TWO launches of the small-channel kernel over the 32-channel halves of the output (each reads
+        dz in full): the generic 64-wide path runs it as a one-chunk K loop per workgroup with nothing to pipeline (155 us against
+        ~2 x 50).  The halves point into the same packed weights (rd_conv_t.w_tap_rows).  None when the launch does not qualify."""
+        if self.dtype != torch.bfloat16 or p.taps != 9 or p.CinPad != 32 or p.CoutPad != 64 or p.Cout <= 32:
+            return None
+        d = p.dst[0]
+        if p.dst[1].kind != L.DST_NONE or d.kind != L.DST_PLAIN or p.c_split < p.Cout or d.Cd % 8 or d.Cd < p.Cout:
+            return None
+        esz, out = 2, []
+        for k in range(2):
+            q = L.RdConv()
+            C.memmove(C.byref(q), C.byref(p), C.sizeof(L.RdConv))
+            q.Cout, q.CoutPad, q.c_split = min(32, p.Cout - 32 * k), 32, min(32, p.Cout - 32 * k)
+            q.w_tap_rows = p.CoutPad
+            q.w = p.w + 32 * k * p.CinPad * esz                    # rows 32k.. of every tap: [chunk][tap][CoutPad][CK]
+            dd = q.dst[0]
+            off = 32 * k
+            dd.g = d.g + off * esz
+            if d.z:
+                dd.z = d.z + off * esz
+            if d.scale:
+                dd.scale, dd.shift = d.scale + 4 * off, d.shift + 4 * off   # fp32 [G][Cd]: the channel offset inside a row
+            if d.bstats:
+                dd.bstats = d.bstats + 16 * off                            # fp64 [G][slots][Cd][2]
+            self.keep.append(q)
+            out.append(q)
+        return out
 
     def _conv_meta(self, node, N, H, W, Cin, Cout, what):
         """Which conv_kernel instantiation a launch uses and its ALGORITHMIC bytes: the logical input read

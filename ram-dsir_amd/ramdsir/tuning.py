@@ -9,6 +9,7 @@ DEFAULTS = dict(
     mat_dz_min_c=64,      # store the BN-backward gradient dz once for layers with at least this many channels
     pool_mat=True,        # store the 2x2 max-pool in front of ConvD levels 2-5 once (rd_pool_fwd / rd_pool_bwd)
     fused_bwd=True,       # <= 32-channel 3x3 convs (bf16): dgrad + weight gradient in one launch (csrc/conv_fused.hip)
+    split_wide_dgrad=True,  # a one-chunk gradient launch with 33..64 output channels as two launches of the small-channel kernel
     side_streams=1,       # HIP streams for the weight-gradient launches
     rec_cus=-1,           # compute units the restoration-decoder lane's persistent launches may take (0: all, -1: half of
                           # the device = 128 on MI355X, where the numbers below were measured); the lane ends
@@ -25,7 +26,7 @@ DEFAULTS = dict(
                           # multi-GPU node either way -- SCALE_r0x were skipped -- hence selectable)
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
 )
-_ENV = dict(mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
+_ENV = dict(split_wide_dgrad='RD_SPLIT_WIDE_DGRAD', mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
             ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', rec_lane='RD_REC_LANE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
 
 

@@ -134,6 +134,25 @@ GRAD_CASES = [
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', GRAD_CASES, ids=[c[0] for c in GRAD_CASES])
 def test_conv_gradient_epilogues(case, dtype):
+    _run_gradient_case(case, dtype, False)
+
+
+ROW_BLOCK_CASES = [
+    # one input chunk (<= 32 channels of dz) -> 33..64 channels of one plain tensor, launched as the engine launches dec.convu1.conv1's
+    # dgrad: two launches over the 32-row blocks of the packed weights (rd_conv_t.w_tap_rows)
+    ('plain64_from32_40x70', 9, [(L.DST_PLAIN, 64, 1)], 32, 2, 40, 70, [0, 1, 2], 0.0, 0),
+    ('plain48_from24_33x50_acc', 9, [(L.DST_PLAIN, 48, 1)], 24, 2, 33, 50, [0, 2], 0.0, 1),
+    ('plain64_noact_from16_20x36', 9, [(L.DST_PLAIN, 64, 0)], 16, 3, 20, 36, [0, 1, 3], 0.0, 0),
+]
+
+
+@pytest.mark.parametrize('halves', [False, True], ids=['one_launch', 'row_blocks'])
+@pytest.mark.parametrize('case', ROW_BLOCK_CASES, ids=[c[0] for c in ROW_BLOCK_CASES])
+def test_conv_gradient_over_row_blocks_of_the_packed_weights(case, halves):
+    _run_gradient_case(case, 'bf16', halves)
+
+
+def _run_gradient_case(case, dtype, halves):
     name, taps, dst_spec, Cout, N, H, W, gstart, slope, accumulate = case
     gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000 + 1)
     keep = U.Keep()
@@ -176,7 +195,24 @@ def test_conv_gradient_epilogues(case, dtype):
         outs.append((gbuf, bst, old))
     if len(dst_spec) == 1:
         p.dst[1].kind = L.DST_NONE
-    L.check(L.lib().rd_conv(C.byref(p), U.DT[dtype][0], None), name)
+    if halves:
+        assert len(dst_spec) == 1 and p.CinPad == 32 and p.CoutPad == 64
+        d0 = p.dst[0]
+        for kb in range(2):
+            q = L.RdConv()
+            C.memmove(C.byref(q), C.byref(p), C.sizeof(L.RdConv))
+            q.Cout = q.c_split = min(32, p.Cout - 32 * kb)
+            q.CoutPad, q.w_tap_rows = 32, p.CoutPad
+            q.w = p.w + 32 * kb * p.CinPad * 2
+            q.dst[0].g, q.dst[0].z = d0.g + 64 * kb, d0.z + 64 * kb
+            q.dst[0].scale, q.dst[0].shift, q.dst[0].bstats = d0.scale + 128 * kb, d0.shift + 128 * kb, d0.bstats + 512 * kb
+            L.check(L.lib().rd_conv(C.byref(q), U.DT[dtype][0], None), name + '.rows%d' % kb)
+        bad = L.RdConv()
+        C.memmove(C.byref(bad), C.byref(p), C.sizeof(L.RdConv))
+        bad.w_tap_rows = 64                                   # only 32-row launches of the small-channel class may carry it
+        assert L.lib().rd_conv(C.byref(bad), U.DT[dtype][0], None) == -2
+    else:
+        L.check(L.lib().rd_conv(C.byref(p), U.DT[dtype][0], None), name)
     torch.cuda.synchronize()
     for i, (kind, Cd, act) in enumerate(dst_spec):
         gbuf, bst, old = outs[i]
