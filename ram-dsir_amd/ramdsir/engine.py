@@ -619,7 +619,7 @@ class Plan:
                 halves = self._dgrad_halves(p) if self.split_wide_dgrad else None
                 if halves is not None:
                     for q in halves:
-                        self.bwd.append((lib.rd_conv, (C.byref(q), dt), dict(dmeta, kernel='conv_small_kernel<bf16,9,*>', bytes=dmeta['bytes'] // 2,
+                        self.bwd.append((lib.rd_conv, (C.byref(q), dt), dict(dmeta, kernel='conv_small_kernel<bf16,%d,*>' % p.taps, bytes=dmeta['bytes'] // 2,
                                                                                flops=dmeta['flops'] // 2)))
                 else:
                     self.bwd.append((lib.rd_conv, (C.byref(p), dt), dmeta))
@@ -630,7 +630,7 @@ class Plan:
         U-Net: dec.convu1.conv1 -- as TWO launches of the small-channel kernel over the 32-channel halves of the output (each reads
         dz in full): the generic 64-wide path runs it as a one-chunk K loop per workgroup with nothing to pipeline (155 us against
         ~2 x 50).  The halves point into the same packed weights (rd_conv_t.w_tap_rows).  None when the launch does not qualify."""
-        if self.dtype != torch.bfloat16 or p.taps != 9 or p.CinPad != 32 or p.CoutPad != 64 or p.Cout <= 32:
+        if self.dtype != torch.bfloat16 or p.CinPad != 32 or p.CoutPad != 64 or p.Cout <= 32:
             return None
         d = p.dst[0]
         if p.dst[1].kind != L.DST_NONE or d.kind != L.DST_PLAIN or p.c_split < p.Cout or d.Cd % 8 or d.Cd < p.Cout:

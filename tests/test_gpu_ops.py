@@ -143,6 +143,7 @@ ROW_BLOCK_CASES = [
     ('plain64_from32_40x70', 9, [(L.DST_PLAIN, 64, 1)], 32, 2, 40, 70, [0, 1, 2], 0.0, 0),
     ('plain48_from24_33x50_acc', 9, [(L.DST_PLAIN, 48, 1)], 24, 2, 33, 50, [0, 2], 0.0, 1),
     ('plain64_noact_from16_20x36', 9, [(L.DST_PLAIN, 64, 0)], 16, 3, 20, 36, [0, 1, 3], 0.0, 0),
+    ('k1_plain64_from32_30x44', 1, [(L.DST_PLAIN, 64, 1)], 32, 2, 30, 44, [0, 1, 2], 0.0, 0),
 ]
 
 
