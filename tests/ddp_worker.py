@@ -23,11 +23,19 @@ def main():
     ap.add_argument('--port', type=int, required=True)
     ap.add_argument('--graph', type=int, default=0)
     ap.add_argument('--size', type=int, default=64)
+    ap.add_argument('--backend', default='gloo', choices=['gloo', 'nccl'])
     args = ap.parse_args()
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(args.port))
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group('gloo', rank=args.rank, world_size=args.world)
+    if args.backend == 'nccl':
+        # RCCL: one rank per device (world 1 on a one-GPU box, rank r on cuda:r otherwise) -- the asynchronous AVG branch of
+        # ramdsir.ddp.Buckets, which gloo never takes
+        dev = torch.device('cuda', args.rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group('nccl', rank=args.rank, world_size=args.world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=args.rank, world_size=args.world)
     import fullsize_util as FU
     from ramdsir import step as S, ddp as D
     cfg = dict(dataset='fundus', bs=[1, 2, 1], S=args.size)
@@ -84,7 +92,8 @@ def main():
     lm /= args.world
     out = dict(rank=args.rank, rel_avg_vs_mean=rel, rel_avg_vs_local=rel_self, same_grad=bool(same_grad), same_params=bool(same_params),
                moved=moved, iters=int(ts.iter), loss_local=[float(v) for v in l_local], loss_mean=[float(v) for v in lm],
-               bn_tracked=int(bank.b('enc', 'convd1.bn1.num_batches_tracked')), graph=args.graph)
+               bn_tracked=int(bank.b('enc', 'convd1.bn1.num_batches_tracked')), graph=args.graph, backend=dist.get_backend(),
+               avg_op=str(runner.buckets._avg))
     print('DDPRESULT ' + json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

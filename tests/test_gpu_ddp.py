@@ -56,3 +56,49 @@ def test_two_ranks_on_one_gpu_average_gradients_and_stay_in_sync(graph):
         assert r['bn_tracked'] == 4, r                    # 2 steps x 2 passes, rank-local
     assert res[0]['loss_local'] != res[1]['loss_local']   # different batches ...
     assert res[0]['loss_mean'] == res[1]['loss_mean']     # ... one logged value
+
+
+def _run_workers(world, graph, backend, timeout=600):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ddp_worker.py'), '--rank', str(r), '--world', str(world),
+                               '--port', str(port), '--graph', str(graph), '--backend', backend],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    res = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        o = o.decode()
+        assert p.returncode == 0, o[-3000:]
+        line = [l for l in o.splitlines() if l.startswith('DDPRESULT ')]
+        assert line, o[-3000:]
+        res.append(json.loads(line[-1][len('DDPRESULT '):]))
+    return res
+
+
+@pytest.mark.parametrize('graph', [0, 1])
+def test_rccl_backend_on_one_gpu_takes_the_asynchronous_avg_branch(graph):
+    """The RCCL ('nccl') process group, world_size 1 on cuda:0: GradBuckets launches asynchronous AVG all-reduces from the
+    weight-gradient lane and the main stream waits on the works (ddp.py) -- the branch the 8-GPU bench runs and the gloo test
+    above never takes -- eagerly and inside the captured graphs.  With one rank the average IS the local gradient."""
+    (r,) = _run_workers(1, graph, 'nccl')
+    assert r['backend'] == 'nccl' and 'AVG' in r['avg_op'], r
+    assert r['rel_avg_vs_mean'] < 1e-6 and r['rel_avg_vs_local'] < 1e-6, r      # same kernels, same batch: the exchange is the identity
+    assert r['same_grad'] and r['same_params'] and r['iters'] == 2 and r['moved'] > 0, r
+
+
+@pytest.mark.parametrize('graph', [0, 1])
+def test_rccl_backend_on_two_gpus_averages_gradients(graph):
+    """Two ranks, two devices, RCCL: skipped on the one-GPU boxes of this pool, there for the first box that has two."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    res = _run_workers(2, graph, 'nccl')
+    for r in res:
+        assert r['backend'] == 'nccl' and r['rel_avg_vs_mean'] < 3e-2 and r['rel_avg_vs_local'] > 0.2, r
+        assert r['same_grad'] and r['same_params'] and r['iters'] == 2, r
+    assert res[0]['loss_mean'] == res[1]['loss_mean']
