@@ -40,8 +40,8 @@ __device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 // XP: timing experiments, compile-time so that they do not change the code around them (debug build only, RD_SW_EXP; results are
 // wrong when set): 1 no MFMAs / fragment reads, 2 no stores, 4 no transform / LDS writes, 16 no epilogue
-// NSL: live 16-byte channel slots of the input: 1, 2 or 4.  OUTV: 16-byte output vectors per lane: 2 (Cout 32), 1 (Cout 16), 0 (any
-// Cout, element-wise stores: the network's output layers)
+// NSL: live 16-byte channel slots of the input: 1, 2 or 4.  OUTV: 16-byte output vectors per lane: 2 (Cout 32), 1 (Cout 16), 3 (Cout <= 4:
+// the network's output layers, four unconditional scalar stores per lane), 0 (any other Cout, element-wise conditional stores)
 template <int NSL, int OUTV, int XP>
 __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t p, int tiles_per_wg) {
     typedef bf16_t T;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
         const unsigned toff = (unsigned)((y0 * W + x0) * p.Cout);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            if (OUTV == 1 && v == 1) continue;
+            if ((OUTV == 1 || OUTV == 3) && v == 1) continue;
             if (OUTV == 0 && v == 1 && !two) continue;
             const int cb = 16 * v + 8 * h;
             float vec[S], o[S];
@@ -270,7 +270,25 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
 #pragma unroll
             for (int e = 0; e < S; ++e) o[e] = vec[e] + bs[e];
             T* dst = out + (toff + ooff + 16 * v);
-            if constexpr (OUTV != 0) {
+            if constexpr (OUTV == 3) {
+                // <= 4 output channels (the out1 convs: 2 classes, 3 colours): four scalar stores per lane, unconditional like the
+                // vector stores below -- lanes of the upper half-wave, pixels outside the image and channels beyond Cout write to the
+                // trash record
+                const bool st = valid && h == 0;
+                T* tr = reinterpret_cast<T*>(&sw_trash[tid]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    T* qd = (st && e < p.Cout) ? dst + e : tr + e;
+                    if constexpr (!(XP & 2)) *qd = from_f<T>(o[e]);
+                }
+                if (st) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sa[v][e] += vec[e];
+                        sb[v][e] += vec[e] * vec[e];
+                    }
+                }
+            } else if constexpr (OUTV != 0) {
                 // the store is UNCONDITIONAL on every path (lanes outside the image / ghost tiles write to a trash record in device
                 // memory): stores count in vmcnt like loads do, and a store that exists on one path only makes every later wait
                 // conservative
@@ -312,7 +330,11 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     // the minimum over the paths that reach it, and a prologue without stores would make the loop wait as if its own stores did not
     // exist -- i.e. for the loads requested only ONE iteration earlier.
     auto fake_stores = [&]() {
-        if constexpr (OUTV != 0 && !(XP & 2)) {
+        if constexpr (OUTV == 3 && !(XP & 2)) {
+            T* tr = reinterpret_cast<T*>(&sw_trash[512 + tid]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tr[e] = from_f<T>(0.f);
+        } else if constexpr (OUTV != 0 && !(XP & 2)) {
 #pragma unroll
             for (int v = 0; v < (OUTV == 2 ? 2 : 1); ++v) sw_trash[v * 512 + tid] = make_uint4(0, 0, 0, 0);
         }
@@ -327,16 +349,35 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     fake_stores();
     sw_barrier();                                            // tile 0 is in buffer 0
     // iteration `it`: tile it+1 -> the other buffer, tile it+1+SW_NSET requested into its set, tile `it` multiplied and stored
-    for (int it0 = 0; it0 < nt; it0 += SW_NSET) {
+    // The two waves of a SIMD (w and w + 4) run the two halves of an iteration in OPPOSITE order: one transforms tile it+1 (VALU, LDS
+    // writes) while the other multiplies tile it (the matrix pipe), then they swap.  With the same order in all eight waves both
+    // waves of a SIMD reach their 18 dependent MFMAs together and one of them waits out the other's 1152 cycles.  Two loops, not a
+    // branch inside one: each is straight-line code, so the compiler still counts the loads and stores in flight (see above).
+    if (XP & 32 ? true : wave < 4) {
+        for (int it0 = 0; it0 < nt; it0 += SW_NSET) {
 #pragma unroll
-        for (int k = 0; k < SW_NSET; ++k) {
-            consume(raw[(k + 1) % SW_NSET], ql);
-            advance(ql);
-            issue(raw[(k + 1) % SW_NSET], qi);
-            advance(qi);
-            compute(qc);
-            advance(qc);
-            sw_barrier();
+            for (int k = 0; k < SW_NSET; ++k) {
+                consume(raw[(k + 1) % SW_NSET], ql);
+                advance(ql);
+                issue(raw[(k + 1) % SW_NSET], qi);
+                advance(qi);
+                compute(qc);
+                advance(qc);
+                sw_barrier();
+            }
+        }
+    } else {
+        for (int it0 = 0; it0 < nt; it0 += SW_NSET) {
+#pragma unroll
+            for (int k = 0; k < SW_NSET; ++k) {
+                compute(qc);
+                advance(qc);
+                consume(raw[(k + 1) % SW_NSET], ql);
+                advance(ql);
+                issue(raw[(k + 1) % SW_NSET], qi);
+                advance(qi);
+                sw_barrier();
+            }
         }
     }
 
@@ -421,12 +462,15 @@ int rd_conv_small_fwd_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
         case 7: RD_SW_LAUNCH(4, 2, 7);
         case 19: RD_SW_LAUNCH(4, 2, 19);
         case 23: RD_SW_LAUNCH(4, 2, 23);
+        case 32: RD_SW_LAUNCH(4, 2, 32);
         default: break;
         }
     }
 #endif
-    const int outv = p.Cout == 32 ? 2 : (p.Cout == 16 ? 1 : 0);
-#define RD_SW_OUT(NSL) do { if (outv == 2) RD_SW_LAUNCH(NSL, 2, 0); if (outv == 1) RD_SW_LAUNCH(NSL, 1, 0); RD_SW_LAUNCH(NSL, 0, 0); } while (0)
+    static const int narrow_on = rd_switch("RD_SW_NARROW", 1);
+    const int outv = p.Cout == 32 ? 2 : (p.Cout == 16 ? 1 : ((p.Cout <= 4 && narrow_on) ? 3 : 0));
+#define RD_SW_OUT(NSL) do { if (outv == 2) RD_SW_LAUNCH(NSL, 2, 0); if (outv == 1) RD_SW_LAUNCH(NSL, 1, 0); \
+                            if (outv == 3) RD_SW_LAUNCH(NSL, 3, 0); RD_SW_LAUNCH(NSL, 0, 0); } while (0)
     if (nl <= 1) RD_SW_OUT(1);
     if (nl <= 2) RD_SW_OUT(2);
     RD_SW_OUT(4);

@@ -69,6 +69,11 @@ FWD_CASES = [
     ('raw8_32_45x70', 9, [(L.SRC_RAW, 8)], 32, 2, 45, 70, [0, 2], 0.0),
     ('aff24_16_33x65', 9, [(L.SRC_AFF, 24)], 16, 2, 33, 65, [0, 1, 2], 0.0),
     ('cat16_aff8_32_41x64', 9, [(L.SRC_AFFACT, 16), (L.SRC_AFFACT, 8)], 32, 2, 41, 64, [0, 2], 0.0),
+    # ... and its narrow-output variant (<= 4 channels: scalar stores, lanes outside the image write to the trash record)
+    ('out32_2_70x100', 9, [(L.SRC_AFFACT, 32)], 2, 2, 70, 100, [0, 1, 2], 0.0),
+    ('out16_3_45x70', 9, [(L.SRC_AFFACT, 16)], 3, 3, 45, 70, [0, 1, 2, 3], 0.0),
+    ('out8_1_33x65', 9, [(L.SRC_RAW, 8)], 1, 2, 33, 65, [0, 2], 0.0),
+    ('out32_4_41x64', 9, [(L.SRC_AFF, 32)], 4, 2, 41, 64, [0, 1, 2], 0.0),
     ('c256_256', 9, [(L.SRC_AFFACT, 256)], 256, 2, 6, 7, [0, 1, 2], 0.0),
     ('c64_64_50x50', 9, [(L.SRC_AFFACT, 64)], 64, 2, 50, 50, [0, 1, 2], 0.0),          # 10 x 25 tiles: 5 x 2 per image, every lane but 6 live
     ('c128_64_23x100', 9, [(L.SRC_AFFACT, 128)], 64, 2, 23, 100, [0, 2], 0.0),          # ... a ragged last tile row
