@@ -564,6 +564,44 @@ __device__ __forceinline__ void grad_plain(const rd_dst_t& d, int n, int y, int 
     *reinterpret_cast<uint4*>(gp + idx) = Slot<T>::pack(gw);
 }
 
+// ------------------------------------------------------------------------------------ half-wave sums of many values
+// The BatchNorm sums of a workgroup: every lane holds NTOT (32 or 64) partial sums -- one pixel column, all channels -- and each has
+// to be summed over the 32 lanes of its half-wave.  A butterfly per VALUE (five __shfl_xor steps each, the form all kernels had) is
+// 5 x NTOT ds_bpermute round trips through the LDS crossbar, and written per channel with the LDS atomic behind it they run as
+// NTOT/2 dependent chains: 17 000 cycles (8 us) per workgroup (scripts/pf_trace.py), more than a third of a conv_pf_kernel
+// workgroup's life.  Here every step HALVES the set instead: lanes whose bit `STEP` is clear keep the lower half of the values and
+// hand the upper half to their partner, and the other way round, so that NTOT - NTOT/32 exchanges do the whole job, the first two
+// steps (48 of 62 exchanges) as DPP quad permutes inside the VALU.  Afterwards lane li of each half-wave holds, in r[0 .. NTOT/32),
+// the complete sums of the values with original index half_wave_sum_index(li) * (NTOT / 32) + j.
+// The order of the fp32 additions is fixed, so the result is the same from run to run.
+template <int MASK>
+__device__ __forceinline__ float lane_xor_f(float v) {
+    if constexpr (MASK == 1) {
+        const int q = __builtin_bit_cast(int, v);
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(q, q, 0xB1, 0xF, 0xF, true));     // quad_perm [1, 0, 3, 2]
+    } else if constexpr (MASK == 2) {
+        const int q = __builtin_bit_cast(int, v);
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(q, q, 0x4E, 0xF, 0xF, true));     // quad_perm [2, 3, 0, 1]
+    } else {
+        return __shfl_xor(v, MASK, 64);
+    }
+}
+template <int NTOT, int N = NTOT, int STEP = 0>
+__device__ __forceinline__ void half_wave_sums(float (&r)[NTOT], int li) {
+    static_assert(NTOT == 32 || NTOT == 64, "32 or 64 values per lane");
+    if constexpr (STEP < 5) {
+        const bool up = ((li >> STEP) & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const float keep = up ? r[i + N / 2] : r[i];
+            const float send = up ? r[i] : r[i + N / 2];
+            r[i] = keep + lane_xor_f<(1 << STEP)>(send);
+        }
+        half_wave_sums<NTOT, N / 2, STEP + 1>(r, li);
+    }
+}
+__device__ __forceinline__ int half_wave_sum_index(int li) { return (int)(__brev((unsigned)li) >> 27); }
+
 // sum b1/b2 over the lanes of a wave that own the same channel slot (lane % SL), then one LDS atomic per
 // wave and channel instead of one per thread (64-way same-address contention otherwise)
 template <int S, int SL>

@@ -122,6 +122,9 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
 // are stored / combined with the destination tensors as whole 16-byte NHWC slots.  ~1/3 of the instructions of the
 // LDS-staged conv_epilogue above.  EP 1 = forward (+bias, BatchNorm sums), EP 2 = gradient into plain destinations.
 // s_epi: [NT] bias (EP 1) or [2][NT] producer scale / shift of the destination channels (EP 2), staged by the caller.
+#ifndef PF_T
+#define PF_T(ev) do { } while (0)
+#endif
 template <typename T, int NB, int EP, int TS = 0>
 __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&acc)[2][NB], double* s_red, const float* s_epi,
                                                    int tid, int n, int g, int y0, int x0, int n0, int slot) {
@@ -131,6 +134,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
     const int H = p.H, W = p.W;
     if (tid < NT * 2) s_red[tid] = 0.0;
     __syncthreads();
+    PF_T(7);
     float sa[NB][2][S], sb[NB][2][S];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -138,6 +142,35 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int e = 0; e < S; ++e) sa[nb][v][e] = sb[nb][v][e] = 0.f;
+    // gradient launches: EVERY z / g vector of this lane is requested before the first one is used.  Written as one loop (load,
+    // use, store, next vector) the compiler has to assume that a store may alias the next load and waits for vmcnt(0) eight times --
+    // the stores count too -- i.e. sixteen dependent memory round trips per tile, most of a workgroup's life (dec.convu2.conv3
+    // dgrad: 29 us per workgroup against 15 us for the forward launch of the same shape).  Lanes without a live destination read
+    // the first weight vector instead (always mapped), so that no load is conditional.
+    uint4 zq[2][NB][2], gq[2][NB][2];
+    if constexpr (EP == 2) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            int pr, pc;
+            bool live;
+            tile_pixel<TS>(wave * 2 + mb, li, pr, pc, live);
+            const int y = y0 + pr, x = x0 + pc;
+            const bool valid = live && y < H && x < W;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int c = n0 + nb * 32 + 16 * v;
+                    const int di = c >= p.c_split ? 1 : 0;
+                    const rd_dst_t d = select_dst(p, di);
+                    const bool ok = d.kind != RD_DST_NONE && valid;
+                    const size_t idx = ((size_t)((n + d.n_off) * H + y) * W + x) * d.Cd + (c - (di ? p.c_split : 0)) + 8 * h;
+                    const T* dummy = reinterpret_cast<const T*>(p.w);
+                    zq[mb][nb][v] = ld16((ok && d.z) ? reinterpret_cast<const T*>(d.z) + idx : dummy);
+                    gq[mb][nb][v] = ld16((ok && d.accumulate) ? reinterpret_cast<const T*>(d.g) + idx : dummy);
+                }
+        }
+    }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         int pr, pc;
@@ -174,9 +207,8 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
                     const rd_dst_t d = select_dst(p, di);
                     if (d.kind == RD_DST_NONE || !valid) continue;
                     const size_t idx = ((size_t)((n + d.n_off) * H + y) * W + x) * d.Cd + (c - (di ? p.c_split : 0)) + 8 * h;
-                    uint4 zu = make_uint4(0, 0, 0, 0), gu = make_uint4(0, 0, 0, 0);
-                    if (d.z) zu = ld16(reinterpret_cast<const T*>(d.z) + idx);
-                    if (d.accumulate) gu = ld16(reinterpret_cast<const T*>(d.g) + idx);
+                    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+                    const uint4 zu = d.z ? zq[mb][nb][v] : zero4, gu = d.accumulate ? gq[mb][nb][v] : zero4;
                     float z[S], gw[S];
                     Slot<T>::unpack(zu, z);
                     Slot<T>::unpack(gu, gw);
@@ -193,25 +225,29 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
                 }
             }
     }
-    // per-channel sums: xor-reduce over the 32 pixel lanes of each half-wave, one LDS atomic per wave half and channel
+    PF_T(9);
+    // per-channel sums over the 32 pixel lanes of each half-wave (half_wave_sums), then NB LDS atomics per lane
+    {
+        float r[NB * 32];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+            for (int v = 0; v < 2; ++v)
 #pragma unroll
-            for (int e = 0; e < S; ++e) {
-                float a = sa[nb][v][e], b = sb[nb][v][e];
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    b += __shfl_xor(b, o, 64);
+                for (int e = 0; e < S; ++e) {
+                    r[((nb * 2 + v) * S + e) * 2 + 0] = sa[nb][v][e];
+                    r[((nb * 2 + v) * S + e) * 2 + 1] = sb[nb][v][e];
                 }
-                if (li == 0) {
-                    const int cl = nb * 32 + 16 * v + 8 * h + e;
-                    atomicAdd(&s_red[cl * 2 + 0], (double)a);
-                    atomicAdd(&s_red[cl * 2 + 1], (double)b);
-                }
-            }
+        half_wave_sums<NB * 32>(r, li);
+        const int base = half_wave_sum_index(li) * NB;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = base + j, c = idx >> 1;                       // c = (nb * 2 + v) * 8 + e
+            const int cl = (c >> 4) * 32 + ((c >> 3) & 1) * 16 + 8 * h + (c & 7);
+            atomicAdd(&s_red[cl * 2 + (idx & 1)], (double)r[j]);
+        }
+    }
+    PF_T(10);
     __syncthreads();
     if (tid < NT) {
         const int cch = n0 + tid;

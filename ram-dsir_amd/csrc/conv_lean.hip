@@ -2,6 +2,18 @@
 // forward launches (EP 1) and gradient launches whose destinations are all plain tensors (EP 2), bf16, whole
 // 32- / 64-channel output tiles.  Everything else stays with the LDS-staged epilogue in conv_big.hip.
 #include "conv_device.h"
+#ifdef RD_DEBUG_SWITCHES
+// debug build: shader-clock stamps of five workgroups (one per round of resident workgroups at 2560 tiles) of the launches whose
+// grid.x equals pf_trace_key (rd_debug_pf_trace; scripts/pf_trace.py)
+__device__ unsigned long long pf_trace[8][16];
+__device__ int pf_trace_key;
+#define PF_T(ev) do { \
+        if (pf_trace_key == (int)gridDim.x && threadIdx.x == 0 && blockIdx.y == 0 && (ev) < 15) { \
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z; \
+            if (lin % 600 == 7 && lin / 600 < 8) { pf_trace[lin / 600][ev] = __builtin_readcyclecounter(); if ((ev) == 0) pf_trace[lin / 600][15] = wall_clock64(); } \
+        } \
+    } while (0)
+#endif
 #include "conv_epilogue.h"
 #include "conv_dispatch.h"
 #include "conv_pf.h"
@@ -61,3 +73,10 @@ int rd_conv_pf_lean_dispatch(const rd_conv_t& p, bool nb2, hipStream_t st) {
     }
     return nb2 ? launch_lean<1, 2, 0>(p, ep, nq, st) : launch_lean<1, 1, 0>(p, ep, nq, st);
 }
+
+#ifdef RD_DEBUG_SWITCHES
+extern "C" int rd_debug_pf_trace(int key, unsigned long long* out) {       // debug library only: arm (out == null) or read 8 x 16 stamps
+    if (!out) return (int)hipMemcpyToSymbol(HIP_SYMBOL(pf_trace_key), &key, sizeof(int));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_trace), sizeof(unsigned long long) * 8 * 16);
+}
+#endif

@@ -53,6 +53,9 @@ int conv_pf_kind(const rd_conv_t& p) {
     return two ? 2 : 1;
 }
 
+#ifndef PF_T
+#define PF_T(ev) do { } while (0)          // conv_lean.hip (debug build) records shader-clock stamps of a few workgroups here
+#endif
 // ------------------------------------------------------------------------------------ chunk-pipelined kernel
 // Same tile / LDS / MFMA layout as conv_kernel, for launches whose sources are all plain per-pixel reads of
 // whole 16-byte channel slots (PlainSrc; the host checks).  The raw input vectors and the weight vectors of
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
             wr[b] = ld16(wbase + ((size_t)((c0 / CK) * TAPS + min(tap, TAPS - 1)) * p.CoutPad + n0 + nn) * CK + sw * S);
         }
     };
+    PF_T(0);
     issue(0);
     // BN coefficient rows of this image's group, all input channels, staged once: the per-chunk fill then reads them
     // from LDS (~100 cycles) instead of from L2 right in front of the transform (an exposed ~1 us per chunk)
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
                     }
                 }
                 pfu_consume<T, NIT>(raw, ps, ig, H, W, y0 - HALO, x0 - HALO, [&](int l, const uint4& u) { s_in[l] = u; });
+                PF_T(1 + 3 * (c0 / CK));
             } else {
 #pragma unroll
                 for (int b = 0; b < NIT; ++b)
@@ -209,12 +214,16 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
             if (idx < WTOT) s_w[rec * 4 + (sw ^ ((nn >> 2) & 3))] = wr[b];
         }
         __syncthreads();
+        PF_T(2 + 3 * (c0 / CK));
         if (c0 + CK < p.CinPad) issue(c0 + CK);
         conv_mma_chunk<T, TAPS, NB, EP != 0, TS>(s_in, s_w, wave, li, h, acc);
+        PF_T(3 + 3 * (c0 / CK));
     }
     __syncthreads();
+    PF_T(13);
     if constexpr (EP == 0) conv_epilogue<T, NB>(p, acc, smem, tid, n, g, y0, x0, n0, slot);
     else conv_epilogue_lean<T, NB, EP, TS>(p, acc, reinterpret_cast<double*>(smem), s_epi, tid, n, g, y0, x0, n0, slot);
+    PF_T(14);
 }
 
 
