@@ -601,6 +601,39 @@ __device__ __forceinline__ void half_wave_sums(float (&r)[NTOT], int li) {
     }
 }
 __device__ __forceinline__ int half_wave_sum_index(int li) { return (int)(__brev((unsigned)li) >> 27); }
+// the same exchange over the lane bits MASK, 2 MASK, .. 32 (lanes that differ in the low bits own different channels): N values -> 1
+template <int NTOT, int N, int MASK>
+__device__ __forceinline__ void lane_group_sums(float (&r)[NTOT], int lane) {
+    if constexpr (N > 1) {
+        static_assert(MASK <= 32, "more values than lanes to spread them over");
+        const bool up = (lane & MASK) != 0;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const float keep = up ? r[i + N / 2] : r[i];
+            const float send = up ? r[i] : r[i + N / 2];
+            r[i] = keep + lane_xor_f<MASK>(send);
+        }
+        lane_group_sums<NTOT, N / 2, MASK * 2>(r, lane);
+    }
+}
+// the common case: NV vectors of S channels per lane (NV * S = 16; channel of (v, e) = 2 S v + S h + e), both statistics -> 32 values,
+// one LDS atomic per lane into the workgroup's fp64 sums s_red[channel][2]
+template <int S, int NV>
+__device__ __forceinline__ void flush_half_wave_sums16(double* s_red, const float (&sa)[NV][S], const float (&sb)[NV][S], int li, int h) {
+    static_assert(NV * S == 16, "16 channels per lane");
+    float r[32];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            r[(v * S + e) * 2 + 0] = sa[v][e];
+            r[(v * S + e) * 2 + 1] = sb[v][e];
+        }
+    half_wave_sums<32>(r, li);
+    const int idx = half_wave_sum_index(li), c = idx >> 1;
+    const int ch = 2 * S * (c / S) + S * h + (c % S);
+    atomicAdd(&s_red[ch * 2 + (idx & 1)], (double)r[0]);
+}
 
 // sum b1/b2 over the lanes of a wave that own the same channel slot (lane % SL), then one LDS atomic per
 // wave and channel instead of one per thread (64-way same-address contention otherwise)
@@ -610,21 +643,20 @@ template <int S, int SL>
 // amplified through the remaining layers (DESIGN.md Numerics).  A sum of fp32 values in fp64 is exact as long as the terms span fewer
 // than 2^(53-24) in magnitude and count, i.e. independent of the order: the step is reproducible run to run (scripts/repro_check.py).
 __device__ __forceinline__ void flush_bstats(double* s_red, int lane, int sl, float* b1, float* b2) {
+    // 2 S values per lane, summed over the 64 / SL lanes with the same channel slot by the halving exchange of half_wave_sums (lane
+    // bits log2(SL) .. 5: 2 S - 1 exchanges instead of 2 S per step), then ONE LDS atomic per lane
+    constexpr int N = 2 * S;
+    static_assert(N * SL == 64, "one value per lane after the last step");
+    float r[N];
 #pragma unroll
     for (int e = 0; e < S; ++e) {
-#pragma unroll
-        for (int o = SL; o < 64; o <<= 1) {
-            b1[e] += __shfl_xor(b1[e], o, 64);
-            b2[e] += __shfl_xor(b2[e], o, 64);
-        }
+        r[e * 2 + 0] = b1[e];
+        r[e * 2 + 1] = b2[e];
     }
-    if (lane < SL) {
-#pragma unroll
-        for (int e = 0; e < S; ++e) {
-            atomicAdd(&s_red[(sl * S + e) * 2 + 0], (double)b1[e]);
-            atomicAdd(&s_red[(sl * S + e) * 2 + 1], (double)b2[e]);
-        }
-    }
+    lane_group_sums<N, N, SL>(r, lane);
+    constexpr int LOGN = (N == 16) ? 4 : 3;
+    const int idx = (int)(__brev((unsigned)(lane / SL)) >> (32 - LOGN));
+    atomicAdd(&s_red[(sl * S + (idx >> 1)) * 2 + (idx & 1)], (double)r[0]);
 }
 
 // picks dst[0] or dst[1] field by field (lane-varying di): keeps the kernarg struct out of scratch

@@ -393,22 +393,9 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
             fz_barrier();
         }
 
-        // ---- BN-backward sums of all tiles: xor-reduce over the 32 lanes of a half-wave, LDS atomics, one global set per workgroup
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-#pragma unroll
-            for (int e = 0; e < S; ++e) {
-                float a = sa[v][e], b = sb[v][e];
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    b += __shfl_xor(b, o, 64);
-                }
-                if (li == 0 && cbv[v] + e < 32) {
-                    atomicAdd(&s_red[(cbv[v] + e) * 2 + 0], a);
-                    atomicAdd(&s_red[(cbv[v] + e) * 2 + 1], b);
-                }
-            }
+        // ---- BN-backward sums of all tiles: summed over the 32 lanes of a half-wave (conv_device.h half_wave_sums), one LDS atomic per
+        //      lane, one global set per workgroup
+        flush_half_wave_sums16<S, NV>(s_red, sa, sb, li, h);
         __syncthreads();                                   // (the other role's cross-wave dW barrier)
         if (tid < 32 && tid < p.Cout) {
             const int dj = tid >= p.c_split ? 1 : 0;

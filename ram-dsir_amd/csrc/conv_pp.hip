@@ -619,37 +619,39 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     auto flush_stats = [&]() {
         if (cur_n0 < 0) return;
         const int slot = blockIdx.x % RD_STAT_SLOTS;
+        // sums over the 32 pixel lanes of each half-wave (conv_device.h half_wave_sums): afterwards every lane holds BOTH statistics
+        // of one channel and adds them to the global fp64 slot itself
+        float r[64];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int v = 0; v < 2; ++v)
 #pragma unroll
                 for (int e = 0; e < S; ++e) {
-                    float a = sa[nb][v][e], b = sb[nb][v][e];
-#pragma unroll
-                    for (int o = 1; o < 32; o <<= 1) {
-                        a += __shfl_xor(a, o, 64);
-                        b += __shfl_xor(b, o, 64);
-                    }
-                    if constexpr (MODE == 1) {
-                        if (li == 0 && p.stats) {
-                            const size_t so = (((size_t)cur_g * RD_STAT_SLOTS + slot) * p.Cout + cur_n0 + nb * 32 + 16 * v + 8 * h + e) * 2;
-                            atomicAdd(&p.stats[so + 0], (double)a);
-                            atomicAdd(&p.stats[so + 1], (double)b);
-                        }
-                    } else {
-                        const int c = cur_n0 + nb * 32 + 16 * v;
-                        const int di = c >= p.c_split ? 1 : 0;
-                        const rd_dst_t d = select_dst(p, di);
-                        if (li == 0 && d.kind != RD_DST_NONE && d.bstats) {
-                            const int gd = d.g_fixed >= 0 ? d.g_fixed : cur_g;
-                            const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * d.Cd + c - (di ? p.c_split : 0) + 8 * h + e) * 2;
-                            atomicAdd(&d.bstats[so + 0], (double)a);
-                            atomicAdd(&d.bstats[so + 1], (double)b);
-                        }
-                    }
+                    r[((nb * 2 + v) * S + e) * 2 + 0] = sa[nb][v][e];
+                    r[((nb * 2 + v) * S + e) * 2 + 1] = sb[nb][v][e];
                     sa[nb][v][e] = sb[nb][v][e] = 0.f;
                 }
+        half_wave_sums<64>(r, li);
+        const int cq = half_wave_sum_index(li);                            // (nb * 2 + v) * 8 + e
+        const int nbq = cq >> 4, vq = (cq >> 3) & 1, eq = cq & 7;
+        if constexpr (MODE == 1) {
+            if (p.stats) {
+                const size_t so = (((size_t)cur_g * RD_STAT_SLOTS + slot) * p.Cout + cur_n0 + nbq * 32 + 16 * vq + 8 * h + eq) * 2;
+                atomicAdd(&p.stats[so + 0], (double)r[0]);
+                atomicAdd(&p.stats[so + 1], (double)r[1]);
+            }
+        } else {
+            const int c = cur_n0 + nbq * 32 + 16 * vq;
+            const int di = c >= p.c_split ? 1 : 0;
+            const rd_dst_t d = select_dst(p, di);
+            if (d.kind != RD_DST_NONE && d.bstats) {
+                const int gd = d.g_fixed >= 0 ? d.g_fixed : cur_g;
+                const size_t so = (((size_t)gd * RD_STAT_SLOTS + slot) * d.Cd + c - (di ? p.c_split : 0) + 8 * h + eq) * 2;
+                atomicAdd(&d.bstats[so + 0], (double)r[0]);
+                atomicAdd(&d.bstats[so + 1], (double)r[1]);
+            }
+        }
     };
     // MODE 2: the producer's raw tensor of this tile (activation mask, sum g*z), requested at the start of its last K step;
     // the old gradient of an accumulating destination (skip connections: few launches) is read in the epilogue itself --

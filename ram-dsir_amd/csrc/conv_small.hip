@@ -218,22 +218,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
     }
 
     // ---- flush the BN sums of all tiles of this workgroup: lanes of a half-wave hold different pixels of the
-    //      same channels -> xor-reduce over the 32 lanes, one LDS atomic per wave half and channel
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int e = 0; e < S; ++e) {
-            float a = sa[v][e], b = sb[v][e];
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                a += __shfl_xor(a, o, 64);
-                b += __shfl_xor(b, o, 64);
-            }
-            if (li == 0 && cbv[v] + e < 32) {
-                atomicAdd(&s_red[(cbv[v] + e) * 2 + 0], a);
-                atomicAdd(&s_red[(cbv[v] + e) * 2 + 1], b);
-            }
-        }
+    //      same channels -> summed over the 32 lanes (conv_device.h half_wave_sums), one LDS atomic per lane
+    flush_half_wave_sums16<S, NV>(s_red, sa, sb, li, h);
     __syncthreads();
     if (tid < 32 && tid < p.Cout) {
         if constexpr (EPI == 0) {

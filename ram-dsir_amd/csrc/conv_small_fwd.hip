@@ -381,22 +381,9 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
         }
     }
 
-    // ---- BatchNorm sums of all tiles: xor-reduce over the 32 lanes of a half-wave, LDS atomics, one global set per workgroup
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int e = 0; e < S; ++e) {
-            float a = sa[v][e], b = sb[v][e];
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                a += __shfl_xor(a, o, 64);
-                b += __shfl_xor(b, o, 64);
-            }
-            if (li == 0) {
-                atomicAdd(&s_red[(16 * v + 8 * h + e) * 2 + 0], (double)a);
-                atomicAdd(&s_red[(16 * v + 8 * h + e) * 2 + 1], (double)b);
-            }
-        }
+    // ---- BatchNorm sums of all tiles: summed over the 32 lanes of a half-wave (conv_device.h half_wave_sums), one LDS atomic per lane,
+    //      one global set per workgroup
+    flush_half_wave_sums16<S, NV>(s_red, sa, sb, li, h);
     __syncthreads();
     if (tid < 32 && tid < p.Cout && p.stats) {
         const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + tid) * 2;
