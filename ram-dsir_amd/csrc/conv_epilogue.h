@@ -171,6 +171,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
                 }
         }
     }
+    PF_T(8);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         int pr, pc;
@@ -212,16 +213,24 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
                     float z[S], gw[S];
                     Slot<T>::unpack(zu, z);
                     Slot<T>::unpack(gu, gw);
-                    const bool masked = d.act && d.z;
+                    // producer scale / shift of the vector's 8 channels as four 16-byte LDS reads; the activation gradient as ONE select
+                    // per element: `lo` is the factor where bn(z) <= 0 -- the slope, or 1 for a destination without a mask (a
+                    // wave-uniform choice made per vector, not a branch per element)
+                    const float4 c0 = *reinterpret_cast<const float4*>(s_epi + cl), c1 = *reinterpret_cast<const float4*>(s_epi + cl + 4);
+                    const float4 h0 = *reinterpret_cast<const float4*>(s_epi + NT + cl), h1 = *reinterpret_cast<const float4*>(s_epi + NT + cl + 4);
+                    const float sc[S] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                    const float sh[S] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                    const float lo = (d.act && d.z) ? d.slope : 1.f;
 #pragma unroll
                     for (int e = 0; e < S; ++e) {
-                        const float m = masked ? act_grad(z[e] * s_epi[cl + e] + s_epi[NT + cl + e], d.slope) : 1.f;
+                        const float m = (z[e] * sc[e] + sh[e]) > 0.f ? 1.f : lo;
                         const float gn = o[e] * m;
                         sa[nb][v][e] += gn;
                         sb[nb][v][e] += gn * z[e];
                         gw[e] += gn;
                     }
                     *reinterpret_cast<uint4*>(reinterpret_cast<T*>(d.g) + idx) = Slot<T>::pack(gw);
+                    if (mb == 0 && nb == 0 && v == 0) PF_T(11);
                 }
             }
     }

@@ -46,4 +46,4 @@ for r in range(8):
         continue
     ev = [int(t[r, k] - t[r, 0]) if t[r, k] else -1 for k in range(15)]
     print('%4d  %8.1f | %s | end-barrier %6d  done %6d' % (7 + 600 * r, (t[r, 15] - w0) / 100.0, '  '.join('%6d %6d %6d' % tuple(ev[1 + 3 * c:4 + 3 * c]) for c in range(2) if ev[1 + 3 * c] >= 0), ev[13], ev[14]),
-          '| epilogue: sums zeroed %6d  vectors stored %6d  shuffles %6d' % (ev[7], ev[9], ev[10]))
+          '| epilogue: sums zeroed %6d  loads issued %6d  first vector stored %6d  all stored %6d  sums reduced %6d' % (ev[7], ev[8], ev[11], ev[9], ev[10]))
