@@ -553,15 +553,54 @@ __device__ __forceinline__ void grad_plain(const rd_dst_t& d, int n, int y, int 
     if (d.accumulate) gu = ld16(gp + idx);
     Slot<T>::unpack(zu, z);
     Slot<T>::unpack(gu, gw);
+    const float lo = (d.act && zp) ? d.slope : 1.f;         // one select per element, no branch (see grad_plain_finish)
 #pragma unroll
     for (int e = 0; e < S; ++e) {
-        const float m = (d.act && zp) ? act_grad(z[e] * sc[e] + sh[e], d.slope) : 1.f;
+        const float m = (z[e] * sc[e] + sh[e]) > 0.f ? 1.f : lo;
         const float gn = da[e] * m;
         b1[e] += gn;
         b2[e] += gn * z[e];
         gw[e] += gn;
     }
     *reinterpret_cast<uint4*>(gp + idx) = Slot<T>::pack(gw);
+}
+
+// grad_plain in two halves, so that a kernel can REQUEST the producer tensor (and the old gradient) of all its vectors before it uses
+// the first one.  A loop of grad_plain calls runs as load, wait, compute, store, wait (the compiler must assume that the store
+// aliases the next load, and stores count in vmcnt): two dependent memory round trips per vector.  Lanes without a live destination
+// read `dummy` (any mapped 16 bytes), so that no load is conditional.
+struct GradPlainReq {
+    uint4 zu, gu;
+    size_t idx;
+    bool ok;
+};
+template <typename T>
+__device__ __forceinline__ void grad_plain_issue(GradPlainReq& q, const rd_dst_t& d, bool ok, int n, int y, int x, int H, int W, int cd, const void* dummy) {
+    q.ok = ok;
+    q.idx = ((size_t)((n + d.n_off) * H + y) * W + x) * d.Cd + cd;
+    const T* dm = reinterpret_cast<const T*>(dummy);
+    q.zu = ld16((ok && d.z) ? reinterpret_cast<const T*>(d.z) + q.idx : dm);
+    q.gu = ld16((ok && d.accumulate) ? reinterpret_cast<const T*>(d.g) + q.idx : dm);
+}
+template <typename T>
+__device__ __forceinline__ void grad_plain_finish(const GradPlainReq& q, const rd_dst_t& d, const float* da, const float* sc, const float* sh,
+                                                  float* b1, float* b2) {
+    constexpr int S = Slot<T>::N;
+    if (!q.ok) return;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    float z[S], gw[S];
+    Slot<T>::unpack(d.z ? q.zu : zero4, z);
+    Slot<T>::unpack(d.accumulate ? q.gu : zero4, gw);
+    const float lo = (d.act && d.z) ? d.slope : 1.f;        // the factor where bn(z) <= 0; 1 for a destination without a mask
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+        const float m = (z[e] * sc[e] + sh[e]) > 0.f ? 1.f : lo;
+        const float gn = da[e] * m;
+        b1[e] += gn;
+        b2[e] += gn * z[e];
+        gw[e] += gn;
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(d.g) + q.idx) = Slot<T>::pack(gw);
 }
 
 // ------------------------------------------------------------------------------------ half-wave sums of many values

@@ -157,6 +157,26 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
                 Mma<T>::chunk(s_w + (tap * NT + li) * 4, (li >> 2) & 3, s_in + pix * 4, (pix >> 2) & 3, h, acc[mb], nks);
             }
         }
+        // plain gradient destinations of the 1x1 kernel: the producer tensors / old gradients of all 2 x NV vectors are requested
+        // together, ahead of the first use (conv_device.h grad_plain_issue).  The 3x3 kernel has no registers left for the requests:
+        // with them it spills (52-116 bytes per lane) and the row-block launches of dec.convu1.conv1's dgrad go from 58 + 54 to
+        // 81 + 71 us, so it keeps the vector-by-vector grad_plain.
+        GradPlainReq gq[2][NV];
+        auto issue_row = [&](int mb) {
+            const int y = y0 + wave * 2 + mb, x = x0 + li;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int cb = cbv[v];
+                const int di = cb >= p.c_split ? 1 : 0;
+                const rd_dst_t d = select_dst(p, di);
+                grad_plain_issue<T>(gq[mb][v], d, y < H && x < W && cb < p.Cout && d.kind != RD_DST_NONE, n, y, x, H, W,
+                                    cb - (di ? p.c_split : 0), p.w);
+            }
+        };
+        if constexpr (EPI == 1 && TAPS == 1) {
+            issue_row(0);
+            issue_row(1);
+        }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int y = y0 + wave * 2 + mb, x = x0 + li;
@@ -201,11 +221,14 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
                     const int cd = cb - (di ? p.c_split : 0);
                     float dsc[S], dsh[S];
 #pragma unroll
-                    for (int e = 0; e < S; ++e) {
-                        dsc[e] = s_dsc[cb + e];
-                        dsh[e] = s_dsh[cb + e];
+                    for (int e = 0; e < S; e += 4) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(s_dsc + cb + e), b4 = *reinterpret_cast<const float4*>(s_dsh + cb + e);
+                        dsc[e] = a4.x; dsc[e + 1] = a4.y; dsc[e + 2] = a4.z; dsc[e + 3] = a4.w;
+                        dsh[e] = b4.x; dsh[e + 1] = b4.y; dsh[e + 2] = b4.z; dsh[e + 3] = b4.w;
                     }
-                    if constexpr (EPI == 1) {
+                    if constexpr (EPI == 1 && TAPS == 1) {
+                        grad_plain_finish<T>(gq[mb][v], d, vec[v], dsc, dsh, sa[v], sb[v]);
+                    } else if constexpr (EPI == 1) {
                         grad_plain<T>(d, n, y, x, H, W, cd, vec[v], dsc, dsh, sa[v], sb[v]);
                     } else {
                         constexpr int KM = EPI == 3 ? 5 : (EPI == 4 ? 3 : 7);
