@@ -195,11 +195,13 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
                 }
                 if constexpr (EP == 1) {
                     if (!valid) continue;
+                    const float4 b0 = *reinterpret_cast<const float4*>(s_epi + cl), b1 = *reinterpret_cast<const float4*>(s_epi + cl + 4);
+                    const float bias[S] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                     for (int e = 0; e < S; ++e) {
                         sa[nb][v][e] += o[e];                     // sums exclude the bias (ramdsir.h, RD_STAT_SLOTS)
                         sb[nb][v][e] += o[e] * o[e];
-                        o[e] += s_epi[cl + e];
+                        o[e] += bias[e];
                     }
                     *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + ((size_t)(n * H + y) * W + x) * p.Cout + n0 + cl) = Slot<T>::pack(o);
                 } else {

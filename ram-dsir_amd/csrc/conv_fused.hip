@@ -350,11 +350,18 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
                         }
                         Slot<T>::unpack(araw[mb][v], xr);
                         const bool on = valid && live[v];
+                        float dsc[S], dsh[S];                // producer scale / shift of the vector's channels: four 16-byte LDS reads
+#pragma unroll
+                        for (int e = 0; e < S; e += 4) {
+                            const float4 a4 = *reinterpret_cast<const float4*>(s_dsc + cb + e), b4 = *reinterpret_cast<const float4*>(s_dsh + cb + e);
+                            dsc[e] = a4.x; dsc[e + 1] = a4.y; dsc[e + 2] = a4.z; dsc[e + 3] = a4.w;
+                            dsh[e] = b4.x; dsh[e + 1] = b4.y; dsh[e + 2] = b4.z; dsh[e + 3] = b4.w;
+                        }
                         if (relu[v]) {
                             // BN + ReLU producer (every layer but ConvD.bn1 / raw inputs): a = max(y, 0), g = y > 0 ? da : 0
 #pragma unroll
                             for (int e = 0; e < S; ++e) {
-                                const float yv = xr[e] * s_dsc[cb + e] + s_dsh[cb + e];
+                                const float yv = xr[e] * dsc[e] + dsh[e];
                                 av[e] = fmaxf(yv, 0.f);
                                 const float gn = (on && yv > 0.f) ? vec[e] : 0.f;
                                 sa[v][e] += gn;
@@ -362,11 +369,12 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
                                 go[e] = gn;
                             }
                         } else {
+                            const float lo = masked[v] ? p.dst[0].slope : 1.f;
 #pragma unroll
                             for (int e = 0; e < S; ++e) {
-                                const float yv = xr[e] * s_dsc[cb + e] + s_dsh[cb + e];
+                                const float yv = xr[e] * dsc[e] + dsh[e];
                                 av[e] = act_fn(yv, slp[v]);
-                                const float m = masked[v] ? act_grad(yv, p.dst[0].slope) : 1.f;
+                                const float m = yv > 0.f ? 1.f : lo;
                                 const float gn = on ? vec[e] * m : 0.f;
                                 sa[v][e] += gn;
                                 sb[v][e] += gn * xr[e];

@@ -786,7 +786,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                         const float4 d0 = *reinterpret_cast<const float4*>(cp + p.CoutPad), d1 = *reinterpret_cast<const float4*>(cp + p.CoutPad + 4);
                         const float psc[S] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                         const float psh[S] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-                        const bool masked = d.act && d.z;
+                        const float lo = (d.act && d.z) ? d.slope : 1.f;       // one select per element (conv_device.h grad_plain_finish)
 #pragma unroll
                         for (int mb = 0; mb < 2; ++mb) {
                             float da[S];
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                             Slot<T>::unpack(d.accumulate ? ld16(gp) : make_uint4(0, 0, 0, 0), gw);
 #pragma unroll
                             for (int e = 0; e < S; ++e) {
-                                const float m = masked ? act_grad(z[e] * psc[e] + psh[e], d.slope) : 1.f;
+                                const float m = (z[e] * psc[e] + psh[e]) > 0.f ? 1.f : lo;
                                 const float gn = da[e] * m;
                                 sa[nb][v][e] += gn;
                                 sb[nb][v][e] += gn * (d.z ? z[e] : 0.f);
