@@ -851,6 +851,31 @@ __device__ __forceinline__ void pfu_issue(uint4 (&raw)[NIT][NQ], const PlainSrc<
     }
 }
 
+// pfu_issue for a loader whose items and source are fixed for the whole kernel: the element offset of every item inside an image
+// ((py W + px) C) is computed ONCE; a request is then one add of the tile's (wave-uniform, scalar) offset, one v_med3 that keeps the
+// address inside the image -- items outside it read SOME pixel of the image instead of the clamped one; pfu_consume discards them
+// either way -- and the pointer add.  pfu_issue pays two clamps and two quarter-rate v_mul_lo_u32 per item: 1450 of the 5300
+// cycles a wgrad_ws_kernel loader wave spent per tile (scripts/wg_trace.py).
+template <typename T, int NIT>
+__device__ __forceinline__ void pfu_item_offsets(int (&ioff)[NIT], const PlainSrc<T>& k, const ItemGeom<NIT>& ig, int W) {
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) ioff[b] = ((int)ig.py[b] * W + (int)ig.px[b]) * k.C;
+}
+template <typename T, int NIT, int NQ>
+__device__ __forceinline__ void pfu_issue_pre(uint4 (&raw)[NIT][NQ], const PlainSrc<T>& k, const int (&ioff)[NIT], int n,
+                                              int H, int W, int yh, int xh) {
+    const size_t img = (size_t)(n + k.n_off) * H * W * k.C;
+    const T* b0 = k.p0 + img;
+    const T* b1 = k.p1 + img;
+    const int toff = (yh * W + xh) * k.C, last = (H * W - 1) * k.C;
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) {
+        const int off = min(max(toff + ioff[b], 0), last);
+        raw[b][0] = ld16(b0 + off);
+        if constexpr (NQ == 2) raw[b][1] = ld16(b1 + off);
+    }
+}
+
 template <typename T, int NIT, int NQ, typename StoreFn>
 __device__ __forceinline__ void pfu_consume(const uint4 (&raw)[NIT][NQ], const PlainSrc<T>& k, const ItemGeom<NIT>& ig,
                                             int H, int W, int yh, int xh, StoreFn store, int nit = NIT) {

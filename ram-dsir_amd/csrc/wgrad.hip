@@ -394,6 +394,18 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
 // LDS tiles are 4 rows x 32 pixels (half of the single-role kernel's) so that two buffers fit: 2 x 48 KB.
 // XP: timing experiments of the debug build, compile-time so that they do not change the code around them (RD_WGWS_EXP; wrong results
 // when set): 1 no MFMA phase, 4 loader does not transform / write LDS
+#ifdef RD_DEBUG_SWITCHES
+// debug build: shader-clock stamps of workgroup (5, 0, 0) of the launches whose total tile count equals wg_trace_key
+// (rd_debug_wg_trace; scripts/wg_trace.py): [role][iteration][event]
+__device__ unsigned long long wg_trace[2][64][4];
+__device__ int wg_trace_key;
+#define WG_T(role, it, ev) do { \
+        if (wg_trace_key == total_tiles && blockIdx.x == 5 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 255) == 0 && (it) < 64) \
+            wg_trace[role][it][ev] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define WG_T(role, it, ev) do { } while (0)
+#endif
 template <int NQZ, int XP>
 __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
     typedef bf16_t T;
@@ -480,20 +492,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
         // barrier wait is ~0 and every tile paid a full memory latency -- timing builds, RD_WGWS_EXP: 153 us with, 108 us
         // without the loads on dec.convu3.conv3.)
         uint4 raw_aA[NITA][1], raw_zA[NITZ][NQZ], raw_aB[NITA][1], raw_zB[NITZ][NQZ];
+        int offa[NITA], offz[NITZ];                             // (py W + px) C of every item, once (conv_device.h pfu_issue_pre)
+        pfu_item_offsets<T, NITA>(offa, psa, iga, W);
+        pfu_item_offsets<T, NITZ>(offz, psz, igz, W);
         auto issue = [&](uint4 (&ra)[NITA][1], uint4 (&rz)[NITZ][NQZ], int tile) {
             int n, y0, x0;
             coords(tile, n, y0, x0);
-            const bool ghost = tile >= total_tiles;
+            const bool ghost = tile >= total_tiles;           // a ghost re-reads tile 0 (at most two per workgroup; fill() zeroes them)
             n = ghost ? 0 : n;
-            y0 = ghost ? -(1 << 20) : y0;
-            x0 = ghost ? -(1 << 20) : x0;
-            pfu_issue<T, NITA>(ra, psa, iga, n, H, W, y0 - 1, x0 - 1);
-            pfu_issue<T, NITZ>(rz, psz, igz, n, H, W, y0, x0);
+            y0 = ghost ? 0 : y0;
+            x0 = ghost ? 0 : x0;
+            pfu_issue_pre<T, NITA>(ra, psa, offa, n, H, W, y0 - 1, x0 - 1);
+            pfu_issue_pre<T, NITZ>(rz, psz, offz, n, H, W, y0, x0);
         };
         const bool z_raw = p.dz.mode == RD_SRC_RAW;             // a stored dz / dlogits: copied, not transformed
         int g_ctx = -1;
         const int stride = gridDim.x;
         auto fill = [&](uint4 (&ra)[NITA][1], uint4 (&rz)[NITZ][NQZ], int tile, int it) {
+            WG_T(1, it, 0);
             int n, y0, x0;
             coords(tile, n, y0, x0);
             const bool ghost = tile >= total_tiles;           // zeros into the buffer nobody reads any more
@@ -538,7 +554,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
                 for (int b = 0; b < NITZ; ++b) acc ^= rz[b][0].x ^ rz[b][0].y ^ rz[b][0].z ^ rz[b][0].w;
                 if (acc == 0x12345678u) *reinterpret_cast<unsigned*>(s_a) = acc;
             }
+            WG_T(1, it, 1);
             issue(ra, rz, tile + 2 * stride);                 // a ghost past the end
+            WG_T(1, it, 2);
         };
         const int t0 = blockIdx.x;
         issue(raw_aA, raw_zA, t0);
@@ -547,8 +565,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
         for (int tile = t0; tile < total_tiles; tile += 2 * stride, it += 2) {
             fill(raw_aA, raw_zA, tile, it);
             __syncthreads();               // tile `it` is in its buffer; the MFMA waves are done with the other one
+            WG_T(1, it, 3);
             fill(raw_aB, raw_zB, tile + stride, it + 1);
             if (tile + stride < total_tiles) __syncthreads();
+            WG_T(1, it + 1, 3);
         }
         return;
     }
@@ -566,32 +586,49 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
     const int aoff = ((gq >> 1) * 8 + (i16 >> 2)) * PA + (nb * 32 + (gq & 1) * 16 + (i16 & 3) * 4) * 2;
     int it = 0;
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
+        WG_T(0, it, 0);
         __syncthreads();
+        WG_T(0, it, 1);
         if constexpr ((XP & 1) != 0) continue;
         const char* s_a = smem + (it & 1) * BUF;
         const char* s_z = s_a + A_BYTES;
+        // The LDS pipe, not the matrix pipe, bounds this kernel (SQ counters: LDS active 88 % of the cycles, a third of that bank
+        // conflicts), so every fragment is read ONCE per tile: the dz fragments of the four output rows up front (32 registers), then
+        // the six halo rows of `a` in turn, each used by the up to three (output row, kernel row) pairs it belongs to --
+        // 16 + 36 transpose reads per wave and tile instead of 16 + 72.
+        uint4 zf[THW][2];
 #pragma unroll
-        for (int row = 0; row < THW; ++row) {
+        for (int row = 0; row < THW; ++row)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const char* zp = s_z + zoff + (row * TW + ks * 16) * PZ;
                 const uint2 z0 = lds_tr(zp), z1 = lds_tr(zp + 4 * PZ);
-                const bf16x8 afrag = __builtin_bit_cast(bf16x8, make_uint4(z0.x, z0.y, z1.x, z1.y));
+                zf[row][ks] = make_uint4(z0.x, z0.y, z1.x, z1.y);
+            }
+#pragma unroll
+        for (int r = 0; r < THW + 2; ++r) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* ap = s_a + aoff + (r * PW + ks * 16) * PA;                 // halo coords: input row = output row + kernel row
+                const uint2 a0 = lds_tr(ap), a1 = lds_tr(ap + 4 * PA), a2 = lds_tr(ap + 8 * PA);
+                const uint4 dq = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(a0.y, a0.x, 16), __builtin_amdgcn_alignbit(a1.x, a0.y, 16),
+                                            __builtin_amdgcn_alignbit(a1.y, a1.x, 16), __builtin_amdgcn_alignbit(a2.x, a1.y, 16));
+                const uint4 m2 = make_uint4(a0.y, a1.x, a1.y, a2.x);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
-                    const char* ap = s_a + aoff + ((row + kh) * PW + ks * 16) * PA;     // halo coords: input = output + tap
-                    const uint2 a0 = lds_tr(ap), a1 = lds_tr(ap + 4 * PA), a2 = lds_tr(ap + 8 * PA);
-                    const uint4 dq = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                    const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(a0.y, a0.x, 16), __builtin_amdgcn_alignbit(a1.x, a0.y, 16),
-                                                __builtin_amdgcn_alignbit(a1.y, a1.x, 16), __builtin_amdgcn_alignbit(a2.x, a1.y, 16));
-                    const uint4 m2 = make_uint4(a0.y, a1.x, a1.y, a2.x);
+                    const int row = r - kh;
+                    if (row < 0 || row >= THW) continue;
+                    const bf16x8 afrag = __builtin_bit_cast(bf16x8, zf[row][ks]);
                     acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, dq), acc[kh * 3 + 0], 0, 0, 0);
                     acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m1), acc[kh * 3 + 1], 0, 0, 0);
                     acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, __builtin_bit_cast(bf16x8, m2), acc[kh * 3 + 2], 0, 0, 0);
                 }
             }
         }
+        WG_T(0, it, 2);
     }
+    WG_T(0, 63, 0);
     const int li = lane & 31, h = lane >> 5;
     float* out = p.partial + (size_t)blockIdx.x * TAPS * CoutPadW * CinPadW;
 #pragma unroll
@@ -602,6 +639,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             const int ccol = cbase + nb * 32 + li;
             out[((size_t)tap * CoutPadW + nrow) * CinPadW + ccol] = acc[tap][r];
         }
+    WG_T(0, 63, 1);
 }
 
 // 16-channel twin of wgrad_tr_kernel (v_mfma_f32_16x16x32_bf16, K = the 32 pixels of a tile row, one 16x16 block,
@@ -1005,3 +1043,10 @@ int64_t rd_wgrad_ws_bytes(const rd_wgrad_t& p, int dtype) {
     return (int64_t)g.nsplit * p.taps * g.CoutPadW * g.CinPadW * (int64_t)sizeof(float);
 }
 
+
+#ifdef RD_DEBUG_SWITCHES
+extern "C" int rd_debug_wg_trace(int key, unsigned long long* out) {       // debug library only: arm (out == null) or read 2 x 64 x 4 stamps
+    if (!out) return (int)hipMemcpyToSymbol(HIP_SYMBOL(wg_trace_key), &key, sizeof(int));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wg_trace), sizeof(unsigned long long) * 2 * 64 * 4);
+}
+#endif
