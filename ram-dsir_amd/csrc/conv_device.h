@@ -873,17 +873,24 @@ __device__ __forceinline__ void pfu_issue_pre(uint4 (&raw)[NIT][NQ], const Plain
         const int off = min(max(toff + ioff[b], 0), last);
         raw[b][0] = ld16(b0 + off);
         if constexpr (NQ == 2) raw[b][1] = ld16(b1 + off);
+        // the loads stay in ITEM order (and two calls in call order): pfu_consume uses them in that order, and the compiler's wait
+        // counts are only as good as the worst order on any path -- left alone it issued the prologue's two sets newest-first, so the
+        // loop's first use waited for vmcnt(0), i.e. for the set requested one tile ago as well
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <typename T, int NIT, int NQ, typename StoreFn>
+// NOSKIP: every item has an LDS destination (the caller points dead lanes at a dummy record): no divergent branch per item
+template <typename T, int NIT, int NQ, bool NOSKIP = false, typename StoreFn>
 __device__ __forceinline__ void pfu_consume(const uint4 (&raw)[NIT][NQ], const PlainSrc<T>& k, const ItemGeom<NIT>& ig,
                                             int H, int W, int yh, int xh, StoreFn store, int nit = NIT) {
     constexpr int S = Slot<T>::N;
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
         if (b >= nit) break;
-        if (ig.lds[b] < 0) continue;
+        if constexpr (!NOSKIP) {
+            if (ig.lds[b] < 0) continue;
+        }
         const int y = yh + ig.py[b], x = xh + ig.px[b];
         const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         float v[S];
@@ -897,7 +904,15 @@ __device__ __forceinline__ void pfu_consume(const uint4 (&raw)[NIT][NQ], const P
 #pragma unroll
             for (int e = 0; e < S; ++e) v[e] = act_fn(k.sc[e] * v[e] + k.sh[e], k.slope);
         }
-        store(ig.lds[b], in ? Slot<T>::pack(v) : make_uint4(0, 0, 0, 0));
+        // pixels outside the image become zeros by an AND with a per-lane mask, and the mask is laundered through an empty asm:
+        // written as a select, the compiler turns it into a BRANCH around the whole transform (one s_cbranch_execz per item) and,
+        // because the loaded registers are then consumed inside a conditional block, waits for them with vmcnt(0) -- i.e. also for
+        // the set that was requested for the NEXT tile (ISA of wgrad_ws_kernel's loader; scripts/wg_trace.py)
+        unsigned keep = in ? 0xffffffffu : 0u;
+        asm("" : "+v"(keep));
+        uint4 u = Slot<T>::pack(v);
+        u.x &= keep; u.y &= keep; u.z &= keep; u.w &= keep;
+        store(ig.lds[b], u);
     }
 }
 

@@ -415,7 +415,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
     constexpr int CA = 64, CZ = 64, PA = 144, PZ = 144;
     constexpr int NSA = CA / S, NSZ = CZ / S;
     constexpr int NITA = (NPIX * NSA + 255) / 256, NITZ = (THW * TW * NSZ) / 256;
-    constexpr int A_BYTES = (NPIX + 4) * PA, Z_BYTES = THW * TW * PZ, BUF = A_BYTES + Z_BYTES;
+    // each buffer ends in a 4 KB dummy record (16 bytes per loader thread): items of dead lanes (channel slots beyond Cin / Cout, the
+    // last item's pixels beyond the tile) are written THERE, so that the loader's fill has no divergent branch per item
+    constexpr int A_BYTES = (NPIX + 4) * PA, Z_BYTES = THW * TW * PZ, DUMMY = 256 * 16, BUF = A_BYTES + Z_BYTES + DUMMY;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_coef = reinterpret_cast<float*>(smem + 2 * BUF);           // [G][a, z][sc, sh, q][64]: the loader's coefficients
 
@@ -478,14 +480,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             const int pix = tid / NSA + (256 / NSA) * b, py = pix / PW, px = pix - py * PW;
             iga.py[b] = (short)py;
             iga.px[b] = (short)px;
-            iga.lds[b] = (pix < NPIX && live_a) ? pix * PA + sla * 16 : -1;
+            iga.lds[b] = (pix < NPIX && live_a) ? pix * PA + sla * 16 : A_BYTES + Z_BYTES + tid * 16;     // (relative to s_a)
         }
 #pragma unroll
         for (int b = 0; b < NITZ; ++b) {
             const int pix = tid / NSZ + (256 / NSZ) * b;
             igz.py[b] = (short)(pix / TW);
             igz.px[b] = (short)(pix % TW);
-            igz.lds[b] = live_z ? pix * PZ + slz * 16 : -1;
+            igz.lds[b] = live_z ? pix * PZ + slz * 16 : Z_BYTES + tid * 16;                                // (relative to s_z)
         }
         // TWO register sets: the tiles after the next are in flight while the next one is transformed.  (With one set the
         // request went out right before the barrier and was consumed right behind it: as the loader is the slower role the
@@ -534,16 +536,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             char* s_a = smem + (it & 1) * BUF;
             char* s_z = s_a + A_BYTES;
             if constexpr (!(XP & 4)) {
-                pfu_consume<T, NITA, 1>(ra, psa, iga, H, W, y0 - 1, x0 - 1,
+                pfu_consume<T, NITA, 1, true>(ra, psa, iga, H, W, y0 - 1, x0 - 1,
                                         [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
                 if (z_raw && NQZ == 1) {
 #pragma unroll
                     for (int b = 0; b < NITZ; ++b) {
                         const int y = y0 + igz.py[b], x = x0 + igz.px[b];
-                        if (igz.lds[b] >= 0) *reinterpret_cast<uint4*>(s_z + igz.lds[b]) = (y < H && x < W) ? rz[b][0] : make_uint4(0, 0, 0, 0);
+                        *reinterpret_cast<uint4*>(s_z + igz.lds[b]) = (y < H && x < W) ? rz[b][0] : make_uint4(0, 0, 0, 0);
                     }
                 } else {
-                    pfu_consume<T, NITZ, NQZ>(rz, psz, igz, H, W, y0, x0,
+                    pfu_consume<T, NITZ, NQZ, true>(rz, psz, igz, H, W, y0, x0,
                                               [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_z + l) = u; });
                 }
             } else {
@@ -953,7 +955,7 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
         // 64 x 64 blocks, plain sources: the warp-specialised kernel (4-row LDS tiles: twice the tile count)
         static const int ws = rd_switch("RD_WG_WS", 1);
         if (ws && wgrad_pf_ok(p)) {
-            const int ws_lds = 2 * ((6 * PW + 4) * 144 + 4 * TW * 144) + p.G * 2 * 3 * 64 * (int)sizeof(float);
+            const int ws_lds = 2 * ((6 * PW + 4) * 144 + 4 * TW * 144 + 256 * 16) + p.G * 2 * 3 * 64 * (int)sizeof(float);
             const int tiles_ws = p.N * ((p.H + 3) / 4) * ((p.W + TW - 1) / TW);
 #define RD_WGWS_LAUNCH(NQZ, XP) do { \
                 static int attr_lds = 0; \
