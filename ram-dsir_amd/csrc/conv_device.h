@@ -852,25 +852,35 @@ __device__ __forceinline__ void pfu_issue(uint4 (&raw)[NIT][NQ], const PlainSrc<
 }
 
 // pfu_issue for a loader whose items and source are fixed for the whole kernel: the element offset of every item inside an image
-// ((py W + px) C) is computed ONCE; a request is then one add of the tile's (wave-uniform, scalar) offset, one v_med3 that keeps the
-// address inside the image -- items outside it read SOME pixel of the image instead of the clamped one; pfu_consume discards them
-// either way -- and the pointer add.  pfu_issue pays two clamps and two quarter-rate v_mul_lo_u32 per item: 1450 of the 5300
-// cycles a wgrad_ws_kernel loader wave spent per tile (scripts/wg_trace.py).
+// ((py W + px) C) is computed ONCE; a request is then the add of the tile's (wave-uniform, scalar) offset, the move of items
+// outside the image to the clamped pixel by full-rate 24-bit multiplies, one v_med3 that keeps the address inside the image, and the
+// pointer add -- no quarter-rate v_mul_lo_u32 per item as in pfu_issue.
 template <typename T, int NIT>
 __device__ __forceinline__ void pfu_item_offsets(int (&ioff)[NIT], const PlainSrc<T>& k, const ItemGeom<NIT>& ig, int W) {
 #pragma unroll
     for (int b = 0; b < NIT; ++b) ioff[b] = ((int)ig.py[b] * W + (int)ig.px[b]) * k.C;
 }
 template <typename T, int NIT, int NQ>
-__device__ __forceinline__ void pfu_issue_pre(uint4 (&raw)[NIT][NQ], const PlainSrc<T>& k, const int (&ioff)[NIT], int n,
-                                              int H, int W, int yh, int xh) {
+__device__ __forceinline__ void pfu_issue_pre(uint4 (&raw)[NIT][NQ], const PlainSrc<T>& k, const ItemGeom<NIT>& ig, const int (&ioff)[NIT], int n,
+                                              int H, int W, int yh, int xh, bool ghost, bool border) {
     const size_t img = (size_t)(n + k.n_off) * H * W * k.C;
     const T* b0 = k.p0 + img;
     const T* b1 = k.p1 + img;
-    const int toff = (yh * W + xh) * k.C, last = (H * W - 1) * k.C;
+    // a ghost tile (past the end of a workgroup's list: requested so that the loop stays branch-free) reads pixel (0, 0) with
+    // every item -- one cache line, not a tile's worth of traffic
+    const int toff = ghost ? -(1 << 28) : (yh * W + xh) * k.C, last = (H * W - 1) * k.C;
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
-        const int off = min(max(toff + ioff[b], 0), last);
+        // items beyond the RIGHT edge move to the last pixel of their row (a full-rate 24-bit multiply of the distance): left where
+        // they were, the 28 columns that a 100-wide image's last tile column hangs over the edge fetched the NEXT rows' lines instead
+        // of re-reading one -- +9 % FETCH_SIZE on the weight-gradient family (PMC).  The single halo row / column beyond the other
+        // edges reads a neighbouring row's pixels (clamping those too costs the 50 x 50 / 100 x 100 layers 5 % of their time).
+        int adj = 0;
+        if (border) {                                         // wave-uniform: only tiles that hang over the right edge pay for it
+            const int x = xh + (int)ig.px[b];
+            adj = __mul24(min(x, W - 1) - x, k.C);
+        }
+        const int off = min(max(toff + ioff[b] + adj, 0), last);
         raw[b][0] = ld16(b0 + off);
         if constexpr (NQ == 2) raw[b][1] = ld16(b1 + off);
         // the loads stay in ITEM order (and two calls in call order): pfu_consume uses them in that order, and the compiler's wait

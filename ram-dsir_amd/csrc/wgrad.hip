@@ -500,12 +500,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
         auto issue = [&](uint4 (&ra)[NITA][1], uint4 (&rz)[NITZ][NQZ], int tile) {
             int n, y0, x0;
             coords(tile, n, y0, x0);
-            const bool ghost = tile >= total_tiles;           // a ghost re-reads tile 0 (at most two per workgroup; fill() zeroes them)
+            const bool ghost = tile >= total_tiles;           // a ghost reads one line of image 0 (fill() zeroes its buffer)
             n = ghost ? 0 : n;
-            y0 = ghost ? 0 : y0;
-            x0 = ghost ? 0 : x0;
-            pfu_issue_pre<T, NITA>(ra, psa, offa, n, H, W, y0 - 1, x0 - 1);
-            pfu_issue_pre<T, NITZ>(rz, psz, offz, n, H, W, y0, x0);
+            const bool border = x0 + TW + 1 > W;                // the halo tile hangs over the right edge
+            pfu_issue_pre<T, NITA>(ra, psa, iga, offa, n, H, W, y0 - 1, x0 - 1, ghost, border);
+            pfu_issue_pre<T, NITZ>(rz, psz, igz, offz, n, H, W, y0, x0, ghost, border);
         };
         const bool z_raw = p.dz.mode == RD_SRC_RAW;             // a stored dz / dlogits: copied, not transformed
         int g_ctx = -1;
