@@ -192,8 +192,11 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
             for (int b = 0; b < NITV; ++b) {
                 const int y = yh + (iyx[b] >> 16), x = xh + (iyx[b] & 0xffff);
                 const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && live_slot;
-                const uint4 u = transform(kind_c, r[b]);
-                s_in[ilds[b]] = in ? u : make_uint4(0, 0, 0, 0);
+                uint4 u = transform(kind_c, r[b]);
+                unsigned keep = in ? 0xffffffffu : 0u;       // a mask, not a select: no branch around the transform (conv_device.h pfu_consume)
+                asm("" : "+v"(keep));
+                u.x &= keep; u.y &= keep; u.z &= keep; u.w &= keep;
+                s_in[ilds[b]] = u;
             }
         }
     };
