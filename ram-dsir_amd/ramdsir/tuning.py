@@ -9,7 +9,11 @@ DEFAULTS = dict(
     mat_dz_min_c=64,      # store the BN-backward gradient dz once for layers with at least this many channels
     pool_mat=True,        # store the 2x2 max-pool in front of ConvD levels 2-5 once (rd_pool_fwd / rd_pool_bwd)
     fused_bwd=True,       # <= 32-channel 3x3 convs (bf16): dgrad + weight gradient in one launch (csrc/conv_fused.hip)
-    split_wide_dgrad=True,  # a one-chunk gradient launch with 33..64 output channels as two launches of the small-channel kernel
+    split_wide_dgrad=False,  # a one-chunk gradient launch with 33..64 output channels as two launches of the small-channel kernel
+                          # over row blocks of the packed weights (rd_conv_t.w_tap_rows).  A gain (-0.05 ms) while the 64-wide
+                          # conv_pf_kernel's gradient epilogue cost 33 000 cycles per workgroup; since that was fixed (DESIGN.md
+                          # section 7) the ONE 64-wide launch wins: dec.convu1.conv1 dgrad 103 us against 57 + 54, and it reads dz
+                          # once -- step 4.61 -> 4.57 ms (debug library, alternating runs)
     side_streams=1,       # HIP streams for the weight-gradient launches
     rec_cus=-1,           # compute units the restoration-decoder lane's persistent launches may take (0: all, -1: half of
                           # the device = 128 on MI355X, where the numbers below were measured); the lane ends
