@@ -2,7 +2,7 @@
 """bench.py -- images/sec of the full RAM-DSIR training step (RAM FFT + seg on img and img_freq +
 consistency + per-domain rec + backward + Adam) on N MI355X of one node.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus 1 --steps 100 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus N --steps K --warmup W
 
@@ -26,21 +26,30 @@ for p in (ROOT, os.path.join(ROOT, 'ram-dsir_amd')):
 import numpy as np
 import torch
 
-# Kernel families of the step (one entry = one op kind of the launch list, ramdsir/engine.py meta['kernel'], with the kernel
-# symbols rocprofv3 reports for it).  `roofline` is the family with the largest share of the summed kernel time in the
-# committed profile of this command (profiles/r03_bench_kernel_stats.csv; scripts/pmc_traffic.py prints the shares), the
-# other families are reported beside it as roofline_<name>:
-#   bwd_fused  round 3: dgrad + weight gradient of the <= 32-channel 3x3 convs in one launch (csrc/conv_fused.hip), HBM-bound
+# Kernel families of the step (one entry = launches of the list selected by `match` on ramdsir/engine.py's meta, with the kernel
+# symbols rocprofv3 reports for them; `count` = the symbols that count as ONE launch where a launch is two kernels):
+#   bwd_fused  dgrad + weight gradient of the <= 32-channel 3x3 convs in one launch (csrc/conv_fused.hip), HBM-bound
 #   conv64     3x3 convs on 64-wide output-channel tiles (conv_ws_kernel + conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> + conv_pp_kernel), MFMA-bound
-#   wgrad      the remaining stand-alone weight gradients (>= 64-channel layers, 1x1 convs, the first conv): MFMA kernel + split reduce
+#   wgrad      the stand-alone weight gradients (>= 64-channel layers, 1x1 convs, the first conv): MFMA kernel + split reduce
+#   conv_small forward (and the few unfused gradient) launches of the <= 32-channel convs (conv_small_fwd_kernel / conv_small_kernel), HBM-bound
+#   ram        Random Amplitude Mixup: rd_ram_mix = row FFT + column FFT / window mix / inverse column FFT + inverse row FFT (3 kernels), HBM-bound
+# The HEADLINE `roofline` is not a constant: bench.py times the step with each of the three families that hold the most kernel time
+# left out (scripts/ablate_step.py's measurement, inside this run) and headlines the one whose absence shortens the step most
+# (`dominant_by_step_cost`); `dominant_by_kernel_time` is reported beside it.  The other families follow as roofline_<name>.
 FAMILIES = {
-    'bwd_fused': dict(kernel='conv_small_bwd_fused', symbols=('conv_small_bwd_fused_kernel',), count=None),
-    'conv64': dict(kernel='conv_kernel<bf16,9,2>',
+    'bwd_fused': dict(match=lambda m: m.get('kernel') == 'conv_small_bwd_fused', symbols=('conv_small_bwd_fused_kernel',), count=None),
+    'conv64': dict(match=lambda m: m.get('kernel') == 'conv_kernel<bf16,9,2>',
                    symbols=('conv_ws_kernel', 'conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel'), count=None),
-    'wgrad': dict(kernel='wgrad', symbols=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel'),
+    'wgrad': dict(match=lambda m: m.get('kernel') == 'wgrad',
+                  symbols=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel'),
                   count=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel')),
+    'conv_small': dict(match=lambda m: str(m.get('kernel', '')).startswith('conv_small_kernel'),
+                       symbols=('conv_small_fwd_kernel', 'conv_small_kernel'), count=None),
+    'ram': dict(match=lambda m: m.get('kernel') == 'ram', symbols=('ram_row_fwd_kernel', 'ram_col_mix_kernel', 'ram_row_inv_kernel'),
+                count=('ram_row_fwd_kernel',)),
 }
-DOMINANT = 'wgrad'
+PMC_JSON = os.path.join(ROOT, 'profiles', 'dominant_kernel_pmc.json')
+SQ_JSON = os.path.join(ROOT, 'profiles', 'r04_mfma_busy.json')
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_COPY_GBS = 5300.0                    # what a plain torch copy (read + write) sustains on this part: profiles/r03_hbm_ceiling.txt
 MFMA_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF (no sparsity)
@@ -84,19 +93,26 @@ def init_weights(bank):
             v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * bound).to(v.device))
 
 
+def _pmc_json():
+    if not os.path.exists(PMC_JSON):
+        return {}
+    with open(PMC_JSON) as f:
+        return json.load(f)
+
+
 def kernel_roofline(ts, fam, eager=True):
     """One more step, launched exactly like the timed ones (eager: weight-gradient kernels on the side stream and the
     restoration-decoder branch on its own stream, so the timed launches see the same contention), with HIP events
-    recorded on the stream each launch goes to around every launch of the dominant kernel family; the algorithmic
-    bytes / flops of each launch come from its descriptor (engine.Plan._conv_meta)."""
-    family = FAMILIES[fam]['kernel']
+    recorded on the stream each launch goes to around every launch of the kernel family; the algorithmic
+    bytes / flops of each launch come from its descriptor (engine.Plan._conv_meta, ram.RamMixer.op)."""
+    match = FAMILIES[fam]['match']
     main = torch.cuda.current_stream()
     ts.zero()
     evs, acc = [], dict(nbytes=0, flops=0)
 
     def wrap(op, stream, launch):
         meta = op[2] if len(op) > 2 else None
-        if meta is None or meta.get('kernel') != family:
+        if not meta or not match(meta):
             return launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -122,38 +138,73 @@ def kernel_roofline(ts, fam, eager=True):
     # FETCH_SIZE / WRITE_SIZE passes) on this command, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for
     # 16-B/lane streaming reads, KB -> B); `traffic_source` names the file, profiles/README.md the procedure
     traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'dominant_kernel_pmc.json')
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        collected = tj.get('collected', 'rocprofv3 PMC, offline')
-        tj = tj.get(fam, {})
-        if tj.get('family') == fam and 'traffic_bytes_per_launch' in tj:
-            traffic = int(tj['traffic_bytes_per_launch'])
-            traffic_source = 'profiles/dominant_kernel_pmc.json (%s)' % collected
+    tj = _pmc_json()
+    collected = tj.get('collected', 'rocprofv3 PMC, offline')
+    tj = tj.get(fam, {})
+    if tj.get('family') == fam and 'traffic_bytes_per_launch' in tj:
+        traffic = int(tj['traffic_bytes_per_launch'])
+        traffic_source = 'profiles/dominant_kernel_pmc.json (%s)' % collected
     if intensity >= ridge:
         out = dict(bound='mfma', achieved=round(tfs, 1), peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tfs / MFMA_PEAK_TFLOPS, 4))
     else:
         out = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
                    frac_of_copy_rate=round(gbs / HBM_COPY_GBS, 4))    # beside the spec: the rate streaming kernels reach in practice
-    out.update(traffic=traffic, traffic_source=traffic_source, kernel=family, family=fam, launches_per_step=n, avg_launch_us=round(total_ms * 1e3 / n, 1),
+    out.update(traffic=traffic, traffic_source=traffic_source, family=fam, kernels=' + '.join(FAMILIES[fam]['symbols']), launches_per_step=n,
+               avg_launch_us=round(total_ms * 1e3 / n, 1), step_kernel_us=round(total_ms * 1e3, 1),
                avg_algorithmic_bytes=int(nbytes / n), avg_flops=int(flops / n), flop_per_byte=round(intensity, 1),
                achieved_gbs=round(gbs, 1), achieved_tflops=round(tfs, 1))
+    if traffic:
+        out['traffic_over_algorithmic'] = round(traffic / (nbytes / n), 3)
     return out
 
 
 def mfma_busy(fam):
-    """MFMA utilisation of a kernel family from the committed SQ-counter summary (scripts/pmc_step.py + scripts/pmc_agg.py ->
-    profiles/r03_mfma_busy.json): SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles).  Like `traffic`: collected with rocprofv3
+    """MFMA utilisation of a kernel family from the committed SQ-counter summary (scripts/collect_sq.sh -> scripts/mfma_busy.py ->
+    profiles/r04_mfma_busy.json): SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles).  Like `traffic`: collected with rocprofv3
     around this workload, not inside this run."""
-    path = os.path.join(ROOT, 'profiles', 'r03_mfma_busy.json')
-    if not os.path.exists(path):
+    if not os.path.exists(SQ_JSON):
         return None
-    with open(path) as f:
+    with open(SQ_JSON) as f:
         j = json.load(f)
     if fam not in j:
         return None
-    return dict(mfma_busy=j[fam]['mfma_busy'], mfma_busy_source='profiles/r03_mfma_busy.json (%s)' % j.get('collected', 'rocprofv3 SQ counters, offline'))
+    src = '%s (%s)' % (os.path.relpath(SQ_JSON, ROOT), j.get('collected', 'rocprofv3 SQ counters, offline'))
+    out = dict(mfma_busy=j[fam]['mfma_busy'], mfma_busy_source=src)
+    if 'lds_conflict_ratio' in j[fam]:
+        out['lds_conflict_ratio'] = j[fam]['lds_conflict_ratio']        # SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+    return out
+
+
+def time_steps(step, n, warm=3):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def step_cost_by_ablation(ts, fams, steps=20):
+    """What a family costs THE STEP (scripts/ablate_step.py inside the bench run): the step is timed with that family's launches left
+    out of the launch list (three streams, as the timed region runs it).  The skipped kernels' outputs keep the values of the last
+    complete step, so the remaining kernels run on realistic data -- the ablated steps compute nothing meaningful, only their
+    duration is used; this therefore runs AFTER everything that reads the state.  Returns {family: ms the step gets shorter}."""
+    full = (list(ts.seg_a), list(ts.seg_b), list(ts.seg_c))
+    out = {}
+    try:
+        base = time_steps(ts.run_eager, steps)
+        for fam in fams:
+            match = FAMILIES[fam]['match']
+            keep = lambda op: op[0] is None or len(op) < 3 or not match(op[2])
+            ts.seg_a, ts.seg_b, ts.seg_c = ([op for op in seg if keep(op)] for seg in full)
+            out[fam] = round(base - time_steps(ts.run_eager, steps), 3)
+            ts.seg_a, ts.seg_b, ts.seg_c = full
+        base2 = time_steps(ts.run_eager, steps)
+    finally:
+        ts.seg_a, ts.seg_b, ts.seg_c = full
+    return out, round(base, 3), round(base2, 3)
 
 
 def cpu_baseline(host_inputs, bs):
@@ -248,22 +299,33 @@ def whole_step_roofline(B, Sz, ms_per_step, dtype):
     nbytes = B * (3 * 170.3e6 * esz * sc + 12 * 3 * Sz * Sz)
     flops = B * 170.9e9 * sc
     t = ms_per_step * 1e-3
-    return dict(algorithmic_gbs=round(nbytes / t / 1e9, 1), hbm_frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
-                algorithmic_tflops=round(flops / t / 1e12, 1), mfma_frac=round(flops / t / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                bytes_per_image=int(nbytes / B), flops_per_image=int(flops / B))
+    out = dict(algorithmic_gbs=round(nbytes / t / 1e9, 1), hbm_frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+               algorithmic_tflops=round(flops / t / 1e12, 1), mfma_frac=round(flops / t / 1e12 / MFMA_PEAK_TFLOPS, 4),
+               bytes_per_image=int(nbytes / B), flops_per_image=int(flops / B), algorithmic_bytes_per_step=int(nbytes))
+    # HBM bytes of EVERY kernel of one step from the PMC passes (scripts/pmc_traffic.py: sum over all dispatches of the profiled
+    # bench run / steps profiled), only for the workload the passes were collected on
+    st = _pmc_json().get('step', {})
+    if st.get('size') == Sz and st.get('dtype') == dtype and st.get('batch') == B and 'traffic_bytes_per_step' in st:
+        out.update(traffic=int(st['traffic_bytes_per_step']), traffic_over_algorithmic=round(st['traffic_bytes_per_step'] / nbytes, 3),
+                   traffic_gbs=round(st['traffic_bytes_per_step'] / t / 1e9, 1),
+                   traffic_source='profiles/dominant_kernel_pmc.json (%s)' % _pmc_json().get('collected', ''))
+    else:
+        out.update(traffic=None)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--size', type=int, default=400)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--graph', action='store_true', help='replay one captured hipGraph per step instead of the 3-stream eager launch (slower on ROCm 7: DESIGN.md section 3)')
     ap.add_argument('--no-graph', action='store_true', help='(default; kept for older command lines)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-leg', action='store_true')
+    ap.add_argument('--no-ablation', action='store_true', help='skip the in-run ablation that picks the headline roofline family')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -349,17 +411,30 @@ def main():
         }
         out['roofline_step'] = whole_step_roofline(B, Sz, out['ms_per_step'], args.dtype)
         if args.dtype == 'bf16':
+            roofs = {}
             for fam in FAMILIES:
-                key = 'roofline' if fam == DOMINANT else 'roofline_' + fam
-                out[key] = kernel_roofline(ts, fam, eager=not args.graph)
+                roofs[fam] = kernel_roofline(ts, fam, eager=not args.graph)
                 if not args.graph:
                     # the same launches on ONE stream (nothing beside them): what the kernels do when they have the GPU to
                     # themselves, next to the headline figures above, which are measured under the step's three-stream contention
                     a = kernel_roofline(ts, fam, eager=False)
-                    out[key]['alone'] = {k: a[k] for k in ('achieved', 'unit', 'frac', 'avg_launch_us')}
-            mb = mfma_busy('conv64')
-            if mb is not None:
-                out['roofline' if DOMINANT == 'conv64' else 'roofline_conv64'].update(mb)
+                    roofs[fam]['alone'] = {k: a[k] for k in ('achieved', 'unit', 'frac', 'avg_launch_us')}
+                mb = mfma_busy(fam)
+                if mb is not None:
+                    roofs[fam].update(mb)
+            # which family is the headline: the three with the most kernel time inside the step, each left out of the step in turn
+            by_time = sorted(roofs, key=lambda f: -roofs[f]['step_kernel_us'])
+            out['dominant_by_kernel_time'] = {'family': by_time[0], 'step_kernel_us': {f: roofs[f]['step_kernel_us'] for f in by_time}}
+            dominant = by_time[0]
+            if not args.graph and runner is None and not args.no_ablation:
+                cost, base, base2 = step_cost_by_ablation(ts, by_time[:3])
+                dominant = max(cost, key=lambda f: cost[f])
+                out['dominant_by_step_cost'] = {'family': dominant, 'step_ms_saved_without': cost, 'complete_step_ms': [base, base2],
+                                                'method': 'step timed (20 steps, 3 streams) with the family\'s launches left out'}
+                for f in cost:
+                    roofs[f]['step_cost_ms'] = cost[f]
+            for fam, r in roofs.items():
+                out['roofline' if fam == dominant else 'roofline_' + fam] = r
         if world == 1 and args.dtype == 'bf16' and not args.no_fp32_leg:
             out['extra'] = {'fp32': fp32_leg(params0, bs, Sz, dev, src, trg, lam, mask)}
         if world == 1 and not args.no_cpu_baseline:

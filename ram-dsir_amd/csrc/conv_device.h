@@ -15,8 +15,20 @@ constexpr int TH = 8, TW = 32;
 // 22-39 % of the MFMA lanes on pixels outside the image (100 -> 4 x 32 columns, 50 -> 2 x 32, 25 -> 32).  Shape 1 flattens the
 // 256 lanes over a 10 x 25 rectangle (pixel j = 32 m + li -> row j / 25, column j % 25; 250 of 256 lanes live): sides 25, 50, 100
 // and 200 are covered exactly in x and within 0-20 % in y, with a halo tile (12 x 27) that is no larger than shape 0's (10 x 34).
-template <int TS> struct TileGeo { static constexpr int H = 8, W = 32; };
-template <> struct TileGeo<1> { static constexpr int H = 10, W = 25; };
+// LdsPitch: row pitch (pixels) of the halo tile in LDS.  The MFMA fragment reads (ds_read_b128, serviced in 16-lane groups over a
+// 256-byte bank row = 16 pixel entries of one channel slot) are conflict-free when the 16 lanes of a group read pixels that are
+// distinct mod 16.  Shape 0: lane li reads pixel base + li of one tile row -- consecutive.  Shape 1: the 32 lanes of an M-block
+// straddle one or two row breaks, and with the natural pitch 27 the lanes behind a break land 2 entries further on, on the entries
+// of two other lanes of their group (2-way conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.20-0.31 in the round-3 counters of
+// every kernel that ran shape 1).  Pitch 41 = 25 + 16 makes the pixel index of lane j equal to j + 16 * row: distinct mod 16 again.
+template <int TS> struct TileGeo {
+    static constexpr int H = 8, W = 32;
+    static constexpr int LdsPitch(int halo) { return W + 2 * halo; }
+};
+template <> struct TileGeo<1> {
+    static constexpr int H = 10, W = 25;
+    static constexpr int LdsPitch(int halo) { return halo ? W + 16 : W; }
+};
 
 template <int TS>
 __device__ __forceinline__ void tile_pixel(int mblock, int li, int& r, int& c, bool& live) {

@@ -11,7 +11,7 @@ namespace {
 template <typename T, int TAPS, int NB, bool SWAP = false, int TS = 0>
 __device__ __forceinline__ void conv_mma_chunk(const uint4* s_in, const uint4* s_w, int wave, int li, int h, f32x16 (&acc)[2][NB]) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    constexpr int PW = TileGeo<TS>::W + 2 * HALO;
+    constexpr int PW = TileGeo<TS>::LdsPitch(HALO);        // LDS row pitch of the halo tile (conv_device.h)
     constexpr int NT = NB * 32;
     int pr[2], pc[2];                                      // this lane's tile pixel of its two M-blocks
 #pragma unroll
@@ -72,12 +72,13 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int TH = TileGeo<TS>::H, TW = TileGeo<TS>::W;     // (shadow the 8 x 32 globals)
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int PWL = TileGeo<TS>::LdsPitch(HALO);       // row pitch of the halo tile IN LDS (>= PW; conv_device.h TileGeo)
     constexpr int NT = NB * 32;
     constexpr int NIT = (PH * PW + 63) / 64;               // halo pixels per thread (fixed channel slot tid & 3)
     constexpr int WTOT = TAPS * NT * 4, WIT = (WTOT + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint4* s_in = reinterpret_cast<uint4*>(smem);          // [PH*PW][4]
-    uint4* s_w = s_in + PH * PW * 4;                       // [TAPS][NT][4]
+    uint4* s_in = reinterpret_cast<uint4*>(smem);          // [PH*PWL][4]
+    uint4* s_w = s_in + PH * PWL * 4;                      // [TAPS][NT][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
             const int pix = (tid >> 2) + 64 * b, py = pix / PW, px = pix - py * PW;
             ig.py[b] = (short)py;
             ig.px[b] = (short)px;
-            ig.lds[b] = pix < PH * PW ? pix * 4 + (s ^ ((pix >> 2) & 3)) : -1;
+            const int lp = py * PWL + px;                  // the pixel's LDS record
+            ig.lds[b] = pix < PH * PW ? lp * 4 + (s ^ ((lp >> 2) & 3)) : -1;
         }
     };
     const T* wbase = reinterpret_cast<const T*>(p.w);
@@ -232,7 +234,7 @@ template <int TAPS, int NB, int TS = 0>
 inline size_t conv_pf_lds(const rd_conv_t& p) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int TH = TileGeo<TS>::H, TW = TileGeo<TS>::W;
-    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int PH = TH + 2 * HALO, PW = TileGeo<TS>::LdsPitch(HALO);
     size_t lds = (size_t)(PH * PW * 4 + TAPS * NB * 32 * 4) * sizeof(uint4) + (size_t)3 * p.CinPad * sizeof(float) + (size_t)2 * NB * 32 * sizeof(float);
     const size_t lds_epi = (size_t)TH * TW * 32 * sizeof(float) + 64 * sizeof(double);
     return lds < lds_epi ? lds_epi : lds;

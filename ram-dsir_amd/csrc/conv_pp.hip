@@ -325,7 +325,22 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
 // The loader's per-item cost is what bounds a step (s_memtime traces, scripts/ws_trace.py), so it is kept lean: halo
 // offsets and bounds are computed once per TILE, the affine runs as v_pk_fma_f32, ReLU as v_pk_max_i16 on the packed
 // bf16 pair (identical to ReLU before the rounding), raw sources are copied without touching the VALU.
-constexpr int WS_TAB = PP_EPI;                               // MODE 1: bias [CoutPad]; MODE 2: [G][2][CoutPad] producer scale | shift
+// LDS map of conv_ws_kernel: two input buffers of four planes [slot][halo pixel at row pitch PL], two weight buffers (the planes of
+// conv_pp_kernel), TAB (MODE 1: bias [CoutPad]; MODE 2: [G][2][CoutPad] producer scale | shift), the channel-slot table.
+// Shape 1 (10 x 25 tiles) stores its 12 x 27 halo tile at pitch 41 (conv_device.h TileGeo::LdsPitch: the fragment reads of an MFMA
+// row block that straddles tile rows stay conflict-free); the room comes from the staged-epilogue area this kernel never had a use for.
+template <int TS> struct WsLds {
+    static constexpr int PL = TileGeo<TS>::LdsPitch(1);
+    static constexpr int NENT = (TileGeo<TS>::H + 2) * PL;                 // entries per plane (+ 4 dummies: stores of non-items)
+    static constexpr int PLANE_A = (NENT + 4) * 16 + 32;
+    static constexpr int IN_BYTES = 4 * PLANE_A;
+    static constexpr int W0 = 2 * IN_BYTES;
+    static constexpr int TAB = W0 + 2 * PP_W_BYTES;
+    static constexpr int TAB_BYTES = 16 * 1024;
+    static constexpr int SLOTS = TAB + TAB_BYTES;
+    static constexpr int LDS = SLOTS + PP_MAX_CHUNKS * 4 * 48;
+};
+static_assert(WsLds<0>::LDS <= 160 * 1024 && WsLds<1>::LDS <= 160 * 1024, "conv_ws_kernel: LDS map exceeds the CU");
 #ifdef RD_DEBUG_SWITCHES
 __device__ unsigned long long ws_trace[2][64][4];          // [role][step][event] shader-clock stamps of workgroup 5 (debug build)
 #define WS_T(role, s, ev) do { if (trace_ && blockIdx.x == 5 && tid == 0 && (s) < 63) ws_trace[role][s][ev] = __builtin_readcyclecounter(); } while (0)
@@ -346,7 +361,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     // TS 1: 10 x 25 pixel tiles, flattened row-major onto the 256 MFMA rows (250 live); the 12 x 27 halo tile fits the planes of
     // the 10 x 34 one, only the per-lane pixel of an MFMA row and the halo row pitch change
     constexpr int THt = TileGeo<TS>::H, TWt = TileGeo<TS>::W, PWt = TWt + 2, NPIXt = (THt + 2) * PWt;
-    static_assert(NPIXt <= PP_NPIX && 64 * PP_NIT >= NPIXt, "halo tile must fit the LDS planes");
+    static_assert(64 * PP_NIT >= NPIXt, "one halo item per thread and pass");
+    // this kernel's own LDS map (WsLds<TS>): the planes hold the halo tile at the conflict-free row pitch of its shape
+    typedef WsLds<TS> LM;
+    constexpr int PLt = LM::PL, WS_PLANE_A = LM::PLANE_A, WS_IN_BYTES = LM::IN_BYTES, WS_W0 = LM::W0, WS_TAB = LM::TAB, WS_SLOTS = LM::SLOTS;
     // who stages the weight chunk of the next step: the MFMA waves in the forward mode (they have ~1.5 issue slots per MFMA
     // gap to spare and 36 registers of headroom; the loader's nine weight vectors cost 1000-3000 cycles per step on top of
     // its ~3000 for the halo items against ~3300 of MFMAs: traces in profiles/r02_ws_trace.txt), the loader waves in the
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         e.g_fixed = rawm ? 0 : sd.g_fixed;
         e.flags = (live ? 1 : 0) | (rawm ? 2 : 0);
         e.pad_ = 0;
-        reinterpret_cast<PpSlot*>(smem + PP_TAB)[t] = e;
+        reinterpret_cast<PpSlot*>(smem + WS_SLOTS)[t] = e;
     }
     {
         float* tab = reinterpret_cast<float*>(smem + WS_TAB);
@@ -426,9 +444,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             const int pix = (tid >> 2) + 64 * b;
             const int py = pix / PWt;
             it_yx[b] = (py << 16) | (pix - py * PWt);
-            it_lds[b] = sw * PP_PLANE_A + (pix < NPIXt ? pix : PP_NPIX) * 16;
+            it_lds[b] = sw * WS_PLANE_A + (pix < NPIXt ? py * PLt + (pix - py * PWt) : LM::NENT) * 16;
         }
-        const int w_lds = PP_W0 + sw * PP_PLANE_W + nn_w * 16;
+        const int w_lds = WS_W0 + sw * PP_PLANE_W + nn_w * 16;
         const T* wbase = reinterpret_cast<const T*>(p.w) + nn_w * 32 + sw * S;
         const size_t w_tap = (size_t)p.CoutPad * 32;            // elements between the taps of one chunk
         uint4 raw[PP_NIT] = {}, wr[PP_WIT] = {};
@@ -454,7 +472,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         };
         int maskL = 0;
         auto begin_issue = [&]() {
-            const PpSlot e = reinterpret_cast<const PpSlot*>(smem + PP_TAB)[L.c * 4 + sw];
+            const PpSlot e = reinterpret_cast<const PpSlot*>(smem + WS_SLOTS)[L.c * 4 + sw];
             const bool live = (e.flags & 1) != 0, rawm = (e.flags & 2) != 0;
             maskL = live ? inL : 0;
             ldC = e.C;
@@ -493,7 +511,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                 u = Slot<T>::pack(v);
             }
             const bool in = ((maskC >> b) & 1) != 0;
-            *reinterpret_cast<uint4*>(smem + par * PP_IN_BYTES + it_lds[b]) = in ? u : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(smem + par * WS_IN_BYTES + it_lds[b]) = in ? u : make_uint4(0, 0, 0, 0);
         };
         auto consume_w = [&](int t, int par) {
             *reinterpret_cast<uint4*>(smem + par * PP_W_BYTES + w_lds + t * (PP_NT * 16)) = wr[t];
@@ -563,9 +581,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         tile_pixel<TS>(wave * 2 + mb, li, px_r[mb], px_c[mb], px_live[mb]);
-        a_off[mb] = h * PP_PLANE_A + (px_r[mb] * PWt + px_c[mb]) * 16;
+        a_off[mb] = h * WS_PLANE_A + (px_r[mb] * PLt + px_c[mb]) * 16;
     }
-    const int b_base = PP_W0 + h * PP_PLANE_W + li * 16;
+    const int b_base = WS_W0 + h * PP_PLANE_W + li * 16;
     const float* tab = reinterpret_cast<const float*>(smem + WS_TAB);
     PpStage M;
     M.tile = tile_begin;
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     uint4 wq[PP_WIT] = {};
     PpStage Lw = M;                                        // the step whose weights are in flight
     const int sw_w = tid & 3, nn_w = tid >> 2;
-    const int w_lds = PP_W0 + sw_w * PP_PLANE_W + nn_w * 16;
+    const int w_lds = WS_W0 + sw_w * PP_PLANE_W + nn_w * 16;
     const T* wbase = reinterpret_cast<const T*>(p.w) + nn_w * 32 + sw_w * S;
     const size_t w_tap = (size_t)p.CoutPad * 32;
     auto w_issue = [&](int t) { wq[t] = ld16(wbase + ((size_t)(Lw.c * 9) * p.CoutPad + Lw.n0) * 32 + t * w_tap); };
@@ -597,10 +615,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     auto load_group = [&](int grp, int par, Frag& f) {
         const int tap = grp >> 1, ks = grp & 1;
         const int kh = tap / 3, kw = tap - 3 * kh;
-        const char* s_a = smem + par * PP_IN_BYTES + ks * 2 * PP_PLANE_A;
+        const char* s_a = smem + par * WS_IN_BYTES + ks * 2 * WS_PLANE_A;
         const char* s_b = smem + par * PP_W_BYTES + b_base + ks * 2 * PP_PLANE_W;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) f.a[mb] = *reinterpret_cast<const uint4*>(s_a + a_off[mb] + (kh * PWt + kw) * 16);
+        for (int mb = 0; mb < 2; ++mb) f.a[mb] = *reinterpret_cast<const uint4*>(s_a + a_off[mb] + (kh * PLt + kw) * 16);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) f.b[nb] = *reinterpret_cast<const uint4*>(s_b + (tap * PP_NT + nb * 32) * 16);
     };
@@ -845,10 +863,10 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     if (!n_cu) {
         n_cu = rd_num_cus();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<0>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<0>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<1>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<1>::LDS);
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / PP_NT);
     const int cus = (p.cu_limit > 0 && p.cu_limit < n_cu) ? p.cu_limit : n_cu;     // a side lane's budget (ramdsir.h)
@@ -866,7 +884,7 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     static const int ws = rd_switch("RD_CONV_WS", 3), ws_min2 = rd_switch("RD_CONV_WS_MIN2", 1 << 30);
     const int mode = rd_conv_lean_mode(p, PP_NT);
     const size_t tab = (size_t)(mode == 1 ? 1 : 2 * p.G) * p.CoutPad * sizeof(float);
-    if (mode && (ws & mode) && (mode == 1 || tiles >= ws_min2) && tab <= (size_t)PP_EPI_BYTES) {
+    if (mode && (ws & mode) && (mode == 1 || tiles >= ws_min2) && tab <= (size_t)WsLds<0>::TAB_BYTES) {
         // debug build only: RD_CONV_WS_EXP = timing experiments (-DRD_WS_EXP), RD_CONV_WS_TRACE_MIN = launches with at least
         // that many tiles record the s_memtime trace (scripts/ws_trace.py); both ride in the high bits of the tile count
         static const int ws_exp = rd_switch("RD_CONV_WS_EXP", 0), ws_trace_min = rd_switch("RD_CONV_WS_TRACE_MIN", 1 << 30);
@@ -880,11 +898,11 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         const int nt = flat ? tiles1 : tiles, grid_ws = nt < cus ? nt : cus;
         const int arg = nt | (ws_exp << 26) | (tiles >= ws_trace_min ? 1 << 25 : 0);
         if (mode == 1) {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1>), dim3(grid_ws), dim3(512), PP_LDS, st, p, arg);
-            else hipLaunchKernelGGL((conv_ws_kernel<1, 0>), dim3(grid_ws), dim3(512), PP_LDS, st, p, arg);
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
+            else hipLaunchKernelGGL((conv_ws_kernel<1, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
         } else {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1>), dim3(grid_ws), dim3(512), PP_LDS, st, p, arg);
-            else hipLaunchKernelGGL((conv_ws_kernel<2, 0>), dim3(grid_ws), dim3(512), PP_LDS, st, p, arg);
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
+            else hipLaunchKernelGGL((conv_ws_kernel<2, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
         }
         return (int)hipGetLastError();
     }

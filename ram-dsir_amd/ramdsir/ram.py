@@ -60,12 +60,17 @@ class RamMixer:
         self._keep = (src, trg, lam, out_img, out_freq, trg_amp)
 
     def op(self):
-        return (L.lib().rd_ram_mix, (C.byref(self.p), self.dt))
+        # meta for bench.py's family table: algorithmic bytes by SURVEY.md 8(d)'s convention = source + partner + output once as
+        # fp32, 12 * C * H * W per image (the uint8 pipeline reads less and the bf16 output writes less; the convention is kept so
+        # that the figure is comparable with the reference's numpy path, code/dataset/fundus.py:13-61); ~62 MFLOP per 400 x 400 image
+        return (L.lib().rd_ram_mix, (C.byref(self.p), self.dt),
+                dict(kernel='ram', what='mix', layer='ram', bytes=12 * 3 * self.H * self.W * self.B,
+                     flops=int(62e6 * self.H * self.W / 160000.0) * self.B))
 
     def run(self, stream=None):
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
-        fn, args = self.op()
+        fn, args = self.op()[:2]
         L.check(fn(*args, stream), 'rd_ram_mix')
 
 

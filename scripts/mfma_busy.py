@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as Bn
 d = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else 'r03'
+tag = sys.argv[2] if len(sys.argv) > 2 else 'r04'
 # the counter passes are separate runs of the same launch list (dispatch ids can shift between them): aggregate per
 # (kernel, grid, workgroup size) and counter, then combine the per-dispatch MEANS
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -22,6 +22,7 @@ out = {'collected': 'rocprofv3 -i scripts/pmc_sq.txt on scripts/pmc_step.py bf16
 mean = lambda v: sum(v) / len(v)
 for fam, spec in Bn.FAMILIES.items():
     busy = cyc = occ = n = 0.0
+    conf = ldsact = 0.0
     for (name, grid, wgs), c in acc.items():
         if not any(DEM.get(s, s) in name for s in spec['symbols']):
             continue
@@ -34,7 +35,12 @@ for fam, spec in Bn.FAMILIES.items():
         cyc += k * 1024.0 * kc
         occ += k * 4.0 * cus * kc
         n += k
+        if 'SQ_LDS_BANK_CONFLICT' in c and 'SQ_LDS_IDX_ACTIVE' in c:
+            conf += k * mean(c['SQ_LDS_BANK_CONFLICT'])
+            ldsact += k * mean(c['SQ_LDS_IDX_ACTIVE'])
     if n:
         out[fam] = dict(mfma_busy=round(busy / cyc, 4), mfma_busy_occupied=round(busy / occ, 4), dispatches=int(n))
+        if ldsact:
+            out[fam]['lds_conflict_ratio'] = round(conf / ldsact, 4)          # SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 json.dump(out, open(os.path.join(ROOT, 'profiles', tag + '_mfma_busy.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))

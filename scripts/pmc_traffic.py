@@ -47,6 +47,23 @@ for fam, spec in FAMILIES.items():
         'fetch_size_kb_per_launch': fk, 'write_size_kb_per_launch': wk, 'traffic_bytes_per_launch': (2 * fk + wk) * 1024,
         'rocprof_avg_launch_us': tot / calls / 1e3, 'rocprof_launches': calls, 'rocprof_share_percent': 100.0 * tot / total_ns,
     }
+# ---- every kernel of a step: HBM bytes of all dispatches of the library's kernels (torch's allocation fills excluded: they run once,
+# before the first step) divided by the number of steps the profiled command ran (= dispatches of the once-per-step Adam kernel)
+ours = lambda n: not n.startswith('_ZN2at') and 'at::native' not in n
+nsteps = {c: sum(1 for r in pmc_rows if r['Counter_Name'] == c and 'adam_update_kernel' in r['Kernel_Name']) for c in ('FETCH_SIZE', 'WRITE_SIZE')}
+tot_kb = {c: sum(float(r['Counter_Value']) for r in pmc_rows if r['Counter_Name'] == c and ours(r['Kernel_Name'])) for c in ('FETCH_SIZE', 'WRITE_SIZE')}
+if min(nsteps.values()) > 0:
+    fk, wk = tot_kb['FETCH_SIZE'] / nsteps['FETCH_SIZE'], tot_kb['WRITE_SIZE'] / nsteps['WRITE_SIZE']
+    bl = json.loads(line)
+    per_kernel = {}
+    for r in pmc_rows:
+        if ours(r['Kernel_Name']):
+            k = r['Kernel_Name'].split('(')[0][:60]
+            per_kernel.setdefault(k, {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})[r['Counter_Name']] += float(r['Counter_Value'])
+    top = sorted(per_kernel.items(), key=lambda kv: -(2 * kv[1]['FETCH_SIZE'] / nsteps['FETCH_SIZE'] + kv[1]['WRITE_SIZE'] / nsteps['WRITE_SIZE']))[:12]
+    out['step'] = {'steps_profiled': nsteps['FETCH_SIZE'], 'fetch_size_kb_per_step': fk, 'write_size_kb_per_step': wk,
+                   'traffic_bytes_per_step': (2 * fk + wk) * 1024, 'size': 400, 'dtype': bl.get('dtype'), 'batch': bl['config']['global_batch'] // bl['n_gpus'],
+                   'top_kernels_mb_per_step': {k: round((2 * v['FETCH_SIZE'] / nsteps['FETCH_SIZE'] + v['WRITE_SIZE'] / nsteps['WRITE_SIZE']) / 1024, 1) for k, v in top}}
 out['collected'] = 'rocprofv3 PMC passes of scripts/collect_profiles.sh, tag %s' % tag
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'dominant_kernel_pmc.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
