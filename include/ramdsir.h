@@ -375,6 +375,41 @@ int rd_ram_amp(const float* img_chw, float* amp_chw, int C, int H, int W, void* 
                void* stream);
 int rd_ram_mutate(const float* amp_src, const float* amp_trg, float* out, int C, int H, int W, int b, float lam, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Launch lists.  The training step (code/train.py:225-296) is ~250 calls of the entry points above over three HIP streams; issued
+ * one by one from the interpreter (a ctypes call + an event record / stream wait per fork) they cost the host 2.2 ms per 4.4 ms step.
+ * rd_run_list walks a prepared list in C++: one call per step segment.
+ *   op      which entry point (RD_OP_*), or RD_OP_FORK / RD_OP_JOIN;
+ *   a[]     its arguments in declaration order WITHOUT the trailing stream: pointers and integers as they are, a float as its
+ *           bit pattern in the low 32 bits.  Descriptor structs and host arrays (gstart_host, rd_zero's arrays) are referenced, not
+ *           copied: they must stay alive and unchanged while the list is in use;
+ *   lane    index into streams[] (0 = the caller's main stream).  An entry on lane k > 0 with wait_main != 0 first makes streams[k]
+ *           wait for everything enqueued on streams[0] so far (the weight-gradient launches: each behind its place in the dgrad
+ *           chain).  RD_OP_FORK: streams[lane] waits for streams[0]; RD_OP_JOIN: streams[0] waits for streams[lane] if the lane is
+ *           open.  A lane is OPEN from its first fork / wait_main entry until it is joined.
+ * *open_lanes (bit k = lane k; may be NULL) carries the open set in and out, so that consecutive segments can leave a lane running
+ * across their boundary (the data-parallel step joins the weight-gradient lane only in front of the optimizer);
+ * rd_join_lanes makes streams[0] wait for every lane in `mask`.  Works eagerly and under stream capture (events only).
+ * Returns 0, the first failing entry point's error code, or -1 for a malformed entry (its index in *bad_index if not NULL). */
+enum {
+    RD_OP_FORK = 1, RD_OP_JOIN = 2,
+    RD_OP_CONV = 10, RD_OP_WGRAD, RD_OP_CONV_BWD_FUSED, RD_OP_CONV_BWD_FUSED_REDUCE, RD_OP_PACK_WEIGHTS_BATCHED,
+    RD_OP_BN_FINALIZE_FWD, RD_OP_BN_FINALIZE_BWD, RD_OP_GN_FINALIZE_FWD, RD_OP_GN_FINALIZE_BWD,
+    RD_OP_UP_STATS, RD_OP_BN_STATS, RD_OP_UP_BWD, RD_OP_POOL_FWD, RD_OP_POOL_BWD, RD_OP_BN_APPLY,
+    RD_OP_NCHW_TO_NHWC, RD_OP_NHWC_TO_NCHW, RD_OP_GRAD_IN, RD_OP_COLSUM,
+    RD_OP_SEG_LOSS, RD_OP_REC_LOSS, RD_OP_ADAM_STEP, RD_OP_ZERO, RD_OP_RAM_MIX
+};
+#define RD_LAUNCH_MAX_ARGS 17
+typedef struct {
+    int32_t op;
+    int32_t lane;
+    int32_t wait_main;
+    int32_t nargs;
+    uint64_t a[RD_LAUNCH_MAX_ARGS];
+} rd_launch_t;
+int rd_run_list(const rd_launch_t* ops, int n, void* const* streams, int n_streams, uint32_t* open_lanes, int* bad_index);
+int rd_join_lanes(void* const* streams, int n_streams, uint32_t mask);
+
 #ifdef __cplusplus
 }
 #endif

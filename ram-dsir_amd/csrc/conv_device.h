@@ -903,7 +903,9 @@ __device__ __forceinline__ void pfu_issue_pre(uint4 (&raw)[NIT][NQ], const Plain
 }
 
 // NOSKIP: every item has an LDS destination (the caller points dead lanes at a dummy record): no divergent branch per item
-template <typename T, int NIT, int NQ, bool NOSKIP = false, typename StoreFn>
+// KIND 0: the general form above; 1: no activation (slope 1 known at compile time: the BatchNorm-backward source P g + Q z + R);
+// 2: the 16 bytes go to LDS as they are (raw tensors)
+template <typename T, int NIT, int NQ, bool NOSKIP = false, int KIND = 0, typename StoreFn>
 __device__ __forceinline__ void pfu_consume(const uint4 (&raw)[NIT][NQ], const PlainSrc<T>& k, const ItemGeom<NIT>& ig,
                                             int H, int W, int yh, int xh, StoreFn store, int nit = NIT) {
     constexpr int S = Slot<T>::N;
@@ -915,16 +917,30 @@ __device__ __forceinline__ void pfu_consume(const uint4 (&raw)[NIT][NQ], const P
         }
         const int y = yh + ig.py[b], x = xh + ig.px[b];
         const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        if constexpr (KIND == 2) {
+            unsigned keep = in ? 0xffffffffu : 0u;
+            asm("" : "+v"(keep));
+            uint4 u = raw[b][0];
+            u.x &= keep; u.y &= keep; u.z &= keep; u.w &= keep;
+            store(ig.lds[b], u);
+            continue;
+        }
         float v[S];
         Slot<T>::unpack(raw[b][0], v);
         if constexpr (NQ == 2) {
             float zz[S];
             Slot<T>::unpack(raw[b][1], zz);
 #pragma unroll
-            for (int e = 0; e < S; ++e) v[e] = act_fn(k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e], k.slope);
+            for (int e = 0; e < S; ++e) {
+                const float t = k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e];
+                v[e] = KIND == 1 ? t : act_fn(t, k.slope);
+            }
         } else {
 #pragma unroll
-            for (int e = 0; e < S; ++e) v[e] = act_fn(k.sc[e] * v[e] + k.sh[e], k.slope);
+            for (int e = 0; e < S; ++e) {
+                const float t = k.sc[e] * v[e] + k.sh[e];
+                v[e] = KIND == 1 ? t : act_fn(t, k.slope);
+            }
         }
         // pixels outside the image become zeros by an AND with a per-lane mask, and the mask is laundered through an empty asm:
         // written as a select, the compiler turns it into a BRANCH around the whole transform (one s_cbranch_execz per item) and,

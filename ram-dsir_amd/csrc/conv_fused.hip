@@ -49,17 +49,30 @@ struct FusedWg {
 };
 
 constexpr int FZ_PH = TH + 2, FZ_PW = TW + 2, FZ_NPIX = FZ_PH * FZ_PW;      // 10 x 34 halo tile
-constexpr int FZ_IN_BYTES = FZ_NPIX * 64;                                    // one dz tile buffer
+// one dz tile buffer + 256 dummy records: loader items that do not exist (past the halo tile, channel slots past Cin) still store
+// somewhere, so that the loader has no branch per item (conv_small_fwd.hip's header comment: one conditional vector-memory
+// instruction anywhere in the loop turns every wait of the compiler into vmcnt(0))
+constexpr int FZ_IN_BYTES = FZ_NPIX * 64 + 256 * 16;
+__device__ uint4 fz_trash[256];                          // where the gradient stores of lanes without a destination pixel go
 constexpr int FZ_A_BYTES = TH * TW * 64;                                     // one `a` tile buffer
 constexpr int FZ_W_BYTES = 9 * 32 * 64;
 constexpr int FZ_LDS = 3 * FZ_IN_BYTES + 2 * FZ_A_BYTES + FZ_W_BYTES + 64 * 8 + (32 + 32) * 4;
 
-// xp: timing experiments of the debug build (RD_FZ_EXP bits; results are wrong when set): 1 no weight-gradient phase, 2 no dgrad MFMAs,
+// NSL: live 16-byte channel slots of dz (1, 2 or 4: compile-time item count); NQ: 2 = BatchNorm-backward source (g and z), 1 = a stored
+// dz / dlogits (copied as it is).
+// FZ_XP: timing experiments (compile with -DRD_FZ_EXP=bits; results are wrong when set): 1 no weight-gradient phase, 2 no dgrad MFMAs,
 // 4 no gradient stores, 8 loader issues no global loads, 16 no epilogue-operand loads, 32 no `a` tile writes
-__global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_conv_t p, const FusedWg w, int tiles_per_wg, int xp) {
+#ifdef RD_FZ_EXP
+#define FZ_XP(bit) (((RD_FZ_EXP) & (bit)) != 0)
+#else
+#define FZ_XP(bit) false
+#endif
+template <int NSL, int NQ>
+__global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_conv_t p, const FusedWg w, int tiles_per_wg) {
     typedef bf16_t T;
     constexpr int S = 8, NT = 32, NV = 2;
-    constexpr int NIT = (FZ_NPIX * 4 + 255) / 256;
+    constexpr int NSH = NSL == 1 ? 0 : (NSL == 2 ? 1 : 2);
+    constexpr int NIT = (FZ_NPIX * NSL + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_inb = smem;                                                      // 3 x [NPIX][4 slots x 16 B]
     char* s_ab = smem + 3 * FZ_IN_BYTES;                                     // 2 x [256][4 x 16 B]
@@ -76,6 +89,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
     const int t_begin = blockIdx.x * tiles_per_wg;
     const int t_end = min(ntiles, t_begin + tiles_per_wg);
     const int nt = t_end - t_begin;
+    const int NI = (nt + 2) & ~1;                          // iterations (barriers) of the tile loop, both roles
     const int n = blockIdx.z;
     const GroupMap gm = make_gm(p.gstart, p.G);
     const int g = group_of(gm, n);
@@ -109,27 +123,24 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
 
     if (role == 1) {
         // =============================================================================== loader + weight-gradient waves
-        int nsl = 4;
-        {
-            const int nl = (p.Cin + S - 1) / S;
-            nsl = nl <= 1 ? 1 : (nl <= 2 ? 2 : 4);
-        }
-        const int nsh = nsl == 1 ? 0 : (nsl == 2 ? 1 : 2);
-        const int sslot = tid & (nsl - 1);
-        const int nit = (FZ_NPIX * nsl + 255) >> 8;
+        const int sslot = tid & (NSL - 1);
+        const bool live_slot = sslot * S < p.Cin;
+        const rd_src_t ssrc = select_src(p.src, 0);
+        PlainSrc<T> ps;
+        plain_src_init<T>(ps, ssrc, live_slot ? sslot * S : 0);
+        plain_src_coef<T>(ps, ssrc, g, live_slot ? sslot * S : 0);
         ItemGeom<NIT> ig;
 #pragma unroll
         for (int b = 0; b < NIT; ++b) {
-            const int pixi = (tid + b * 256) >> nsh;
+            const int pixi = (tid + b * 256) >> NSH;
             const int pix = min(pixi, FZ_NPIX - 1);
             ig.py[b] = (short)(pix / FZ_PW);
             ig.px[b] = (short)(pix - (pix / FZ_PW) * FZ_PW);
-            ig.lds[b] = pixi < FZ_NPIX ? pix * 4 + (sslot ^ ((ig.px[b] >> 2) & 3)) : -1;       // slots swizzled by the halo COLUMN
+            // slots swizzled by the halo COLUMN; items that do not exist land in this thread's dummy record behind the tile
+            ig.lds[b] = (pixi < FZ_NPIX && live_slot) ? pix * 4 + (sslot ^ ((ig.px[b] >> 2) & 3)) : FZ_NPIX * 4 + tid;
         }
-        SlotCtx<T> ctx;
-        slot_ctx<T>(ctx, p.src, 1, p.Cin, g, sslot * S);
-        const rd_src_t ssrc = select_src(p.src, 0);
-        const bool live_slot = ctx.si >= 0;
+        int ioff[NIT];
+        pfu_item_offsets<T, NIT>(ioff, ps, ig, W);
 
         // ---- weight-gradient roles: 16x16 blocks (cob, cib); nb blocks over these 4 waves, a block's waves split the tile rows
         const int nbi = w.CinPadW >> 4, nb = (w.CoutPadW >> 4) * nbi;          // nb in {1, 2, 4}
@@ -160,42 +171,37 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
             aoff[j] = c * 64 + ((as0 ^ (((c >> 1) & 3) ^ (((c >> 3) & 1) << 1))) << 4) + sub;
         }
 
-        // two register sets: tiles t+2 and t+3 are in flight while tile t+1 is transformed
-        uint4 rawA[NIT][2], rawB[NIT][2];
-        auto origin = [&](int t, int& yh, int& xh) {
-            yh = (t / tiles_x) * TH - 1;
-            xh = (t % tiles_x) * TW - 1;
+        // two register sets: tiles t+2 and t+3 are in flight while tile t+1 is transformed.  EVERY request and EVERY transform happens
+        // on every path: tiles past the workgroup's range are ghosts (all items read pixel (0, 0), zeros go to a buffer nobody reads
+        // any more), so that the compiler can count the loads in flight and wait for the older set only (vmcnt(NIT * NQ))
+        uint4 rawA[NIT][NQ], rawB[NIT][NQ];
+        constexpr int CK_ = NQ == 1 ? 2 : 1;               // pfu_consume KIND: copy / affine without activation
+        auto request = [&](uint4 (&raw)[NIT][NQ], int j) {
+            const bool ghost = j >= nt;
+            const int t = t_begin + j;
+            const int yh = (t / tiles_x) * TH - 1, xh = (t % tiles_x) * TW - 1;
+            if (!FZ_XP(8)) pfu_issue_pre<T, NIT, NQ>(raw, ps, ig, ioff, n, H, W, yh, xh, ghost, !ghost && xh + FZ_PW > W);
         };
-        int yh, xh;
+        auto transform = [&](const uint4 (&raw)[NIT][NQ], int j) {
+            const bool ghost = j >= nt;
+            const int t = t_begin + j;
+            const int yh = ghost ? -(1 << 20) : (t / tiles_x) * TH - 1, xh = ghost ? -(1 << 20) : (t % tiles_x) * TW - 1;
+            uint4* dstb = reinterpret_cast<uint4*>(s_inb + (j % 3) * FZ_IN_BYTES);
+            pfu_consume<T, NIT, NQ, true, CK_>(raw, ps, ig, H, W, yh, xh, [&](int l, const uint4& u) { dstb[l] = u; });
+        };
         // set A carries the even tiles of this workgroup, set B the odd ones
-        if (live_slot && nt > 0) {
-            origin(t_begin, yh, xh);
-            pf_issue<T, NIT, 2>(rawA, ssrc, ctx, ig, n, H, W, yh, xh, nit);
-            if (nt > 1) {
-                int y1, x1;
-                origin(t_begin + 1, y1, x1);
-                pf_issue<T, NIT, 2>(rawB, ssrc, ctx, ig, n, H, W, y1, x1, nit);
-            }
-            pf_consume<T, NIT>(rawA, ssrc, ctx, ig, H, W, yh, xh, reinterpret_cast<uint4*>(s_inb), nit);
-            if (nt > 2) {
-                origin(t_begin + 2, yh, xh);
-                pf_issue<T, NIT, 2>(rawA, ssrc, ctx, ig, n, H, W, yh, xh, nit);
-            }
-        }
+        request(rawA, 0);
+        request(rawB, 1);
+        transform(rawA, 0);
+        request(rawA, 2);
         __syncthreads();                                   // tile 0 is in buffer 0
         // iteration `it`: tile it+1 goes into buffer (it+1) % 3, tile it+3 is requested into the register set just emptied, and the
         // weight gradient of tile it-1 is accumulated from the `a` tile the epilogue of iteration it-1 wrote and that tile's dz
         // halo buffer (still intact: three buffers) -- K = the 32 pixels of a tile row per MFMA
-        auto step = [&](uint4 (&raw)[NIT][2], int it) {
-            if (live_slot && it + 1 < nt) {
-                origin(t_begin + it + 1, yh, xh);
-                pf_consume<T, NIT>(raw, ssrc, ctx, ig, H, W, yh, xh, reinterpret_cast<uint4*>(s_inb + ((it + 1) % 3) * FZ_IN_BYTES), nit);
-                if (it + 3 < nt && !(xp & 8)) {
-                    origin(t_begin + it + 3, yh, xh);
-                    pf_issue<T, NIT, 2>(raw, ssrc, ctx, ig, n, H, W, yh, xh, nit);
-                }
-            }
-            if (it >= 1 && !(xp & 1)) {
+        auto step = [&](uint4 (&raw)[NIT][NQ], int it) {
+            transform(raw, it + 1);
+            request(raw, it + 3);
+            if (it >= 1 && it <= nt && !FZ_XP(1)) {
                 const char* s_a = s_ab + ((it - 1) & 1) * FZ_A_BYTES;
                 const char* s_z = s_inb + ((it - 1) % 3) * FZ_IN_BYTES;
                 for (int r = kq; r < TH; r += wpb) {
@@ -218,13 +224,13 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
                 }
             }
         };
-        for (int it = 0; it <= nt; it += 2) {
+        // both roles run NI = nt + 1 iterations rounded up to an even count (the compute waves' last one or two are empty), so that the
+        // pair below has no conditional half: a request that exists on one path only would make every wait conservative
+        for (int it = 0; it < NI; it += 2) {
             step(rawB, it);
             fz_barrier();
-            if (it + 1 <= nt) {
-                step(rawA, it + 1);
-                fz_barrier();
-            }
+            step(rawA, it + 1);
+            fz_barrier();
         }
         // ---- weight-gradient blocks: waves that split a block's rows (kq > 0) hand their sums to kq == 0 through LDS
         float* s_acc = reinterpret_cast<float*>(smem);     // [(wpb-1)][nb][9*4][64]: the tile buffers are dead now
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
         }
     } else {
         // =============================================================================== dgrad waves
-        int nks = p.Cin <= 16 ? 1 : 2;
+        constexpr int nks = NSL <= 2 ? 1 : 2;
         // ---- epilogue constants (conv_small_kernel's register epilogue: lane owns pixel li of a tile row and channels
         //      16v + 8h .. +7 after the permlane regroup)
         int cbv[NV];
@@ -292,21 +298,25 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
         uint4 araw[2][NV];
         // epilogue operands (the forward input's raw tensor) of a tile: requested one iteration ahead, right after the previous
         // tile's epilogue has consumed the registers (clamped addresses: branch-free loads; invalid pixels are masked later)
-        auto request = [&](int t) {
-            if (xp & 16) return;
+        // unconditional like the loader's: a tile past the range (ghost) and a vector without a destination read one valid line
+        const T* dummy = reinterpret_cast<const T*>(p.w);
+        auto request = [&](int j) {
+            if (FZ_XP(16)) return;
+            const bool ghost = j >= nt;
+            const int t = t_begin + j;
             const int xx0 = (t % tiles_x) * TW, yy0 = (t / tiles_x) * TH;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const int y = min(yy0 + wave * 2 + mb, H - 1), x = min(xx0 + li, W - 1);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    if (v == 1 && !two) continue;
-                    araw[mb][v] = live[v] ? ld16(ap[v] + (unsigned)((y * W + x) * Cd[v])) : make_uint4(0, 0, 0, 0);
+                    const T* q = (live[v] && !ghost) ? ap[v] + (unsigned)((y * W + x) * Cd[v]) : dummy;
+                    araw[mb][v] = ld16(q);
                 }
             }
         };
-        if (nt > 0) request(t_begin);
-        for (int it = 0; it <= nt; ++it) {
+        request(0);
+        for (int it = 0; it < NI; ++it) {
             const int t = t_begin + it;
             const int x0 = (t % tiles_x) * TW, y0 = (t / tiles_x) * TH;
             if (it < nt) {
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
                     for (int r = 0; r < 16; ++r) accs[mb][r] = 0.f;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    if (xp & 2) break;
+                    if (FZ_XP(2)) break;
                     const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb) {
@@ -337,7 +347,10 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
                     const bool valid = y < H && x < W;
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
-                        if (v == 1 && !two) continue;
+                        if (v == 1 && !two) {                // same vector-memory instructions on both paths (see the loader)
+                            if (!FZ_XP(4)) fz_trash[tid] = make_uint4(0, 0, 0, 0);
+                            continue;
+                        }
                         const int cb = cbv[v];
                         float vec[S], xr[S], go[S], av[S];
 #pragma unroll
@@ -387,16 +400,19 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
 #pragma unroll
                             for (int e = 0; e < S; ++e) go[e] += gold[e];
                         }
-                        if (on && !(xp & 4))
-                            *reinterpret_cast<uint4*>(gp[v] + (unsigned)((y * W + x) * Cd[v])) = Slot<T>::pack(go);
+                        // unconditional store (lanes without a destination pixel write to the trash record): stores count in vmcnt too
+                        if (!FZ_XP(4)) {
+                            uint4* qd = on ? reinterpret_cast<uint4*>(gp[v] + (unsigned)((y * W + x) * Cd[v])) : &fz_trash[tid];
+                            *qd = Slot<T>::pack(go);
+                        }
                         // the forward input of this pixel for the weight gradient (zero outside the image / beyond the channels)
                         const int c = li, sl = 2 * v + h;
                         const uint4 au = on ? Slot<T>::pack(av) : make_uint4(0, 0, 0, 0);
-                        if (!(xp & 32)) *reinterpret_cast<uint4*>(s_aw + ((wave * 2 + mb) * TW + c) * 64 +
+                        if (!FZ_XP(32)) *reinterpret_cast<uint4*>(s_aw + ((wave * 2 + mb) * TW + c) * 64 +
                                                   ((sl ^ (((c >> 1) & 3) ^ (((c >> 3) & 1) << 1))) << 4)) = au;
                     }
                 }
-                if (it + 1 < nt) request(t + 1);
+                request(it + 1);
             }
             fz_barrier();
         }
@@ -420,6 +436,21 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
 }
 
 inline bool aligned16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
+
+template <int NSL, int NQ>
+int fused_launch_one(dim3 grid, hipStream_t st, const rd_conv_t& p, const FusedWg& fw, int tpw) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_bwd_fused_kernel<NSL, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_small_bwd_fused_kernel<NSL, NQ>), grid, dim3(512), FZ_LDS, st, p, fw, tpw);
+    return (int)hipGetLastError();
+}
+int fused_launch(int nsl, int nq, dim3 grid, hipStream_t st, const rd_conv_t& p, const FusedWg& fw, int tpw) {
+    if (nq == 2) return nsl == 1 ? fused_launch_one<1, 2>(grid, st, p, fw, tpw) : nsl == 2 ? fused_launch_one<2, 2>(grid, st, p, fw, tpw) : fused_launch_one<4, 2>(grid, st, p, fw, tpw);
+    return nsl == 1 ? fused_launch_one<1, 1>(grid, st, p, fw, tpw) : nsl == 2 ? fused_launch_one<2, 1>(grid, st, p, fw, tpw) : fused_launch_one<4, 1>(grid, st, p, fw, tpw);
+}
 
 }  // namespace
 
@@ -491,14 +522,10 @@ int rd_bwd_fused_dispatch(const rd_conv_t& p, const rd_wgrad_t& w, hipStream_t s
     fw.partial = w.partial;
     fw.CoutPadW = (w.Cout + 15) / 16 * 16;
     fw.CinPadW = (w.Cin + 15) / 16 * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS);
-        attr_set = true;
-    }
     dim3 grid(gx, 1, p.N);
-    hipLaunchKernelGGL(conv_small_bwd_fused_kernel, grid, dim3(512), FZ_LDS, st, p, fw, tpw, rd_switch("RD_FZ_EXP", 0));
-    return (int)hipGetLastError();
+    const int nl = (p.Cin + 7) / 8, nsl = nl <= 1 ? 1 : (nl <= 2 ? 2 : 4);
+    const int nq = p.src[0].mode == RD_SRC_BNBWD ? 2 : 1;
+    return fused_launch(nsl, nq, grid, st, p, fw, tpw);
 }
 
 // the workgroups' dW block sums -> dW (fixed order: deterministic); its own entry point so that the host can put it on the

@@ -1,0 +1,139 @@
+// runlist.hip -- rd_run_list / rd_join_lanes (include/ramdsir.h): the step's launch list walked in C++, one call per segment,
+// with the lane forks / joins as HIP events.  Host code only.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "common.h"
+#include "../../include/ramdsir.h"
+
+namespace {
+
+// Events for the cross-stream edges.  An event can be recorded again as soon as the hipStreamWaitEvent that uses it has been
+// enqueued (the wait captures the record it was called after), so a small ring per device is enough; the ring only keeps an event
+// from being re-recorded while the runtime may still be processing the previous wait call on another thread of its own.
+constexpr int EV_RING = 64, EV_MAX_DEV = 16;
+struct EvRing {
+    hipEvent_t ev[EV_RING];
+    int next = 0;
+    bool ready = false;
+};
+EvRing g_rings[EV_MAX_DEV];
+
+int next_event(hipEvent_t* out) {
+    int dev = 0;
+    RD_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= EV_MAX_DEV) return -1;
+    EvRing& r = g_rings[dev];
+    if (!r.ready) {
+        for (int i = 0; i < EV_RING; ++i) RD_CHECK(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+        r.ready = true;
+    }
+    *out = r.ev[r.next];
+    r.next = (r.next + 1) % EV_RING;
+    return 0;
+}
+
+// stream `to` waits for everything enqueued on `from` so far
+int edge(hipStream_t from, hipStream_t to) {
+    if (from == to) return 0;
+    hipEvent_t e;
+    const int err = next_event(&e);
+    if (err) return err;
+    RD_CHECK(hipEventRecord(e, from));
+    RD_CHECK(hipStreamWaitEvent(to, e, 0));
+    return 0;
+}
+
+inline float as_f(uint64_t v) {
+    const uint32_t u = (uint32_t)v;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+#define P(i) ((void*)(uintptr_t)o.a[i])
+#define CP(T, i) ((const T*)(uintptr_t)o.a[i])
+#define I(i) ((int)(int64_t)o.a[i])
+#define L64(i) ((int64_t)o.a[i])
+#define F(i) (as_f(o.a[i]))
+#define NARGS(k) do { if (o.nargs != (k)) return -1; } while (0)
+
+int call(const rd_launch_t& o, void* st) {
+    switch (o.op) {
+    case RD_OP_CONV: NARGS(2); return rd_conv(CP(rd_conv_t, 0), I(1), st);
+    case RD_OP_WGRAD: NARGS(2); return rd_wgrad(CP(rd_wgrad_t, 0), I(1), st);
+    case RD_OP_CONV_BWD_FUSED: NARGS(3); return rd_conv_bwd_fused(CP(rd_conv_t, 0), CP(rd_wgrad_t, 1), I(2), st);
+    case RD_OP_CONV_BWD_FUSED_REDUCE: NARGS(3); return rd_conv_bwd_fused_reduce(CP(rd_conv_t, 0), CP(rd_wgrad_t, 1), I(2), st);
+    case RD_OP_PACK_WEIGHTS_BATCHED: NARGS(6); return rd_pack_weights_batched(CP(float, 0), P(1), CP(rd_pack_entry_t, 2), I(3), L64(4), I(5), st);
+    case RD_OP_BN_FINALIZE_FWD: NARGS(1); return rd_bn_finalize_fwd(CP(rd_bn_fwd_t, 0), st);
+    case RD_OP_BN_FINALIZE_BWD: NARGS(1); return rd_bn_finalize_bwd(CP(rd_bn_bwd_t, 0), st);
+    case RD_OP_GN_FINALIZE_FWD: NARGS(1); return rd_gn_finalize_fwd(CP(rd_bn_fwd_t, 0), st);
+    case RD_OP_GN_FINALIZE_BWD: NARGS(1); return rd_gn_finalize_bwd(CP(rd_bn_bwd_t, 0), st);
+    case RD_OP_UP_STATS: NARGS(10); return rd_up_stats(P(0), (double*)P(1), P(2), I(3), I(4), I(5), I(6), I(7), CP(int32_t, 8), I(9), st);
+    case RD_OP_BN_STATS: NARGS(9); return rd_bn_stats(P(0), (double*)P(1), I(2), I(3), I(4), I(5), I(6), CP(int32_t, 7), I(8), st);
+    case RD_OP_UP_BWD: NARGS(13); return rd_up_bwd(P(0), P(1), P(2), CP(float, 3), CP(float, 4), CP(float, 5), I(6), I(7), I(8), I(9), I(10), CP(int32_t, 11), I(12), st);
+    case RD_OP_POOL_FWD: NARGS(12); return rd_pool_fwd(P(0), CP(float, 1), CP(float, 2), F(3), P(4), I(5), I(6), I(7), I(8), I(9), CP(int32_t, 10), I(11), st);
+    case RD_OP_POOL_BWD:
+        NARGS(16);
+        return rd_pool_bwd(P(0), P(1), CP(float, 2), CP(float, 3), F(4), I(5), P(6), I(7), (double*)P(8), I(9), I(10), I(11), I(12), I(13), CP(int32_t, 14), I(15), st);
+    case RD_OP_BN_APPLY:
+        NARGS(14);
+        return rd_bn_apply(P(0), P(1), P(2), CP(float, 3), CP(float, 4), CP(float, 5), F(6), I(7), I(8), I(9), I(10), I(11), CP(int32_t, 12), I(13), st);
+    case RD_OP_NCHW_TO_NHWC: NARGS(8); return rd_nchw_to_nhwc(CP(float, 0), P(1), I(2), I(3), I(4), I(5), I(6), I(7), st);
+    case RD_OP_NHWC_TO_NCHW:
+        NARGS(13);
+        return rd_nhwc_to_nchw(P(0), (float*)P(1), CP(float, 2), CP(float, 3), I(4), F(5), I(6), I(7), I(8), I(9), I(10), CP(int32_t, 11), I(12), st);
+    case RD_OP_GRAD_IN:
+        NARGS(16);
+        return rd_grad_in(CP(float, 0), P(1), P(2), CP(float, 3), CP(float, 4), (double*)P(5), I(6), F(7), I(8), I(9), I(10), I(11), I(12), I(13), CP(int32_t, 14), I(15), st);
+    case RD_OP_COLSUM: NARGS(8); return rd_colsum(P(0), (float*)P(1), (float*)P(2), L64(3), I(4), I(5), F(6), I(7), st);
+    case RD_OP_SEG_LOSS: NARGS(2); return rd_seg_loss(CP(rd_seg_loss_t, 0), I(1), st);
+    case RD_OP_REC_LOSS:
+        NARGS(15);
+        return rd_rec_loss(P(0), P(1), P(2), (float*)P(3), (float*)P(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11), CP(int32_t, 12), F(13), I(14), st);
+    case RD_OP_ADAM_STEP: NARGS(1); return rd_adam_step(CP(rd_adam_t, 0), st);
+    case RD_OP_ZERO: NARGS(3); return rd_zero((void* const*)P(0), CP(int64_t, 1), I(2), st);
+    case RD_OP_RAM_MIX: NARGS(2); return rd_ram_mix(CP(rd_ram_t, 0), I(1), st);
+    default: return -1;
+    }
+}
+
+}  // namespace
+
+extern "C" int rd_join_lanes(void* const* streams, int n_streams, uint32_t mask) {
+    for (int k = 1; k < n_streams && k < 32; ++k)
+        if (mask & (1u << k)) {
+            const int err = edge((hipStream_t)streams[k], (hipStream_t)streams[0]);
+            if (err) return err;
+        }
+    return 0;
+}
+
+extern "C" int rd_run_list(const rd_launch_t* ops, int n, void* const* streams, int n_streams, uint32_t* open_lanes, int* bad_index) {
+    if (n_streams < 1 || n_streams > 32) return -1;
+    uint32_t open = open_lanes ? *open_lanes : 0u;
+    hipStream_t main_s = (hipStream_t)streams[0];
+    int rc = 0, i = 0;
+    for (; i < n && rc == 0; ++i) {
+        const rd_launch_t& o = ops[i];
+        if (o.lane < 0 || o.lane >= n_streams || o.nargs < 0 || o.nargs > RD_LAUNCH_MAX_ARGS) { rc = -1; break; }
+        hipStream_t st = (hipStream_t)streams[o.lane];
+        if (o.op == RD_OP_FORK) {
+            if (o.lane > 0) { rc = edge(main_s, st); open |= 1u << o.lane; }
+            continue;
+        }
+        if (o.op == RD_OP_JOIN) {
+            if (o.lane > 0 && (open & (1u << o.lane))) { rc = edge(st, main_s); open &= ~(1u << o.lane); }
+            continue;
+        }
+        if (o.lane > 0 && o.wait_main) {
+            rc = edge(main_s, st);
+            open |= 1u << o.lane;
+            if (rc) break;
+        }
+        rc = call(o, (void*)st);
+        if (rc) break;
+    }
+    if (rc && bad_index) *bad_index = i;
+    if (open_lanes) *open_lanes = open;
+    return rc;
+}
