@@ -325,6 +325,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='(default; kept for older command lines)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-leg', action='store_true')
+    ap.add_argument('--no-pipeline', action='store_true', help='classical step: RAM at the head of every step instead of in the previous step\'s tail')
     ap.add_argument('--no-ablation', action='store_true', help='skip the in-run ablation that picks the headline roofline family')
     args = ap.parse_args()
 
@@ -369,11 +370,25 @@ def main():
         runner = D.DataParallelStep(ts)
         if args.graph:
             runner.capture()
-        step = runner.step
+        base_step = runner.step
     else:
         if args.graph:
             ts.capture()
-        step = ts.step
+        base_step = ts.step
+    if args.graph or args.no_pipeline:
+        step = base_step
+    else:
+        # the pipelined step of train.py (TrainStep.load_raw_next): every step mixes the NEXT batch (RAM) in its tail, beside Adam and
+        # the weight repack, and starts on an input that is already mixed.  The synthetic batch is resident in both input slots
+        # (inputs in HBM before the timed region, as the contract says); each timed step still runs exactly one RAM mix and one
+        # complete training step -- the first one's mix ran in the last warm-up step's tail, the last one's tail mixes for a step
+        # that is not timed.
+        for dst, val in zip(ts.raw_slots[1], (src, trg, lam)):
+            dst.copy_(val)
+
+        def step():
+            ts.reuse_next()
+            base_step()
 
     for _ in range(args.warmup):
         step()
@@ -407,6 +422,7 @@ def main():
                        'global_batch': world * B, 'parallelism': 'dp%d' % world,
                        'process_group': ('%s world %d' % (dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else 'none (single process)', 'hipgraph': bool(args.graph), 'streams': 1 if (args.graph or not ts.fork) else 1 + len(ts.lanes()),
                        'lanes_verified': bool(ts.lanes_verified), 'gradient_exchange': exchange,
+                       'ram_pipelined': not (args.graph or args.no_pipeline), 'launch': 'rd_run_list (one native call per step)' if not args.graph else 'hipGraph replay',
                        'final_loss': round(losses['loss'], 4)},
         }
         out['roofline_step'] = whole_step_roofline(B, Sz, out['ms_per_step'], args.dtype)

@@ -304,7 +304,7 @@ int64_t rd_seg_loss_workspace(const rd_seg_loss_t* p);
 int rd_seg_loss(const rd_seg_loss_t* p, int dtype, void* stream);
 
 /* Restoration loss (train.py:265-276): per domain group d, MSELoss(tanh(rec_logits[d]), img[d]);
- * loss += lambda_rec * mse_d.  rec_logits / target / dlogits: NHWC [B][H][W][C].  mse_out[G] device. */
+ * loss += lambda_rec * mse_d.  rec_logits / target / dlogits: NHWC [B][H][W][C].  mse_out[G] device.  H*W*C < 2^24 (-1 otherwise). */
 int rd_rec_loss(const void* rec_logits, const void* target, void* dlogits, float* mse_out, float* partial_ws,
                 int B, int H, int W, int C, int target_cstride /* 0: C */, int dlogits_cstride /* 0: C */, int G,
                 const int32_t* gstart_host, float lambda_rec, int dtype, void* stream);

@@ -48,6 +48,15 @@ inline double tile_efficiency(int H, int W, int th, int tw) {
     return (double)H * W / (double)(tiles * 256);
 }
 
+// dz = P*g + Q*z + R of the BatchNorm backward (and sc*x + q*x2 + sh of the unified plain-source form) with the two fused
+// multiply-adds written out: left to the compiler, `a*b + c*d + e` contracts as fma(a, b, fma(c, d, e)) in one kernel and as
+// fma(c, d, fma(a, b, e)) in another (it depends on what the surrounding code lets the vectoriser do), the results differ in the
+// last fp32 bit, and one element in ~10^5 then rounds to the other bf16 -- enough to break "the fused backward's input gradient is
+// bit-identical to rd_conv's" (tests/test_gpu_fused_bwd.py) on an unlucky case.
+__device__ __forceinline__ float bn_bwd_value(float sc, float x, float q, float x2, float sh) {
+    return __builtin_fmaf(sc, x, __builtin_fmaf(q, x2, sh));
+}
+
 // ------------------------------------------------------------------------------------ tile loader
 template <typename T>
 __device__ __forceinline__ void load_vec(const T* p, int cvalid, bool vec_ok, float* f) {
@@ -162,7 +171,7 @@ __device__ __forceinline__ void load_slot(const rd_src_t& s, const SlotCtx<T>& k
         load_vec<T>(base + off, cvalid, vec_ok, gz);
         load_vec<T>(zb + off, cvalid, vec_ok, zz);
 #pragma unroll
-        for (int e = 0; e < S; ++e) v[e] = k.sc[e] * gz[e] + k.q[e] * zz[e] + k.sh[e];
+        for (int e = 0; e < S; ++e) v[e] = bn_bwd_value(k.sc[e], gz[e], k.q[e], zz[e], k.sh[e]);
     } break;
     default:
 #pragma unroll
@@ -291,7 +300,7 @@ __device__ __forceinline__ void tile_fill_mode(const rd_src_t& s, const SlotCtx<
                     Slot<T>::unpack(raw[b][0], v);
                     Slot<T>::unpack(raw[b][1], zz);
 #pragma unroll
-                    for (int e = 0; e < S; ++e) v[e] = k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e];
+                    for (int e = 0; e < S; ++e) v[e] = bn_bwd_value(k.sc[e], v[e], k.q[e], zz[e], k.sh[e]);
                 } else if constexpr (MODE == RD_SRC_POOL) {
                     float t[S];
                     Slot<T>::unpack(raw[b][0], v);
@@ -794,7 +803,7 @@ __device__ __forceinline__ void pf_consume_fn(const uint4 (&raw)[NIT][NQ], const
                 float zz[S];
                 Slot<T>::unpack(raw[b][1], zz);
 #pragma unroll
-                for (int e = 0; e < S; ++e) v[e] = k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e];
+                for (int e = 0; e < S; ++e) v[e] = bn_bwd_value(k.sc[e], v[e], k.q[e], zz[e], k.sh[e]);
             }
             u = in ? Slot<T>::pack(v) : make_uint4(0, 0, 0, 0);
         }
@@ -932,7 +941,7 @@ __device__ __forceinline__ void pfu_consume(const uint4 (&raw)[NIT][NQ], const P
             Slot<T>::unpack(raw[b][1], zz);
 #pragma unroll
             for (int e = 0; e < S; ++e) {
-                const float t = k.sc[e] * v[e] + k.q[e] * zz[e] + k.sh[e];
+                const float t = bn_bwd_value(k.sc[e], v[e], k.q[e], zz[e], k.sh[e]);
                 v[e] = KIND == 1 ? t : act_fn(t, k.slope);
             }
         } else {

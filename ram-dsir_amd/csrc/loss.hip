@@ -433,6 +433,9 @@ int rd_rec_loss(const void* lg, const void* tgt, void* dl, float* mse_out, float
     const int Ts = target_cstride > 0 ? target_cstride : C, Ds = dlogits_cstride > 0 ? dlogits_cstride : C;
     if (Ts < C || Ds < C) return -1;
     hipStream_t st = (hipStream_t)stream;
+    // rec_loss_kernel splits an element index into (pixel, channel) with a float reciprocal + one correction step: exact while the
+    // index stays below 2^24 (a 2048 x 2048 x 3 image is 12.6 M); larger images are refused rather than indexed wrongly
+    if ((long long)H * W * C >= (1ll << 24)) return -1;
     const int per_img = H * W * C;
     const int bx = rec_bx(per_img);
     const GroupMap gm = host_gm2(G, gstart_host);

@@ -74,6 +74,9 @@ class ConvD(M.FusedModule):
         N, Cc, H, W = x.shape
         if not self.first and (H % 2 or W % 2):
             raise ValueError('ConvD: H and W must be even for the 2x2 max-pool, got %dx%d' % (H, W))
+        chunks = _image_chunks(self._norm, N)
+        if chunks is not None:
+            return torch.cat([self.forward(x[a:b]) for a, b in chunks], 0)
         self._ensure_bound(x.device)
 
         def graph(pl):
@@ -105,6 +108,9 @@ class ConvU(M.FusedModule):
         _check_input(x, 'ConvU')
         _check_input(prev, 'ConvU')
         N = x.shape[0]
+        chunks = _image_chunks(self._norm, N)
+        if chunks is not None:
+            return torch.cat([self.forward(x[a:b], prev[a:b]) for a, b in chunks], 0)
         self._ensure_bound(x.device)
 
         def graph(pl):
@@ -149,6 +155,15 @@ class ConvU_Rec(M.FusedModule):
         return M.run_fused(self, pl, [pl.x_in], [pl.out], [x])[0]
 
 
+def _image_chunks(norm, N):
+    """gn / in keep one statistics group per image and a launch plan holds at most RD_MAX_GROUPS_C of them: a larger batch is run in
+    chunks of that many images (exact: per-image statistics do not see the other images; the reference's nn.GroupNorm /
+    nn.InstanceNorm2d have no batch limit).  None: the call fits one plan (always, for bn)."""
+    if norm not in ('gn', 'in') or N <= L.MAXG:
+        return None
+    return [(i, min(i + L.MAXG, N)) for i in range(0, N, L.MAXG)]
+
+
 def _check_input(x, name):
     if not (torch.is_tensor(x) and x.dim() == 4 and x.is_cuda):
         raise RuntimeError('%s: expected a 4-D CUDA tensor; the HIP path has no CPU fallback' % name)
@@ -174,6 +189,10 @@ class Encoder(M.FusedModule):
         N, Cc, H, W = x.shape
         if H % 16 or W % 16:
             raise ValueError('Encoder: H and W must be multiples of 16 (four 2x2 max-pools), got %dx%d' % (H, W))
+        chunks = _image_chunks(self._norm, N)
+        if chunks is not None:
+            parts = [self.forward(x[a:b]) for a, b in chunks]
+            return [torch.cat([q[k] for q in parts], 0) for k in range(len(parts[0]))]
         self._ensure_bound(x.device)
         training = self._bn_training()
 
@@ -209,6 +228,9 @@ class Decoder(M.FusedModule):
             _check_input(f, 'Decoder')
         shapes = tuple(tuple(f.shape) for f in feats)
         N = feats[0].shape[0]
+        chunks = _image_chunks(self._norm, N)
+        if chunks is not None:
+            return torch.cat([self.forward([f[a:b] for f in feats]) for a, b in chunks], 0)
         self._ensure_bound(feats[0].device)
         training = self._bn_training()
 

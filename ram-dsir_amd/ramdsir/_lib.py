@@ -77,6 +77,20 @@ class RdPackEntry(C.Structure):
                 ('transpose', i32), ('RowPad', i32), ('ColPad', i32)]
 
 
+class RdLaunch(C.Structure):
+    """rd_launch_t (include/ramdsir.h): one entry of a native launch list."""
+    _fields_ = [('op', i32), ('lane', i32), ('wait_main', i32), ('nargs', i32), ('a', C.c_uint64 * 17)]
+
+
+# RD_OP_* (include/ramdsir.h) by entry-point name
+OP_FORK, OP_JOIN = 1, 2
+OP_CODES = {name: 10 + i for i, name in enumerate((
+    'rd_conv', 'rd_wgrad', 'rd_conv_bwd_fused', 'rd_conv_bwd_fused_reduce', 'rd_pack_weights_batched',
+    'rd_bn_finalize_fwd', 'rd_bn_finalize_bwd', 'rd_gn_finalize_fwd', 'rd_gn_finalize_bwd',
+    'rd_up_stats', 'rd_bn_stats', 'rd_up_bwd', 'rd_pool_fwd', 'rd_pool_bwd', 'rd_bn_apply',
+    'rd_nchw_to_nhwc', 'rd_nhwc_to_nchw', 'rd_grad_in', 'rd_colsum',
+    'rd_seg_loss', 'rd_rec_loss', 'rd_adam_step', 'rd_zero', 'rd_ram_mix'))}
+
 _SIGS = {
     'rd_ram_workspace': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'rd_ram_mix': (C.c_int, [C.POINTER(RdRam), C.c_int, vp]),
@@ -117,6 +131,8 @@ _SIGS = {
     'rd_rec_loss_workspace': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'rd_adam_step': (C.c_int, [C.POINTER(RdAdam), vp]),
     'rd_zero': (C.c_int, [C.POINTER(vp), C.POINTER(i64), C.c_int, vp]),
+    'rd_run_list': (C.c_int, [C.POINTER(RdLaunch), C.c_int, C.POINTER(vp), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    'rd_join_lanes': (C.c_int, [C.POINTER(vp), C.c_int, C.c_uint32]),
 }
 
 _lib = None
@@ -145,6 +161,26 @@ def lib():
 def check(err, what=''):
     if err != 0:
         raise RuntimeError('ramdsir HIP call failed (%s): error %d' % (what, err))
+
+
+def pack_arg(value, ctype):
+    """One argument of an entry point as the 64-bit word rd_launch_t.a[] carries (include/ramdsir.h): pointers and integers as they
+    are, a float as its bit pattern."""
+    import struct
+    if value is None:
+        return 0
+    if ctype is f32 or ctype is C.c_float:
+        return struct.unpack('<I', struct.pack('<f', float(value)))[0]
+    if ctype in (C.c_int, i32, i64, C.c_int64, C.c_uint32):
+        return int(value) & 0xFFFFFFFFFFFFFFFF
+    # pointer-like: byref(obj), a ctypes array / structure, a c_void_p, or a raw address
+    if hasattr(value, '_obj'):
+        return C.addressof(value._obj)
+    if isinstance(value, (C.Array, C.Structure)):
+        return C.addressof(value)
+    if isinstance(value, C.c_void_p):
+        return value.value or 0
+    return int(value)
 
 
 def gstart_array(gs):

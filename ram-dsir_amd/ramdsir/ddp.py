@@ -90,17 +90,23 @@ class DataParallelStep:
         ts._restore(saved)
         torch.cuda.synchronize()
 
+    def _names(self, i):
+        """Segment i of the eager step by name (TrainStep.launch): A = reset + [RAM] + forward + decoder backwards, B1 / B2 = encoder
+        backward, C = Adam + repack -- with the next batch's RAM beside it when load_raw_next() has provided one (step.py)."""
+        ts = self.ts
+        return (ts.head_names(), ('seg_b1',), ('seg_b2',), (ts.tail_name(),))[i]
+
     def _run(self, i, main):
         if self.graphs is not None:
             self.graphs[i].replay()
         else:
-            if i == 0:
-                self.ts.zero()
-            self.ts.run_segment(self._segments()[i], main)
+            self.ts.launch(self._names(i), main)
 
     def step(self):
         main = torch.cuda.current_stream()
         works = []
+        if self.graphs is not None and (self.ts._slot != 0 or self.ts._x_ready or self.ts._next_loaded):
+            raise RuntimeError('captured graphs replay the classical step on input slot 0: do not mix them with load_raw_next()')
         # segment -> bucket that is complete when it ends: A -> decoders (2), B1 -> deep encoder (1), B2 -> shallow (0)
         plan = ((0, 2), (1, 1), (2, 0))
         if self.graphs is not None:
@@ -114,22 +120,24 @@ class DataParallelStep:
             # would serialise the dgrad chain behind the weight gradients three times per step); a bucket's exchange
             # waits for the main stream and for every lane with work outstanding -- the lanes are in-order queues, so
             # their state at this point covers exactly the gradients of the segments launched so far
+            # the segments go through the same native launch loop as the single-GPU step (TrainStep.launch -> rd_run_list), the open
+            # lanes carried from one segment to the next as its bitmask
             ts = self.ts
-            lanes, open_lanes = ts.lanes(), set()
-            ts.zero()
-            segs = self._segments()
+            lanes, mask, ll = ts.lanes(), 0, None
             for seg_i, bucket in plan:
-                open_lanes |= E.Plan.run_lanes(segs[seg_i], main, lanes)
+                ll, mask = ts.launch(self._names(seg_i), main, lanes, open_mask=mask, join=False)
                 self.comm.wait_stream(main)
-                for name in open_lanes:
-                    if lanes[name] is not self.comm:
+                for k, name in enumerate(ll.lane_names):
+                    if mask & (1 << (k + 1)) and lanes[name] is not self.comm:
                         self.comm.wait_stream(lanes[name])
                 with torch.cuda.stream(self.comm):
                     works.append(self.buckets.reduce(bucket, async_op=True))
-            for name in open_lanes:
-                main.wait_stream(lanes[name])
+            if ll is not None:
+                ll.join(main, lanes, mask)
         for w in works:
             if w is not None:
                 w.wait()
         main.wait_stream(self.comm)
         self._run(3, main)
+        if self.graphs is None:
+            self.ts.advance()

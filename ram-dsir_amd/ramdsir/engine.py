@@ -748,6 +748,62 @@ class Plan:
         return open_lanes
 
 
+class LaunchList:
+    """A launch list compiled for rd_run_list (include/ramdsir.h): the same entries, lanes and fork / join semantics as
+    Plan.run_lanes, walked in C++ with ONE ctypes call per segment instead of one call + one event record / stream wait per entry
+    (2.2 ms of host time per step -> a fraction).  `lane_names`: the lanes that exist, in stream-index order (index 0 is the main
+    stream); entries of a lane that does not exist run on the main stream, exactly as in run_lanes.  The descriptors referenced by
+    the entries are owned by the plans (Plan.keep); `ops` is kept so that they stay alive with the list."""
+
+    def __init__(self, ops, lane_names):
+        self.lane_names = list(lane_names)
+        idx = {name: i + 1 for i, name in enumerate(self.lane_names)}
+        entries = []
+        for op in ops:
+            fn, args = op[0], op[1]
+            meta = op[2] if len(op) > 2 else None
+            e = L.RdLaunch()
+            if fn is None:
+                kind, lane = args
+                if lane not in idx:
+                    continue
+                e.op, e.lane = (L.OP_FORK if kind == 'fork' else L.OP_JOIN), idx[lane]
+                entries.append(e)
+                continue
+            e.op = L.OP_CODES[fn.__name__]
+            if meta is not None:
+                if meta.get('lane') == 'rec' and 'rec' in idx:
+                    e.lane = idx['rec']
+                elif meta.get('side') and 'side0' in idx:
+                    name = 'side%d' % meta.get('side_idx', 0)
+                    e.lane, e.wait_main = idx[name if name in idx else 'side0'], 1
+            types = fn.argtypes[:-1]                         # without the trailing stream
+            assert len(types) == len(args) <= 17, (fn.__name__, len(types), len(args))
+            e.nargs = len(args)
+            for i, (v, t) in enumerate(zip(args, types)):
+                e.a[i] = L.pack_arg(v, t)
+            entries.append(e)
+        self.n = len(entries)
+        self.arr = (L.RdLaunch * max(self.n, 1))(*entries)
+        self.ops = ops
+        self._bad = C.c_int(-1)
+
+    def run(self, main, lanes, open_mask=0):
+        """Enqueue the list; returns the bitmask of lanes left open (bit k = lane_names[k - 1])."""
+        streams = (L.vp * (1 + len(self.lane_names)))(main.cuda_stream, *[lanes[nm].cuda_stream for nm in self.lane_names])
+        mask = C.c_uint32(open_mask)
+        err = L.lib().rd_run_list(self.arr, self.n, streams, len(streams), C.byref(mask), C.byref(self._bad))
+        if err:
+            bad = self._bad.value
+            raise RuntimeError('ramdsir launch list failed at entry %d (op %d): error %d' % (bad, self.arr[bad].op if 0 <= bad < self.n else -1, err))
+        return mask.value
+
+    def join(self, main, lanes, mask):
+        if mask:
+            streams = (L.vp * (1 + len(self.lane_names)))(main.cuda_stream, *[lanes[nm].cuda_stream for nm in self.lane_names])
+            L.check(L.lib().rd_join_lanes(streams, len(streams), mask), 'rd_join_lanes')
+
+
 def sync_op(kind, lane):
     """Pseudo-op for Plan.run_lanes: 'fork' = the lane's stream waits for the main stream here, 'join' = the
     main stream waits for everything the lane has been given so far."""

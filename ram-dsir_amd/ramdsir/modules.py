@@ -12,9 +12,24 @@ from . import _lib as L
 from . import engine as E
 
 
+_storage_override = None
+
+
+def set_storage_dtype(dtype):
+    """Activation storage type of the module-level path for this process (torch.float32 / torch.bfloat16; None: back to the
+    RAMDSIR_DTYPE environment default).  ramdsir.trainer.ModuleTrainer sets it from its `dtype` argument, so that
+    `train.py --norm gn --dtype bf16` really trains in bf16 storage."""
+    global _storage_override
+    if dtype not in (None, torch.float32, torch.bfloat16):
+        raise ValueError('storage dtype must be torch.float32 or torch.bfloat16, got %r' % (dtype,))
+    _storage_override = dtype
+
+
 def storage_dtype():
-    """Activation storage type of the module-level path: fp32 (default, parity-grade) or bf16
+    """Activation storage type of the module-level path: set_storage_dtype() if called, else fp32 (default, parity-grade) or bf16
     (RAMDSIR_DTYPE=bf16).  The fused trainer chooses its own dtype."""
+    if _storage_override is not None:
+        return _storage_override
     return torch.bfloat16 if os.environ.get('RAMDSIR_DTYPE', 'f32') == 'bf16' else torch.float32
 
 

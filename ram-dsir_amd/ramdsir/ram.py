@@ -44,6 +44,12 @@ class RamMixer:
             p.clip_lo, p.clip_hi, p.scale, p.div, p.offset = -1.0, 1.0, 1.0, 0.0, 0.0
         self.p = p
 
+    def share_workspace(self, other):
+        """Use another mixer's workspace and twiddle tables (same geometry; the two are never in flight together)."""
+        assert (self.B, self.H, self.W, self.b) == (other.B, other.H, other.W, other.b)
+        self.ws, self.tw_w, self.tw_h = other.ws, other.tw_w, other.tw_h
+        self.p.workspace, self.p.tw_w, self.p.tw_h = self.ws.data_ptr(), self.tw_w.data_ptr(), self.tw_h.data_ptr()
+
     def bind(self, src, trg, lam, out_img, out_freq, trg_amp=None):
         """src/trg: NHWC [B,H,W,3], both fp32 or both uint8 (decoded PNG pixels); lam: fp32 [B]; outputs: NHWC `dtype`
         [B,H,W,Cs] with Cs == 3 (dense) or one 16-byte slot (channels 3.. are then written as zeros).  trg_amp: fp32

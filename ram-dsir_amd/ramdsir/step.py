@@ -106,16 +106,23 @@ class TrainStep:
         # ---- RAM (optional: raw images + partner images + lambda in, both network inputs out)
         # ram = True: fp32 source / partner buffers; ram = 'u8': uint8 buffers (decoded PNG pixels of the Fundus pipeline:
         # 1 byte per value over PCIe and out of HBM; the values are the same integers the reference holds as float32)
+        # TWO input slots (src / trg / lam) with one RAM descriptor each, both writing the network input x: while step N runs on slot
+        # k, the host uploads batch N+1 into slot 1-k (load_raw_next), and step N's tail mixes it (step(): the pipelined form below)
         self.ram = None
+        self._slot, self._x_ready, self._next_loaded = 0, False, False
         if ram:
             idt = torch.uint8 if ram == 'u8' else torch.float32
-            self.src = torch.zeros(B, H, W, in_channels, dtype=idt, device=dev)
-            self.trg = torch.zeros(B, H, W, in_channels, dtype=idt, device=dev)
-            self.lam = torch.ones(B, dtype=torch.float32, device=dev)
-            self.ram = R.RamMixer(B, H, W, dtype, dev, dataset)
-            self.ram.bind(self.src, self.trg, self.lam, self.x.buf[:B], self.x.buf[B:])
+            self.raw_slots = [(torch.zeros(B, H, W, in_channels, dtype=idt, device=dev), torch.zeros(B, H, W, in_channels, dtype=idt, device=dev),
+                               torch.ones(B, dtype=torch.float32, device=dev)) for _ in range(2)]
+            self.rams = [R.RamMixer(B, H, W, dtype, dev, dataset) for _ in range(2)]
+            self.rams[1].share_workspace(self.rams[0])               # never in flight together: x is written by one RAM at a time
+            for k in range(2):
+                self.rams[k].bind(*self.raw_slots[k], self.x.buf[:B], self.x.buf[B:])
+            self.ram = self.rams[0]
+            self.src, self.trg, self.lam = self.raw_slots[0]         # the current slot's buffers (load_raw's destination)
         self.graph = None
         self._zero_args = None
+        self._native = {}
         # eager execution uses three HIP streams (Plan.run_lanes): main = the forward / dgrad chain, 'side' = the
         # weight-gradient kernels beside it, 'rec' = the whole restoration-decoder branch beside the seg decoder.
         # RD_FORK=0: everything on one stream.  Captured into a hipGraph the same forks become parallel branches,
@@ -151,8 +158,6 @@ class TrainStep:
                                       self.rec.G, self.rec.gs_arr,
                                       self.lambda_rec, self.dt))
         a = []
-        if self.ram is not None:
-            a.append(self.ram.op())
         a += self.seg.fwd[:fdec]                                     # encoder
         a.append(E.sync_op('fork', 'rec'))
         rec_branch = E.tag_lane(self.rec.fwd + [rec_loss] + self.rec.bwd[:-1], 'rec')
@@ -168,8 +173,20 @@ class TrainStep:
         self.seg_b1, self.seg_b2 = b[:cut], b[cut:]
         self.enc_deep_offset = min(off for (m, k), (off, _) in self.bank.index.items() if m == 'enc' and k.startswith('convd3.'))
         c = [(lib.rd_adam_step, (C.byref(self.ad),)), self.wpack.refresh_op()]
-        self.seg_a, self.seg_b, self.seg_c = a, b, c
-        return a + b + c
+        # RAM of slot k as a head segment (the classical step: mix, then train on it) and as part of the tail (the pipelined step:
+        # the NEXT batch is mixed on the restoration lane -- idle by then -- beside Adam + weight repack, after every reader of x
+        # (first conv forward, its weight gradient, the restoration loss) has been joined)
+        self.seg_a_noram = a
+        self.seg_ram0 = [self.rams[0].op()] if self.ram is not None else []
+        self.seg_ram1 = [self.rams[1].op()] if self.ram is not None else []
+        for k in range(2):
+            tail = []
+            if self.ram is not None:
+                tail = [E.sync_op('fork', 'rec')] + E.tag_lane([self.rams[k].op()], 'rec')
+            setattr(self, 'seg_c_pf%d' % k, tail + c + ([E.sync_op('join', 'rec')] if tail else []))
+        # the classical segments (RAM of slot 0 at the head of A): hipGraph capture, the data-parallel step's fallback, the scripts
+        self.seg_a, self.seg_b, self.seg_c = self.seg_ram0 + a, b, c
+        return self.seg_a + b + c
 
     def lanes(self):
         if not self.fork:
@@ -193,13 +210,31 @@ class TrainStep:
         transformed image and the partner image as HWC arrays, and the mix ratio.  The buffers are uint8 when the step
         was built with ram='u8' (decoded PNG pixels) and float32 otherwise; a float image handed to a uint8 step would be
         truncated / wrapped by the copy where the reference mixes it as float32, so that combination is refused."""
+        self._copy_raw(self._slot, src_nhwc, trg_nhwc, lam)
+        self._x_ready, self._next_loaded = False, False
+
+    def load_raw_next(self, src_nhwc, trg_nhwc, lam):
+        """The RAM inputs of the NEXT step, into the other input slot: the following step() then mixes them in its tail (beside Adam
+        and the weight repack) instead of opening the step after it with three latency-bound RAM launches.  Call order per
+        iteration: load_raw_next(batch N+1); step(); load_target(mask N+1) -- the target buffer is single: it is read by step N's
+        loss, so the next mask is uploaded after step N has been enqueued (stream order does the rest)."""
+        self._copy_raw(1 - self._slot, src_nhwc, trg_nhwc, lam)
+        self._next_loaded = True
+
+    def reuse_next(self):
+        """The other input slot already holds the next batch (inputs resident in HBM: bench.py steps over one synthetic batch that
+        was loaded into both slots): the following step() runs pipelined without a copy."""
+        self._next_loaded = True
+
+    def _copy_raw(self, slot, src_nhwc, trg_nhwc, lam):
+        src, trg, lm = self.raw_slots[slot]
         for name, t in (('src', src_nhwc), ('trg', trg_nhwc)):
-            if self.src.dtype == torch.uint8 and t.dtype != torch.uint8:
+            if src.dtype == torch.uint8 and t.dtype != torch.uint8:
                 raise TypeError('%s images are %s but this TrainStep was built with ram=\'u8\' (uint8 buffers): pass uint8 '
                                 'pixels or build the step with ram=True (float32 buffers)' % (name, t.dtype))
-        self.src.copy_(src_nhwc)
-        self.trg.copy_(trg_nhwc)
-        self.lam.copy_(lam)
+        src.copy_(src_nhwc, non_blocking=True)
+        trg.copy_(trg_nhwc, non_blocking=True)
+        lm.copy_(lam, non_blocking=True)
 
     def load_target(self, mask):
         self.target.copy_(mask)
@@ -211,22 +246,75 @@ class TrainStep:
     # ---- execution
     def zero(self, stream=None):
         """optimizer.zero_grad() (train.py:285) + the BatchNorm sum arenas, through the library (rd_zero)."""
-        if self._zero_args is None:
-            ts = (self.seg.stat_arena, self.rec.stat_arena, self.bank.grads)
-            self._zero_args = ((L.vp * 3)(*[t.data_ptr() for t in ts]), (L.i64 * 3)(*[t.numel() * t.element_size() for t in ts]))
-        L.check(L.lib().rd_zero(self._zero_args[0], self._zero_args[1], 3, self._stream() if stream is None else stream), 'rd_zero')
+        fn, args = self.zero_op()
+        L.check(fn(*args, self._stream() if stream is None else stream), 'rd_zero')
 
     def run_segment(self, ops, main=None, lanes=None, wrap=None):
-        """One segment over the lanes; every lane it used is joined before returning."""
+        """One segment over the lanes, entry by entry from Python (Plan.run_lanes: the instrumented path -- `wrap` may time each
+        launch); every lane it used is joined before returning.  Plain execution goes through launch() below."""
         main = torch.cuda.current_stream() if main is None else main
         lanes = self.lanes() if lanes is None else lanes
         for lane in E.Plan.run_lanes(ops, main, lanes, wrap):
             main.wait_stream(lanes[lane])
 
+    def zero_op(self):
+        if self._zero_args is None:
+            ts = (self.seg.stat_arena, self.rec.stat_arena, self.bank.grads)
+            self._zero_args = ((L.vp * 3)(*[t.data_ptr() for t in ts]), (L.i64 * 3)(*[t.numel() * t.element_size() for t in ts]))
+        return (L.lib().rd_zero, (self._zero_args[0], self._zero_args[1], 3))
+
+    def native_list(self, names, lanes, join_before_last=False):
+        """The segments `names` (attribute names: 'seg_a', 'seg_b', ...; 'zero' = the per-step reset) as ONE native launch list
+        (engine.LaunchList -> rd_run_list), compiled once per lane configuration and rebuilt when a segment list has been replaced
+        (scripts/ablate_step.py, bench.py's ablation) or changed length.  join_before_last: every lane is joined in front of the
+        last segment (the optimizer must see all gradients)."""
+        lane_names = tuple(lanes.keys())
+        key = (tuple(names), lane_names, join_before_last)
+        lists = [[self.zero_op()] if nm == 'zero' else getattr(self, nm) for nm in names]
+        ent = self._native.get(key)
+        # stale when a segment attribute now holds another list object, or the same object with another length
+        fresh = ent is not None and all(nm == 'zero' or (src is l and n == len(l)) for nm, l, (src, n) in zip(names, lists, ent[1]))
+        if not fresh:
+            ops = []
+            for i, l in enumerate(lists):
+                if join_before_last and i == len(lists) - 1:
+                    ops += [E.sync_op('join', ln) for ln in lane_names]
+                ops += l
+            ent = (E.LaunchList(ops, lane_names), [(l, len(l)) for l in lists])
+            self._native[key] = ent
+        return ent[0]
+
+    def launch(self, names, main=None, lanes=None, open_mask=0, join=True, join_before_last=False):
+        """Enqueue segments through the native launch loop: ONE ctypes call.  Returns (list, bitmask of the lanes still open)."""
+        main = torch.cuda.current_stream() if main is None else main
+        lanes = self.lanes() if lanes is None else lanes
+        ll = self.native_list(names, lanes, join_before_last)
+        mask = ll.run(main, lanes, open_mask)
+        if join and mask:
+            ll.join(main, lanes, mask)
+            mask = 0
+        return ll, mask
+
     def run_eager(self, lanes=None):
-        self.zero()
-        self.run_segment(self.seg_a + self.seg_b, lanes=lanes)   # one join of the weight-gradient stream, right before Adam
-        self.run_segment(self.seg_c, lanes=lanes)
+        """The classical step on input slot 0: RAM, forward, backward, ONE join of the weight-gradient lane right before Adam, Adam +
+        repack -- one native call (rd_run_list)."""
+        self.launch(('zero', 'seg_a', 'seg_b', 'seg_c'), lanes=lanes, join_before_last=True)
+
+    def head_names(self):
+        """Segment names of the step's head: the reset, RAM of the current slot unless the previous step's tail has mixed it already."""
+        return ('zero',) + (() if (self._x_ready or self.ram is None) else ('seg_ram%d' % self._slot,)) + ('seg_a_noram',)
+
+    def tail_name(self):
+        return 'seg_c_pf%d' % (1 - self._slot) if (self._next_loaded and self.ram is not None) else 'seg_c'
+
+    def advance(self):
+        """Bookkeeping after a step has been enqueued: a pipelined tail has left the next batch's x ready and flips the slots."""
+        if self._next_loaded and self.ram is not None:
+            self._slot, self._x_ready = 1 - self._slot, True
+            self.src, self.trg, self.lam = self.raw_slots[self._slot]
+        else:
+            self._x_ready = False
+        self._next_loaded = False
 
     def capture(self):
         """Capture one step (zeroing + every launch) into a hipGraph on a side stream."""
@@ -270,10 +358,15 @@ class TrainStep:
         self.wpack.refresh(self._stream())
 
     def step(self):
+        """One training step on the current input slot.  If load_raw_next() has been called, the tail also mixes the next batch
+        (pipelined form); a captured graph always replays the classical list on slot 0."""
         if self.graph is not None:
+            if self._slot != 0 or self._x_ready or self._next_loaded:
+                raise RuntimeError('a captured hipGraph replays the classical step on input slot 0: do not mix it with load_raw_next()')
             self.graph.replay()
-        else:
-            self.run_eager()
+            return
+        self.launch(self.head_names() + ('seg_b', self.tail_name()), join_before_last=True)
+        self.advance()
 
     def loss_dict(self):
         """Synchronises.  Names follow the tensorboard scalars of train.py:298-304."""

@@ -27,6 +27,7 @@ class FusedTrainer:
                               # a captured graph replays one chain: no lane to leave compute units to (tuning.py)
                               options=dict(side_cus=0, rec_cus=0) if use_graph else None)
         self.ts.wpack.refresh()
+        self._primed, self._graphs = False, bool(use_graph)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         if self.world > 1:
             # identical initial weights on every rank (DataParallel broadcasts replica 0's, train.py:205-208)
@@ -43,13 +44,24 @@ class FusedTrainer:
                 self.ts.capture()
             self._step = self.ts.step
 
-    def step(self, src_nhwc, trg_nhwc, lam, target):
+    def step(self, src_nhwc, trg_nhwc, lam, target, next_batch=None):
         """src/trg: NHWC images as the dataset holds them before RAM -- fundus: uint8 pixels 0..255 (the step is built with
         uint8 RAM buffers; float images are refused by TrainStep.load_raw), prostate: float32 in [-1,1];
-        lam: [B]; target: fundus (B,2,H,W) float multilabel mask / prostate (B,H,W) int64."""
-        self.ts.load_raw(src_nhwc, trg_nhwc, lam)
-        self.ts.load_target(target)
+        lam: [B]; target: fundus (B,2,H,W) float multilabel mask / prostate (B,H,W) int64.
+        next_batch = (src, trg, lam, target) of the FOLLOWING step, if the caller has it: its images go into the other input slot now
+        and are mixed (RAM) in this step's tail, beside Adam and the weight repack, instead of opening the next step alone
+        (step.TrainStep.load_raw_next); the next call's first four arguments are then ignored -- that batch is already on the
+        device.  Not with captured graphs (they replay the classical step)."""
+        if not self._primed:
+            self.ts.load_raw(src_nhwc, trg_nhwc, lam)
+            self.ts.load_target(target)
+        pipelined = next_batch is not None and not self._graphs
+        if pipelined:
+            self.ts.load_raw_next(*next_batch[:3])
         self._step()
+        if pipelined:
+            self.ts.load_target(next_batch[3])            # after the step has been enqueued: its loss still reads the current mask
+        self._primed = pipelined
 
     def losses(self):
         """The five loss terms + per-domain rec losses (names of the tensorboard scalars, train.py:298-304).  Data parallel:
@@ -90,12 +102,31 @@ class ModuleTrainer:
         self.opt = Adam([{'params': encoder.parameters(), 'lr': lr / 2}, {'params': seg_decoder.parameters(), 'lr': lr},
                          {'params': rec_decoder.parameters(), 'lr': lr}], lr=lr, betas=(0.9, 0.999))                 # train.py:573-576
         self._last = None
+        # the modules' activation storage follows `dtype` (the default of train.py --dtype is bf16; the RAMDSIR_DTYPE environment default
+        # of the module path is fp32: without this the flag was silently ignored here)
+        from . import modules as M
+        M.set_storage_dtype(dtype)
+        self.dtype = dtype
+        # ONE RAM plan (twiddles, workspace, the two output tensors), bound per step: the geometry is fixed
+        from .ram import RamMixer
+        B = sum(self.bs)
+        dev = next(encoder.parameters()).device
+        self._ram = RamMixer(B, H, W, torch.float32, dev, dataset)
+        self._ram_out = (torch.empty(B, H, W, 3, dtype=torch.float32, device=dev), torch.empty(B, H, W, 3, dtype=torch.float32, device=dev))
 
-    def step(self, src_nhwc, trg_nhwc, lam, target):
+    def _mix(self, src_nhwc, trg_nhwc, lam):
+        """(img, img_freq) NCHW fp32 in [-1, 1] (ram.source_to_target_freq_batch with the plan built once)."""
+        if not (src_nhwc.dtype == torch.uint8 and trg_nhwc.dtype == torch.uint8):
+            src_nhwc, trg_nhwc = src_nhwc.float(), trg_nhwc.float()
+        oi, of = self._ram_out
+        self._ram.bind(src_nhwc.contiguous(), trg_nhwc.contiguous(), lam.float().contiguous(), oi, of)
+        self._ram.run()
+        return oi.permute(0, 3, 1, 2).contiguous(), of.permute(0, 3, 1, 2).contiguous()
+
+    def step(self, src_nhwc, trg_nhwc, lam, target, next_batch=None):
         import torch.nn.functional as F
-        from ramdsir.ram import source_to_target_freq_batch
         from utils.losses import dice_loss, dice_loss_multi
-        img, img_freq = source_to_target_freq_batch(src_nhwc, trg_nhwc, lam, self.dataset)
+        img, img_freq = self._mix(src_nhwc, trg_nhwc, lam)
         fundus = self.dataset == 'fundus'
 
         def seg(feats):

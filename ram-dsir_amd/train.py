@@ -115,15 +115,19 @@ def _val_resources(data_dir, datasetTest, batch_size):
         loader = DataLoader(testset, batch_size=batch_size, num_workers=nw, shuffle=False, drop_last=False, pin_memory=True,
                             persistent_workers=True)
         pool = mp.get_context('fork').Pool(min(16, max(2, (os.cpu_count() or 4) // 4)))     # children never touch the GPU
-        _VAL[key] = (loader, pool)
-    return _VAL[key]
+        # a DataLoader forks its workers at the first iter(), not at construction: start them NOW (main() calls this before the
+        # first GPU call), so that they too are forked from an address space that has never initialised HIP.  With
+        # persistent_workers the DataLoader keeps this iterator (and its workers) and resets it at every later `for ... in loader`.
+        it = iter(loader)
+        _VAL[key] = (loader, pool, it)
+    return _VAL[key][:2]
 
 
 def _close_val():
-    for loader, pool in _VAL.values():
+    for loader, pool, it in _VAL.values():
         pool.terminate()
         pool.join()
-        del loader                                          # persistent workers shut down with the loader's iterator
+        del it, loader                                      # persistent workers shut down with the loader's iterator
     _VAL.clear()
 
 
@@ -182,8 +186,9 @@ def main(args):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     data_root = os.path.join(args.data_root, args.dataset)
-    # The validation pool (fork) and the persistent test loader are created HERE, before the first GPU call of this process:
-    # their children are forked from an address space that has never initialised HIP (rank 0 validates, below)
+    # The validation pool (fork) and the persistent test loader -- with its worker processes started (_val_resources) -- are created
+    # HERE, before the first GPU call of this process: their children are forked from an address space that has never initialised
+    # HIP (rank 0 validates, below)
     has_val = args.dataset == 'fundus' and os.path.exists(os.path.join(data_root, 'Domain%d_test.list' % (args.test_domain_idx + 1)))
     if rank == 0 and has_val:
         _val_resources(data_root, args.test_domain_idx, args.test_batch_size)
@@ -262,12 +267,23 @@ def main(args):
         for sp in samplers:
             if sp is not None:
                 sp.set_epoch(epoch)
-        for i, batches in enumerate(zip(*loaders)):
-            src = torch.cat([b[0] for b in batches], 0).cuda(non_blocking=True)
-            trg = torch.cat([b[1] for b in batches], 0).cuda(non_blocking=True)
-            lam = torch.cat([b[2] for b in batches], 0).cuda(non_blocking=True)
-            mask = torch.cat([b[3] for b in batches], 0).cuda(non_blocking=True)
-            trainer.step(src, trg, lam, mask)
+        def on_device(batches):
+            return tuple(torch.cat([b[k] for b in batches], 0).cuda(non_blocking=True) for k in range(4))       # src, trg, lam, mask
+
+        # one batch of look-ahead: the step of batch i also mixes batch i+1 (RAM) in its tail, beside Adam and the weight repack
+        # (FusedTrainer.step next_batch; the last iteration of an epoch -- or of --max_iters -- has no successor and runs the
+        # classical step)
+        stream_it = iter(zip(*loaders))
+        cur = next(stream_it, None)
+        cur = on_device(cur) if cur is not None else None
+        i = -1
+        while cur is not None:
+            i += 1
+            nxt = next(stream_it, None)
+            last = nxt is None or bool(args.max_iters and iter_num + 1 >= args.max_iters)
+            nxt = None if last else on_device(nxt)
+            trainer.step(*cur, next_batch=nxt)
+            cur = nxt
             if iter_num % args.log_every == 0:
                 l = trainer.losses()                    # collective when world > 1: the mean over the ranks
             if rank == 0 and iter_num % args.log_every == 0:

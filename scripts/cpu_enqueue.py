@@ -26,6 +26,26 @@ print('eager: CPU enqueue %.2f ms/step, until GPU done %.2f ms/step (%d launches
 torch.cuda.synchronize()
 t0 = time.perf_counter(); ts.step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print('single step on an idle GPU: enqueue %.2f ms, done after %.2f ms' % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+# the same step entry by entry from Python (Plan.run_lanes: one ctypes call + event record / stream wait per entry), for comparison
+def python_step():
+    ts.zero()
+    ts.run_segment(ts.seg_a + ts.seg_b)
+    ts.run_segment(ts.seg_c)
+for _ in range(3):
+    python_step()
+torch.cuda.synchronize()
+best = []
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); python_step(); t1 = time.perf_counter(); torch.cuda.synchronize()
+    best.append((t1 - t0) * 1e3)
+print('python launch loop, single step on an idle GPU: enqueue %.2f ms (min of 5: %.2f)' % (sum(best) / 5, min(best)))
+best = []
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); ts.step(); t1 = time.perf_counter(); torch.cuda.synchronize()
+    best.append((t1 - t0) * 1e3)
+print('native launch list (rd_run_list), single step on an idle GPU: enqueue %.2f ms (min of 5: %.2f)' % (sum(best) / 5, min(best)))
 # one chain: rebuilt without the lane budgets (TrainStep.capture refuses them)
 ts = S.TrainStep(bank, mods, torch.bfloat16, [2, 3, 3], 400, 400, ram='u8', options=dict(side_cus=0, rec_cus=0))
 ts.wpack.refresh(); ts.load_raw(src, trg, lam); ts.load_target(mask)

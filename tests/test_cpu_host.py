@@ -36,7 +36,7 @@ def test_ctypes_struct_sizes_match_the_c_compiler(tmp_path):
     from ramdsir import _lib as L
     names = {'rd_src_t': L.RdSrc, 'rd_dst_t': L.RdDst, 'rd_conv_t': L.RdConv, 'rd_wgrad_t': L.RdWgrad, 'rd_bn_fwd_t': L.RdBnFwd,
              'rd_bn_bwd_t': L.RdBnBwd, 'rd_seg_loss_t': L.RdSegLoss, 'rd_adam_t': L.RdAdam, 'rd_pack_entry_t': L.RdPackEntry,
-             'rd_ram_t': L.RdRam}
+             'rd_ram_t': L.RdRam, 'rd_launch_t': L.RdLaunch}
     src = '#include <stdio.h>\n#include "ramdsir.h"\nint main(){' + ''.join(
         'printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + 'return 0;}'
     c = tmp_path / 's.c'
@@ -47,6 +47,48 @@ def test_ctypes_struct_sizes_match_the_c_compiler(tmp_path):
     sizes = dict(zip(out[0::2], map(int, out[1::2])))
     for n, cls in names.items():
         assert ctypes.sizeof(cls) == sizes[n], n
+
+
+def test_launch_list_packing_and_lanes():
+    """engine.LaunchList (-> rd_run_list): entries in list order, lane / wait_main as Plan.run_lanes routes them, arguments packed as
+    include/ramdsir.h says (pointers and integers as they are, a float as its bit pattern); no GPU call is made."""
+    import struct
+    from ramdsir import _lib as L, engine as E
+    lib = L.lib()
+    assert ctypes.sizeof(L.RdLaunch) == 16 + 8 * 17
+    assert L.pack_arg(1.5, L.f32) == struct.unpack('<I', struct.pack('<f', 1.5))[0]
+    assert L.pack_arg(-1, ctypes.c_int) == 0xFFFFFFFFFFFFFFFF and L.pack_arg(None, L.vp) == 0 and L.pack_arg(4096, L.vp) == 4096
+    p, gs = L.RdConv(), L.gstart_array([0, 2, 4])
+    assert L.pack_arg(ctypes.byref(p), ctypes.POINTER(L.RdConv)) == ctypes.addressof(p)
+    assert L.pack_arg(gs, ctypes.POINTER(L.i32)) == ctypes.addressof(gs)
+    ops = [(lib.rd_conv, (ctypes.byref(p), 1), dict(kernel='x')),
+           E.sync_op('fork', 'rec'),
+           (lib.rd_pool_fwd, (0x1000, None, None, 0.25, 0x2000, 4, 5, 6, 16, 2, gs, 1), dict(lane='rec')),
+           (lib.rd_wgrad, (ctypes.byref(L.RdWgrad()), 1), dict(side=True, side_idx=0)),
+           E.sync_op('join', 'rec'),
+           (lib.rd_adam_step, (ctypes.byref(L.RdAdam()),))]
+    ll = E.LaunchList(ops, ('side0', 'rec'))
+    got = [(e.op, e.lane, e.wait_main, e.nargs) for e in ll.arr[:ll.n]]
+    oc = L.OP_CODES
+    assert got == [(oc['rd_conv'], 0, 0, 2), (L.OP_FORK, 2, 0, 0), (oc['rd_pool_fwd'], 2, 0, 12), (oc['rd_wgrad'], 1, 1, 2),
+                   (L.OP_JOIN, 2, 0, 0), (oc['rd_adam_step'], 0, 0, 1)]
+    e = ll.arr[2]
+    assert e.a[0] == 0x1000 and e.a[1] == 0 and e.a[3] == L.pack_arg(0.25, L.f32) and e.a[10] == ctypes.addressof(gs) and e.a[11] == 1
+    # without lanes everything runs on the main stream and the fork / join entries vanish (Plan.run_lanes' fallback)
+    l0 = E.LaunchList(ops, ())
+    assert [(e.op, e.lane, e.wait_main) for e in l0.arr[:l0.n]] == [(oc['rd_conv'], 0, 0), (oc['rd_pool_fwd'], 0, 0), (oc['rd_wgrad'], 0, 0),
+                                                                    (oc['rd_adam_step'], 0, 0)]
+    # the op codes of the binding are the header's enum
+    txt = open(os.path.join(ROOT, 'include', 'ramdsir.h')).read()
+    enum = re.search(r'enum \{\s*RD_OP_FORK = 1, RD_OP_JOIN = 2,(.*?)\};', txt, re.S).group(1)
+    names, val = [], 10
+    for tok in [t.strip() for t in enum.replace('\n', ' ').split(',') if t.strip()]:
+        if '=' in tok:
+            tok, v = [x.strip() for x in tok.split('=')]
+            val = int(v)
+        names.append((tok, val))
+        val += 1
+    assert {('RD_OP_' + k[3:].upper(), v) for k, v in oc.items()} == set(names)
 
 
 def test_parameter_layout_equals_reference_manifest(golden_dir):

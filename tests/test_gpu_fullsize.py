@@ -19,7 +19,8 @@ Tolerances and where they come from
          with fp32 is not defined (logits 12 %, gradients ~40 % relative L2 -- and the SAME numbers separate the fp32 oracle
          from the oracle run with bf16 rounding at the HIP path's rounding points, oracle.unet.rounding).  Asserted instead:
          losses within 2e-3 of that rounding-model oracle (measured 5e-4) and 3e-2 of fp32; logits closer to the rounding
-         model than the rounding model is to fp32; the full gradient's direction (cosine >= 0.85 vs the model; measured 0.97);
+         model than the rounding model is to fp32; the full gradient's direction (cosine >= 0.93 vs the model; measured 0.97) and
+         its distance from the model's own one-ulp self-distance, at every configuration;
          and a 20-step fixed-batch loss trajectory inside a band around the fp32 oracle's (torch-Adam restatement).
 """
 import functools
@@ -56,7 +57,9 @@ def _flat(grads, keys):
     return torch.cat([grads[k].double().reshape(-1) for k in keys])
 
 
-@pytest.mark.parametrize('name', ['C2', 'C3', 'C5'])
+# F256 = the reference's own Fundus training shape: batch 16 = [3, 6, 7] at 256 x 256 (code/train.py:35,541): uneven DSBN groups
+# of 3 / 6 / 7 images through the default dispatch -- what a user's first real run executes
+@pytest.mark.parametrize('name', ['C2', 'C3', 'C5', 'F256'])
 def test_fullsize_fp32_step_matches_oracle(name):
     cfg, (src, trg, lam, mask), states, (img, frq), ref = _case(name)
     ts, bank, got = FU.hip_step(cfg, states, src, trg, lam, mask, torch.float32)
@@ -84,10 +87,10 @@ def test_fullsize_fp32_step_matches_oracle(name):
     assert FU.rel_l2(_flat(got['grads'], keys), _flat(ref['grads'], keys)) < 6e-3
 
 
-@pytest.mark.parametrize('name', ['C2', 'C3', 'C5'])
+@pytest.mark.parametrize('name', ['C2', 'C3', 'C5', 'F256'])
 def test_fullsize_bf16_step_against_the_rounding_model_oracle(name):
     """bf16 -- the dtype of the bench line -- at every BASELINE.json shape: C2, C3 (softmax / CE / dice_loss_multi, five
-    single-pair DSBN groups at 384x384) and C5 (512x512, four domains)."""
+    single-pair DSBN groups at 384x384) and C5 (512x512, four domains), and at the reference's native training shape F256."""
     cfg, (src, trg, lam, mask), states, (img, frq), ref32 = _case(name)
     _, _, _, _, refb = _case(name, rounded=True)
     ts, bank, got = FU.hip_step(cfg, states, src, trg, lam, mask, torch.bfloat16)
@@ -100,23 +103,26 @@ def test_fullsize_bf16_step_against_the_rounding_model_oracle(name):
     rows = FU.grad_table(got['grads'], refb['grads'])
     rows_dtype = FU.grad_table(refb['grads'], ref32['grads'])
     med, med_dtype = float(np.median([r[0] for r in rows])), float(np.median([r[0] for r in rows_dtype]))
-    assert med < 0.8 * med_dtype and med < 0.35, (med, med_dtype)    # the kernels add less than the dtype itself does
     keys = [(r[2], r[3]) for r in rows]
     a, b, c = _flat(got['grads'], keys), _flat(refb['grads'], keys), _flat(ref32['grads'], keys)
     cos = lambda u, v: float((u @ v) / (u.norm() * v.norm()))
-    assert cos(a, b) >= 0.85 and cos(a, c) >= 0.80, (cos(a, b), cos(a, c), cos(b, c))
+    # The yardstick for "how close can two correct implementations of these rounding points be": the rounding-model oracle
+    # against ITSELF on inputs one fp32 ulp away.  A one-ulp difference in an fp32 sum flips the bf16 rounding of a fraction
+    # of the stored values by a whole bf16 ulp, and every layer re-quantises: a perturbation eps grows like 0.04 sqrt(eps)
+    # per layer until it saturates near 1e-2 (scripts/bf16_gap.py, profiles/r03_bf16_gap_C2.txt: layer by layer, no jump at
+    # any layer kind -- the HIP path misses no rounding point of the model).  The kernels must sit at that self-distance, at
+    # EVERY configuration (a broken rounding point would pass the absolute gates below at C3 / C5 / F256 otherwise).
+    _, _, _, _, refp = _case(name, rounded=True, perturbed=True)
+    med_self = float(np.median([r[0] for r in FU.grad_table(refp['grads'], refb['grads'])]))
+    bp = _flat(refp['grads'], keys)
+    print('bf16 %s: median grad rel-L2 %.3f (dtype %.3f, self %.3f), cos(hip, model) %.4f cos(hip, fp32) %.4f cos(model, fp32) %.4f '
+          'cos(self, model) %.4f' % (name, med, med_dtype, med_self, cos(a, b), cos(a, c), cos(b, c), cos(bp, b)))
+    # gates at what is measured (round 4, MI355X): median 0.19-0.23, cos(hip, model) 0.96-0.98 -- round 3 asserted 0.35 / 0.85
+    assert med < 0.8 * med_dtype and med < 0.30, (med, med_dtype)    # the kernels add less than the dtype itself does
+    assert cos(a, b) >= 0.93 and cos(a, c) >= 0.88, (cos(a, b), cos(a, c), cos(b, c))
     assert abs(float(a.norm() / b.norm()) - 1.0) < 0.1
-    if name == 'C2':
-        # The yardstick for "how close can two correct implementations of these rounding points be": the rounding-model oracle
-        # against ITSELF on inputs one fp32 ulp away.  A one-ulp difference in an fp32 sum flips the bf16 rounding of a fraction
-        # of the stored values by a whole bf16 ulp, and every layer re-quantises: a perturbation eps grows like 0.04 sqrt(eps)
-        # per layer until it saturates near 1e-2 (scripts/bf16_gap.py, profiles/r03_bf16_gap_C2.txt: layer by layer, no jump at
-        # any layer kind -- the HIP path misses no rounding point of the model).  The kernels must sit at that self-distance.
-        _, _, _, _, refp = _case(name, rounded=True, perturbed=True)
-        med_self = float(np.median([r[0] for r in FU.grad_table(refp['grads'], refb['grads'])]))
-        bp = _flat(refp['grads'], keys)
-        assert med <= 1.6 * med_self + 0.02, (med, med_self)
-        assert cos(a, b) >= cos(bp, b) - 0.05, (cos(a, b), cos(bp, b))
+    assert med <= 1.6 * med_self + 0.02, (med, med_self)
+    assert cos(a, b) >= cos(bp, b) - 0.05, (cos(a, b), cos(bp, b))
 
 
 def test_bf16_and_fp32_loss_trajectories_track_the_oracle():

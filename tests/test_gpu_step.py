@@ -270,6 +270,55 @@ def test_step_is_bitwise_reproducible(dtype, dataset, bs, S):
     assert float(runs[0][0].abs().max()) > 0 and torch.isfinite(runs[0][0]).all()
 
 
+@pytest.mark.parametrize('fork', [1, 0])
+def test_native_launch_list_equals_the_python_launch_loop(fork):
+    """TrainStep.run_eager goes through rd_run_list (one C++ walk of the launch list per step: include/ramdsir.h); the instrumented
+    path (Plan.run_lanes, one ctypes call per entry) must enqueue the SAME work in the same stream order: identical bits after two
+    steps, on three streams and on one."""
+    torch.manual_seed(0)
+    bs, S = [2, 3, 3], 128
+    B = sum(bs)
+    bank, mods = S_.make_bank(DEV, 3, 16, 2, len(bs))
+    g = torch.Generator().manual_seed(1)
+    for (m, k), (off, shape) in bank.index.items():
+        v = bank.p(m, k)
+        if len(shape) == 4:
+            v.copy_((torch.randn(shape, generator=g) * (2.0 / (shape[0] * shape[2] * shape[3])) ** 0.5).to(DEV))
+        elif '.bn' in k and k.endswith('weight'):
+            v.fill_(1.0)
+    ts = S_.TrainStep(bank, mods, torch.bfloat16, bs, S, S, dataset='fundus', consistency='kd', lr=1e-3, total_iters=100, ram='u8',
+                      options=dict(fork=fork))
+    ts.wpack.refresh()
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    src = (torch.rand(B, S, S, 3, device=DEV, generator=gen) * 255).to(torch.uint8)
+    trg = (torch.rand(B, S, S, 3, device=DEV, generator=gen) * 255).to(torch.uint8)
+    tgt = (torch.rand(B, 2, S, S, device=DEV, generator=gen) > 0.5).float()
+    lam = torch.tensor([0.1 * (1 + i % 9) for i in range(B)], device=DEV)
+    ts.load_raw(src, trg, lam)
+    ts.load_target(tgt)
+    torch.cuda.synchronize()
+    saved = ts._snapshot()
+
+    def python_step():
+        ts.zero()
+        ts.run_segment(ts.seg_a + ts.seg_b)
+        ts.run_segment(ts.seg_c)
+
+    outs = []
+    for stepper in (ts.run_eager, python_step, ts.run_eager):
+        ts._restore(saved)
+        stepper()
+        stepper()
+        torch.cuda.synchronize()
+        outs.append((bank.grads.clone(), bank.params.clone(), ts.losses.clone(), ts.rec_mse.clone()))
+    assert int(ts.iter) == 2
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a, b)
+    assert float(outs[0][0].abs().max()) > 0 and torch.isfinite(outs[0][0]).all()
+    assert len(ts._native) == 1                                   # compiled once, reused
+
+
 @pytest.mark.parametrize('dataset,bs,S', [('fundus', [2, 3, 3], 400), ('prostate', [2, 2, 2, 2, 2], 384), ('fundus', [2, 2, 2, 2], 512)])
 def test_step_at_baseline_config_shapes(dataset, bs, S):
     """BASELINE.json configs 1/3/5 at full size (bf16, hipGraph, RAM on the GPU): size-independent properties --
