@@ -378,10 +378,10 @@ def main():
     if args.graph or args.no_pipeline:
         step = base_step
     else:
-        # the pipelined step of train.py (TrainStep.load_raw_next): every step mixes the NEXT batch (RAM) in its tail, beside Adam and
-        # the weight repack, and starts on an input that is already mixed.  The synthetic batch is resident in both input slots
+        # the pipelined step of train.py (TrainStep.load_raw_next): every step mixes the NEXT batch (RAM) on the restoration lane while
+        # its encoder backward runs, and starts on an input that is already mixed.  The synthetic batch is resident in both input slots
         # (inputs in HBM before the timed region, as the contract says); each timed step still runs exactly one RAM mix and one
-        # complete training step -- the first one's mix ran in the last warm-up step's tail, the last one's tail mixes for a step
+        # complete training step -- the first one's mix ran during the last warm-up step, the last one mixes for a step
         # that is not timed.
         for dst, val in zip(ts.raw_slots[1], (src, trg, lam)):
             dst.copy_(val)
@@ -412,6 +412,12 @@ def main():
     # data parallel: each gradient bucket's all-reduce on its own (nothing else on the GPU), so that a multi-GPU run says
     # what the exchange costs next to what the step hides of it
     exchange = bucket_allreduce_us(runner, world) if runner is not None else None
+    # every rank's lane / queue layout (streams measured to run beside each other, compute-unit budgets), gathered on rank 0
+    layouts = [ts.lane_layout()]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, layouts[0])
+        layouts = gathered
 
     if rank == 0:
         out = {
@@ -422,6 +428,7 @@ def main():
                        'global_batch': world * B, 'parallelism': 'dp%d' % world,
                        'process_group': ('%s world %d' % (dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else 'none (single process)', 'hipgraph': bool(args.graph), 'streams': 1 if (args.graph or not ts.fork) else 1 + len(ts.lanes()),
                        'lanes_verified': bool(ts.lanes_verified), 'gradient_exchange': exchange,
+                       'lane_layout': layouts, 'ddp_comm': runner.comm_choice if runner is not None else None,
                        'ram_pipelined': not (args.graph or args.no_pipeline), 'launch': 'rd_run_list (one native call per step)' if not args.graph else 'hipGraph replay',
                        'final_loss': round(losses['loss'], 4)},
         }

@@ -409,6 +409,12 @@ typedef struct {
 } rd_launch_t;
 int rd_run_list(const rd_launch_t* ops, int n, void* const* streams, int n_streams, uint32_t* open_lanes, int* bad_index);
 int rd_join_lanes(void* const* streams, int n_streams, uint32_t mask);
+/* enable != 0: rd_run_list enqueues the entries of every lane k > 0 from a worker thread of the library (one per lane, started on first
+ * use), in parallel with the calling thread's lane 0: a launch costs the host ~2.4 us inside the HIP runtime whoever issues it, so ONE
+ * thread needs ~0.85 ms for the step's ~305 kernels and three need ~0.4.  Same per-stream order, same events between the streams: the
+ * GPU executes the same graph.  Not used while the main stream is being captured.  Returns the previous setting.  Process-wide;
+ * rd_run_list itself must still be called from one thread at a time. */
+int rd_run_list_threads(int enable);
 
 #ifdef __cplusplus
 }

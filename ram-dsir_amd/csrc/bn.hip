@@ -432,9 +432,11 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* z, const float* 
 // backward: the gradient gp w.r.t. the pooled tensor goes to the FIRST maximum of each window (ATen max_pool2d), times the
 // activation's derivative there; the other three positions get 0 (or keep what a skip connection wrote: accumulate); the
 // BatchNorm-backward sums (sum g, sum g*z) of the scattered part are added to the producer's statistics slots.
-template <typename T>
+// ACC (the old gradient is read and added to) is a template parameter: as a run-time flag, the four conditional loads made every wait
+// of the loop a vmcnt(0) -- the z loads were waited for one by one
+template <typename T, bool ACC>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* gp, const T* z, const float* scale, const float* shift, float slope,
-                                                       int act, T* gout, int accumulate, double* bstats, int Ho, int Wo, int C,
+                                                       int act, T* gout, double* bstats, int Ho, int Wo, int C,
                                                        GroupMap gm) {
     constexpr int S = Slot<T>::N;
     extern __shared__ double s_redd[];                     // [C][2], then [2][C] floats of coefficients
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* gp, const T* z, 
         for (int k = 0; k < 4; ++k) {
             const size_t o = ((size_t)(2 * y + (k >> 1)) * W + 2 * x + (k & 1)) * C;
             ldv<T>(zb + o, zz[k]);
-            if (accumulate) ldv<T>(gb + o, gw[k]);
+            if constexpr (ACC) ldv<T>(gb + o, gw[k]);
         }
 #pragma unroll
         for (int e = 0; e < S; ++e) {
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* gp, const T* z, 
                     b1[e] += gn;
                     b2[e] += gn * zz[k][e];
                 }
-                gw[k][e] = accumulate ? gw[k][e] + gn : gn;
+                gw[k][e] = ACC ? gw[k][e] + gn : gn;
             }
         }
 #pragma unroll
@@ -814,12 +816,21 @@ int rd_pool_bwd(const void* gp, const void* z, const float* scale, const float* 
     const GroupMap gm = host_gm(G, gstart_host);
     dim3 grid(grid_for((size_t)Ho * Wo * (C / S), 256 * 4, 2048), N);
     const size_t lds = 2 * C * sizeof(double) + 2 * C * sizeof(float);
-    if (dtype == RD_BF16)
-        hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale, shift,
-                           slope, act, (bf16_t*)g, accumulate, bstats, Ho, Wo, C, gm);
-    else
-        hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
-                           slope, act, (float*)g, accumulate, bstats, Ho, Wo, C, gm);
+    if (dtype == RD_BF16) {
+        if (accumulate)
+            hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, true>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale,
+                               shift, slope, act, (bf16_t*)g, bstats, Ho, Wo, C, gm);
+        else
+            hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, false>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale,
+                               shift, slope, act, (bf16_t*)g, bstats, Ho, Wo, C, gm);
+    } else {
+        if (accumulate)
+            hipLaunchKernelGGL((pool_bwd_kernel<float, true>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
+                               slope, act, (float*)g, bstats, Ho, Wo, C, gm);
+        else
+            hipLaunchKernelGGL((pool_bwd_kernel<float, false>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
+                               slope, act, (float*)g, bstats, Ho, Wo, C, gm);
+    }
     return (int)hipGetLastError();
 }
 

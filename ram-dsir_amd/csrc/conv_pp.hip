@@ -685,7 +685,12 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         const int cd = M.n0 + nb * 32 + 16 * v - (di ? p.c_split : 0) + 8 * h;
         return ((size_t)((M.n + d.n_off) * H + y) * W + x) * d.Cd + cd;
     };
+    // The eight requests are UNCONDITIONAL (a vector without a producer tensor reads a dummy line): written as `if (d.z) zq = load`, every
+    // load sat in its own conditional block and the compiler put `s_waitcnt vmcnt(0)` in front of each one -- eight dependent HBM round
+    // trips in front of the last K step's MFMAs (scripts/ws_trace.py on dec.convu2.conv3's gradient: 9 000-10 700 cycles for that step
+    // against 3 300 for the others)
     auto dgrad_prefetch = [&]() {
+        const T* dummy = reinterpret_cast<const T*>(p.w);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int y = min(M.y0 + px_r[mb], H - 1), x = min(M.x0 + px_c[mb], W - 1);
@@ -695,9 +700,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                 for (int v = 0; v < 2; ++v) {
                     const int di = (M.n0 + nb * 32 + 16 * v) >= p.c_split ? 1 : 0;
                     const rd_dst_t d = select_dst(p, di);
-                    if (d.kind == RD_DST_NONE) continue;
-                    const size_t idx = dst_index(d, di, nb, v, y, x);
-                    if (d.z) zq[mb][nb][v] = ld16(reinterpret_cast<const T*>(d.z) + idx);
+                    const bool has = d.kind != RD_DST_NONE && d.z != nullptr;
+                    const size_t idx = has ? dst_index(d, di, nb, v, y, x) : 0;
+                    zq[mb][nb][v] = ld16(has ? reinterpret_cast<const T*>(d.z) + idx : dummy);
                 }
         }
     };
@@ -810,17 +815,20 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                             float da[S];
                             regroup(acc[mb][nb], v, da);
                             if (!pin[mb]) continue;
+                            // no load in this loop (destinations that accumulate go to conv_pf_kernel: rd_conv_pp_dispatch): with the old
+                            // gradient read here (`d.accumulate ? ld16(gp) : 0`), every vector waited vmcnt(0) -- i.e. for the previous
+                            // vector's STORE to be acknowledged -- before its own arithmetic: eight serialized round trips per tile
+                            // (6 500-11 000 cycles of epilogue against the forward mode's 2 000-3 000)
                             T* gp = reinterpret_cast<T*>(d.g) + dst_index(d, di, nb, v, py[mb], pxx[mb]);
                             float z[S], gw[S];
                             Slot<T>::unpack(zq[mb][nb][v], z);
-                            Slot<T>::unpack(d.accumulate ? ld16(gp) : make_uint4(0, 0, 0, 0), gw);
 #pragma unroll
                             for (int e = 0; e < S; ++e) {
                                 const float m = (z[e] * psc[e] + psh[e]) > 0.f ? 1.f : lo;
                                 const float gn = da[e] * m;
                                 sa[nb][v][e] += gn;
                                 sb[nb][v][e] += gn * (d.z ? z[e] : 0.f);
-                                gw[e] += gn;
+                                gw[e] = gn;
                             }
                             *reinterpret_cast<uint4*>(gp) = Slot<T>::pack(gw);
                         }
@@ -881,10 +889,19 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     //   Round 3, in the STEP (scripts/sweep_opts.sh, alternating): threshold 1536 5.06-5.07 ms, 800: 5.19, 400: 5.22, never: 5.01-5.02 --
     //   a gradient launch that takes whole CUs (512 threads, 154 KB LDS) keeps the weight-gradient lane's kernels off them for its
     //   whole duration; the two-workgroup conv_pf_kernel shares.  Default: never for gradients (the kernel mode stays, tests force it).
-    static const int ws = rd_switch("RD_CONV_WS", 3), ws_min2 = rd_switch("RD_CONV_WS_MIN2", 1 << 30);
+    //   Round 4: the gradient mode's MFMA waves had their eight producer-tensor loads and their eight stores each behind a vmcnt(0)
+    //   (scripts/ws_trace.py: last K step 9 000-10 700 cycles, epilogue 6 500-11 000); with both fixed a tile takes ~15 000 cycles
+    //   instead of ~24 000 and every >= 64-channel gradient launch is 15-20 % faster here than on conv_pf_kernel (dec.convu2.conv3
+    //   103 -> 87 us, dec.convu3.conv3 85 -> 70, dec.convu4.conv3 84 -> 69, enc.convd3.* 40 -> 33).  In the step it needs a compute-unit
+    //   budget (tuning.py dgrad_cus = 160: the persistent workgroups leave 96 CUs to the other lanes): 4.48 -> 4.43 ms
+    //   (scripts/sweep_ws2.sh, alternating; 4.48 with the whole GPU, 4.51 with 128).  Default: every non-accumulating gradient launch.
+    static const int ws = rd_switch("RD_CONV_WS", 3), ws_min2 = rd_switch("RD_CONV_WS_MIN2", 0);
     const int mode = rd_conv_lean_mode(p, PP_NT);
     const size_t tab = (size_t)(mode == 1 ? 1 : 2 * p.G) * p.CoutPad * sizeof(float);
-    if (mode && (ws & mode) && (mode == 1 || tiles >= ws_min2) && tab <= (size_t)WsLds<0>::TAB_BYTES) {
+    bool accumulates = false;                                  // gradient launches that add to an existing gradient stay with conv_pf_kernel
+    if (mode == 2)
+        for (int i = 0; i < 2; ++i) accumulates = accumulates || (p.dst[i].kind != RD_DST_NONE && p.dst[i].accumulate);
+    if (mode && (ws & mode) && (mode == 1 || (tiles >= ws_min2 && !accumulates)) && tab <= (size_t)WsLds<0>::TAB_BYTES) {
         // debug build only: RD_CONV_WS_EXP = timing experiments (-DRD_WS_EXP), RD_CONV_WS_TRACE_MIN = launches with at least
         // that many tiles record the s_memtime trace (scripts/ws_trace.py); both ride in the high bits of the tile count
         static const int ws_exp = rd_switch("RD_CONV_WS_EXP", 0), ws_trace_min = rd_switch("RD_CONV_WS_TRACE_MIN", 1 << 30);

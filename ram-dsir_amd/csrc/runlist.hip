@@ -2,6 +2,11 @@
 // with the lane forks / joins as HIP events.  Host code only.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include "common.h"
 #include "../../include/ramdsir.h"
 
@@ -99,6 +104,183 @@ int call(const rd_launch_t& o, void* st) {
 
 }  // namespace
 
+namespace {
+
+// ------------------------------------------------------------------------------------------------ lane worker threads
+// A launch costs the host ~2.4 us inside the HIP runtime whoever calls it, so one thread cannot enqueue the step's ~305 kernels in less
+// than ~0.85 ms.  With rd_run_list_threads(1) every lane k > 0 has a worker thread that enqueues that lane's entries while the calling
+// thread enqueues lane 0's and records the events of the cross-lane edges:
+//   fork / wait_main edge  the caller records an event at its position on the main stream, then hands the lane {wait for that event}:
+//                          the event is recorded before the worker can see the command, so the worker never waits on the host side;
+//   join                   the caller hands the lane {record an event}, waits (host side, bounded) until the worker has executed it and
+//                          makes the main stream wait for the event.
+// Stream order per lane is the list order, exactly as in the single-threaded walk: the GPU sees the same dependency graph.  Before
+// rd_run_list returns every worker has drained its queue (everything is enqueued; descriptors may be changed by the caller afterwards).
+struct Cmd {
+    int kind;            // 0 launch ops[idx]; 1 stream waits for ev; 2 record ev on the stream; 3 new call: device / ops / stream
+    int idx;
+    hipEvent_t ev;
+    const rd_launch_t* ops;
+    hipStream_t stream;
+};
+constexpr unsigned RING = 4096;
+struct Worker {
+    Cmd ring[RING];
+    std::atomic<unsigned> head{0}, tail{0};     // single producer (the caller), single consumer (the worker)
+    std::atomic<int> err{0};
+    std::atomic<int> asleep{0};
+    std::mutex m;
+    std::condition_variable cv;
+};
+Worker* g_workers[32] = {};
+std::atomic<int> g_threads_enabled{0};
+
+void worker_main(Worker* w) {
+    const rd_launch_t* ops = nullptr;
+    hipStream_t stream = nullptr;
+    for (;;) {
+        unsigned h = w->head.load(std::memory_order_relaxed);
+        int spins = 0;
+        while (w->tail.load(std::memory_order_acquire) == h) {
+            if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+            std::unique_lock<std::mutex> lk(w->m);                // nothing for ~100 us: sleep until the next call pushes
+            w->asleep.store(1, std::memory_order_seq_cst);
+            if (w->tail.load(std::memory_order_seq_cst) == h) w->cv.wait_for(lk, std::chrono::milliseconds(50));
+            w->asleep.store(0, std::memory_order_seq_cst);
+            spins = 0;
+        }
+        const Cmd c = w->ring[h % RING];
+        int rc = 0;
+        switch (c.kind) {
+        case 0: rc = call(ops[c.idx], (void*)stream); break;
+        case 1: rc = (int)hipStreamWaitEvent(stream, c.ev, 0); break;
+        case 2: rc = (int)hipEventRecord(c.ev, stream); break;
+        case 3: rc = (int)hipSetDevice(c.idx); ops = c.ops; stream = c.stream; break;
+        }
+        if (rc && !w->err.load()) w->err.store(rc);
+        w->head.store(h + 1, std::memory_order_release);
+    }
+}
+
+Worker* worker_for(int lane) {
+    if (!g_workers[lane]) {
+        Worker* w = new Worker();                                  // never freed: the thread outlives every static destructor
+        std::thread(worker_main, w).detach();
+        g_workers[lane] = w;
+    }
+    return g_workers[lane];
+}
+
+int push(Worker* w, const Cmd& c) {
+    const unsigned t = w->tail.load(std::memory_order_relaxed);
+    int spins = 0;
+    while (t - w->head.load(std::memory_order_acquire) >= RING) {   // ring full: the worker is behind
+        if (++spins > 200000000) return -2;
+        __builtin_ia32_pause();
+    }
+    w->ring[t % RING] = c;
+    w->tail.store(t + 1, std::memory_order_seq_cst);
+    if (w->asleep.load(std::memory_order_seq_cst)) {
+        std::lock_guard<std::mutex> lk(w->m);
+        w->cv.notify_one();
+    }
+    return 0;
+}
+
+// wait until the worker has executed everything pushed so far (bounded: a stuck runtime call must not hang the caller for ever)
+int drain(Worker* w) {
+    const unsigned t = w->tail.load(std::memory_order_relaxed);
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while ((int)(w->head.load(std::memory_order_acquire) - t) < 0) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return -2;
+    }
+    return w->err.exchange(0);
+}
+
+int run_list_threaded(const rd_launch_t* ops, int n, void* const* streams, int n_streams, uint32_t* open_lanes, int* bad_index) {
+    uint32_t open = open_lanes ? *open_lanes : 0u;
+    hipStream_t main_s = (hipStream_t)streams[0];
+    int dev = 0;
+    RD_CHECK(hipGetDevice(&dev));
+    Worker* ws[32] = {};
+    int rc = 0, i = 0;
+    auto lane_worker = [&](int lane) -> Worker* {
+        if (!ws[lane]) {
+            ws[lane] = worker_for(lane);
+            Cmd c{3, dev, nullptr, ops, (hipStream_t)streams[lane]};
+            if (push(ws[lane], c)) return nullptr;
+        }
+        return ws[lane];
+    };
+    auto edge_to_lane = [&](int lane) -> int {                     // streams[lane] waits for the main stream's current position
+        Worker* w = lane_worker(lane);
+        if (!w) return -2;
+        if ((hipStream_t)streams[lane] == main_s) return 0;
+        hipEvent_t e;
+        const int err = next_event(&e);
+        if (err) return err;
+        RD_CHECK(hipEventRecord(e, main_s));
+        return push(w, Cmd{1, 0, e, nullptr, nullptr});
+    };
+    for (; i < n && rc == 0; ++i) {
+        const rd_launch_t& o = ops[i];
+        if (o.lane < 0 || o.lane >= n_streams || o.nargs < 0 || o.nargs > RD_LAUNCH_MAX_ARGS) { rc = -1; break; }
+        if (o.op == RD_OP_FORK) {
+            if (o.lane > 0) { rc = edge_to_lane(o.lane); open |= 1u << o.lane; }
+            continue;
+        }
+        if (o.op == RD_OP_JOIN) {
+            if (o.lane > 0 && (open & (1u << o.lane))) {
+                open &= ~(1u << o.lane);
+                Worker* w = lane_worker(o.lane);
+                if (!w) { rc = -2; break; }
+                if ((hipStream_t)streams[o.lane] != main_s) {
+                    hipEvent_t e;
+                    rc = next_event(&e);
+                    if (rc) break;
+                    rc = push(w, Cmd{2, 0, e, nullptr, nullptr});
+                    if (rc) break;
+                    rc = drain(w);                                 // the record has been enqueued (and everything before it)
+                    if (rc) break;
+                    rc = (int)hipStreamWaitEvent(main_s, e, 0);
+                } else {
+                    rc = drain(w);
+                }
+            }
+            continue;
+        }
+        if (o.lane == 0) {
+            rc = call(o, (void*)main_s);
+            continue;
+        }
+        if (o.wait_main) {
+            rc = edge_to_lane(o.lane);
+            open |= 1u << o.lane;
+            if (rc) break;
+        }
+        Worker* w = lane_worker(o.lane);
+        if (!w) { rc = -2; break; }
+        rc = push(w, Cmd{0, i, nullptr, nullptr, nullptr});
+    }
+    if (rc && bad_index) *bad_index = i;
+    for (int k = 1; k < n_streams; ++k)
+        if (ws[k]) {
+            const int e = drain(ws[k]);
+            if (e && !rc) { rc = e; if (bad_index) *bad_index = -1; }
+        }
+    if (open_lanes) *open_lanes = open;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int rd_run_list_threads(int enable) {
+    const int old = g_threads_enabled.exchange(enable ? 1 : 0);
+    return old;
+}
+
 extern "C" int rd_join_lanes(void* const* streams, int n_streams, uint32_t mask) {
     for (int k = 1; k < n_streams && k < 32; ++k)
         if (mask & (1u << k)) {
@@ -110,8 +292,14 @@ extern "C" int rd_join_lanes(void* const* streams, int n_streams, uint32_t mask)
 
 extern "C" int rd_run_list(const rd_launch_t* ops, int n, void* const* streams, int n_streams, uint32_t* open_lanes, int* bad_index) {
     if (n_streams < 1 || n_streams > 32) return -1;
-    uint32_t open = open_lanes ? *open_lanes : 0u;
     hipStream_t main_s = (hipStream_t)streams[0];
+    if (n_streams > 1 && g_threads_enabled.load()) {
+        // worker threads only outside stream capture (a capture is recorded by the capturing thread)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(main_s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)
+            return run_list_threaded(ops, n, streams, n_streams, open_lanes, bad_index);
+    }
+    uint32_t open = open_lanes ? *open_lanes : 0u;
     int rc = 0, i = 0;
     for (; i < n && rc == 0; ++i) {
         const rd_launch_t& o = ops[i];

@@ -133,6 +133,7 @@ _SIGS = {
     'rd_zero': (C.c_int, [C.POINTER(vp), C.POINTER(i64), C.c_int, vp]),
     'rd_run_list': (C.c_int, [C.POINTER(RdLaunch), C.c_int, C.POINTER(vp), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     'rd_join_lanes': (C.c_int, [C.POINTER(vp), C.c_int, C.c_uint32]),
+    'rd_run_list_threads': (C.c_int, [C.c_int]),
 }
 
 _lib = None

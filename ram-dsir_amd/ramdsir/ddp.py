@@ -59,8 +59,55 @@ class DataParallelStep:
         # The collectives are LAUNCHED from the weight-gradient lane (RCCL runs them on its own stream and only makes that
         # stream wait for the launching one): a separate communication stream would be the fifth stream of the step, and
         # HIP gives a process four hardware queues -- a fifth one aliases a lane (streams.py; 5.9 -> 9-11 ms/step measured)
-        self.comm = torch.cuda.Stream(device=b.device) if ts.opt['ddp_own_comm_stream'] else ts.side[0]
+        choice = int(ts.opt['ddp_own_comm_stream'])
+        self._own = None
+        self.comm_choice = {'own_comm_stream': bool(choice > 0), 'how': 'option'}
+        self.comm = self._comm_stream(choice > 0)
         self.graphs = None
+        if choice < 0:
+            self.pick_comm()
+
+    def _comm_stream(self, own):
+        if own:
+            if self._own is None:
+                self._own = torch.cuda.Stream(device=self.ts.bank.device)
+            return self._own
+        return self.ts.side[0]
+
+    def pick_comm(self, steps=4):
+        """Launch the bucket exchanges from the weight-gradient lane or from a stream of their own?  Decided the way streams.pick_lanes
+        decides the lanes: by measurement, here on the real process group -- `steps` eager steps each way (after one warm-up each) on
+        whatever the input buffers hold, state restored afterwards; every rank takes the choice that is faster for the SLOWEST rank
+        (one small all-reduce).  With one rank there is nothing to exchange with: the lane."""
+        import time
+        ts = self.ts
+        if self.buckets.world <= 1 or not dist.is_initialized():
+            self.comm_choice = {'own_comm_stream': False, 'how': 'single rank: the weight-gradient lane'}
+            self.comm = self._comm_stream(False)
+            return
+        saved, state = ts._snapshot(), (ts._slot, ts._x_ready, ts._next_loaded)
+        times = []
+        for own in (False, True):
+            self.comm = self._comm_stream(own)
+            ts._restore(saved)
+            self.step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / steps * 1e3)
+        t = torch.tensor(times, dtype=torch.float64, device=ts.bank.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times = [float(v) for v in t]
+        own = times[1] < times[0]
+        self.comm = self._comm_stream(own)
+        self.comm_choice = {'own_comm_stream': bool(own), 'how': 'measured', 'ms_per_step_lane': round(times[0], 3), 'ms_per_step_own': round(times[1], 3)}
+        ts._restore(saved)
+        ts._slot, ts._x_ready, ts._next_loaded = state
+        ts.src, ts.trg, ts.lam = ts.raw_slots[ts._slot] if ts.ram is not None else (None, None, None)
+        torch.cuda.synchronize()
 
     def _segments(self):
         ts = self.ts
@@ -94,7 +141,8 @@ class DataParallelStep:
         """Segment i of the eager step by name (TrainStep.launch): A = reset + [RAM] + forward + decoder backwards, B1 / B2 = encoder
         backward, C = Adam + repack -- with the next batch's RAM beside it when load_raw_next() has provided one (step.py)."""
         ts = self.ts
-        return (ts.head_names(), ('seg_b1',), ('seg_b2',), (ts.tail_name(),))[i]
+        b1, b2 = ts.backward_names(split=True)
+        return (ts.head_names(), (b1,), (b2,), ('seg_c',))[i]
 
     def _run(self, i, main):
         if self.graphs is not None:

@@ -294,6 +294,7 @@ class Plan:
         self.materialize_pool = T.options()['pool_mat']
         self.side_cus = 0               # >0: compute-unit budget of the weight-gradient launches (they run on a side stream)
         self.conv_cus = 0               # >0: compute-unit budget of this plan's persistent conv launches (a side-lane plan)
+        self.dgrad_cus = 0              # >0: ... of its >= 64-channel gradient launches only (tuning.py dgrad_cus)
         self.materialize_min_c = None   # channels from which BN+ReLU outputs are stored once (rd_bn_apply)
         self.materialize_dz_min_c = None  # ... and from which the BN-backward gradients dz are
         self.fused_bwd = bool(T.options()['fused_bwd'])   # small-channel 3x3 convs: dgrad + weight gradient in one launch
@@ -578,6 +579,8 @@ class Plan:
             if not all(d.kind == L.DST_NONE for d in dsts):
                 p = L.RdConv()
                 p.cu_limit = int(self.conv_cus)
+                if not p.cu_limit and self.dgrad_cus and (node.Cin > 32 or node.Cout > 32):
+                    p.cu_limit = int(self.dgrad_cus)
                 p.src[0] = self._dz_src(node)
                 p.nsrc, p.taps = 1, node.taps
                 p.w = wpack.ptr(node.mname, node.name, True)

@@ -43,6 +43,7 @@ class TrainStep:
         # itself becomes the critical path when it is narrowed: 315 -> 268 images/s)
         budget = bool(opt['fork']) and dtype == torch.bfloat16
         self.seg.side_cus = T.cu_budget(opt['side_cus'], dev) if budget else 0
+        self.seg.dgrad_cus = int(opt['dgrad_cus']) if budget else 0
         self.seg.materialize_min_c = opt['mat_min_c'] if opt['mat_min_c'] > 0 else None
         self.seg.materialize_dz_min_c = opt['mat_dz_min_c'] if opt['mat_dz_min_c'] > 0 else None
         slot = self.seg.slot_channels()
@@ -106,18 +107,21 @@ class TrainStep:
         # ---- RAM (optional: raw images + partner images + lambda in, both network inputs out)
         # ram = True: fp32 source / partner buffers; ram = 'u8': uint8 buffers (decoded PNG pixels of the Fundus pipeline:
         # 1 byte per value over PCIe and out of HBM; the values are the same integers the reference holds as float32)
-        # TWO input slots (src / trg / lam) with one RAM descriptor each, both writing the network input x: while step N runs on slot
-        # k, the host uploads batch N+1 into slot 1-k (load_raw_next), and step N's tail mixes it (step(): the pipelined form below)
+        # TWO input slots: raw inputs (src / trg / lam), a RAM descriptor and a copy of the network input x each.  While step N trains
+        # on slot k, the host uploads batch N+1 into slot 1-k (load_raw_next) and step N mixes it into x[1-k] on the restoration lane
+        # while the encoder backward runs on the main lane (step(): the pipelined form below) -- the three latency-bound RAM launches
+        # no longer open the next step alone.
         self.ram = None
         self._slot, self._x_ready, self._next_loaded = 0, False, False
+        self.xbufs = [self.x.buf, torch.zeros_like(self.x.buf) if ram else self.x.buf]
         if ram:
             idt = torch.uint8 if ram == 'u8' else torch.float32
             self.raw_slots = [(torch.zeros(B, H, W, in_channels, dtype=idt, device=dev), torch.zeros(B, H, W, in_channels, dtype=idt, device=dev),
                                torch.ones(B, dtype=torch.float32, device=dev)) for _ in range(2)]
             self.rams = [R.RamMixer(B, H, W, dtype, dev, dataset) for _ in range(2)]
-            self.rams[1].share_workspace(self.rams[0])               # never in flight together: x is written by one RAM at a time
+            self.rams[1].share_workspace(self.rams[0])               # never in flight together: a step mixes at most one batch
             for k in range(2):
-                self.rams[k].bind(*self.raw_slots[k], self.x.buf[:B], self.x.buf[B:])
+                self.rams[k].bind(*self.raw_slots[k], self.xbufs[k][:B], self.xbufs[k][B:])
             self.ram = self.rams[0]
             self.src, self.trg, self.lam = self.raw_slots[0]         # the current slot's buffers (load_raw's destination)
         self.graph = None
@@ -139,6 +143,8 @@ class TrainStep:
         self.lanes_verified = bool(opt['fork']) and all(streams.verified.get(id(st), False) for st in picked)
         self.fork = bool(opt['fork'])
         self.rec_lane = bool(opt['rec_lane'])
+        self.launch_threads = bool(opt['launch_threads']) and self.fork
+        self._slot1_keep = []
         self._ops = self._build_ops()
 
     def _build_ops(self):
@@ -173,20 +179,68 @@ class TrainStep:
         self.seg_b1, self.seg_b2 = b[:cut], b[cut:]
         self.enc_deep_offset = min(off for (m, k), (off, _) in self.bank.index.items() if m == 'enc' and k.startswith('convd3.'))
         c = [(lib.rd_adam_step, (C.byref(self.ad),)), self.wpack.refresh_op()]
-        # RAM of slot k as a head segment (the classical step: mix, then train on it) and as part of the tail (the pipelined step:
-        # the NEXT batch is mixed on the restoration lane -- idle by then -- beside Adam + weight repack, after every reader of x
-        # (first conv forward, its weight gradient, the restoration loss) has been joined)
-        self.seg_a_noram = a
-        self.seg_ram0 = [self.rams[0].op()] if self.ram is not None else []
-        self.seg_ram1 = [self.rams[1].op()] if self.ram is not None else []
+        # Segment lists per input slot k.  Three launches read the network input: the first conv's forward, its weight gradient, and the
+        # restoration loss (target = the un-mixed images); slot 1's lists carry copies of those descriptors that point at x[1].
+        #   seg_ram_s<k>      RAM of slot k -> x[k] as a head segment (the classical order: mix, then train on it)
+        #   seg_a_noram_s<k>  forward, losses, decoder backwards on x[k]
+        #   seg_b_s<k>        encoder backward (seg_b1_s<k> + seg_b2_s<k>: the data-parallel split)
+        #   seg_b_pf_s<k> / seg_b1_pf_s<k>   the same with the NEXT batch's RAM (slot 1-k -> x[1-k]) forked onto the restoration lane in
+        #                   front of it: that lane has finished its branch by then and is idle for the whole encoder backward; the
+        #                   final join in front of Adam covers it
         for k in range(2):
-            tail = []
-            if self.ram is not None:
-                tail = [E.sync_op('fork', 'rec')] + E.tag_lane([self.rams[k].op()], 'rec')
-            setattr(self, 'seg_c_pf%d' % k, tail + c + ([E.sync_op('join', 'rec')] if tail else []))
-        # the classical segments (RAM of slot 0 at the head of A): hipGraph capture, the data-parallel step's fallback, the scripts
-        self.seg_a, self.seg_b, self.seg_c = self.seg_ram0 + a, b, c
+            ak, bk = (a, b) if k == 0 else ([self._on_slot1(op) for op in a], [self._on_slot1(op) for op in b])
+            setattr(self, 'seg_a_noram_s%d' % k, ak)
+            setattr(self, 'seg_b_s%d' % k, bk)
+            setattr(self, 'seg_b1_s%d' % k, bk[:cut])
+            setattr(self, 'seg_b2_s%d' % k, bk[cut:])
+            setattr(self, 'seg_ram_s%d' % k, [self.rams[k].op()] if self.ram is not None else [])
+        for k in range(2):
+            pf = ([E.sync_op('fork', 'rec')] + E.tag_lane([self.rams[1 - k].op()], 'rec')) if self.ram is not None else []
+            setattr(self, 'seg_b_pf_s%d' % k, pf + getattr(self, 'seg_b_s%d' % k))
+            setattr(self, 'seg_b1_pf_s%d' % k, pf + getattr(self, 'seg_b1_s%d' % k))
+        # the classical segments on slot 0 (RAM at the head of A): hipGraph capture, the scripts, bench.py's instrumented passes
+        self.seg_a_noram = a
+        self.seg_a, self.seg_b, self.seg_c = self.seg_ram_s0 + a, b, c
         return self.seg_a + b + c
+
+    def _on_slot1(self, op):
+        """The launch `op` with every reference to the network input x[0] replaced by x[1] (a copy of its descriptor); other launches
+        are returned as they are."""
+        x0, x1 = self.xbufs[0].data_ptr(), self.xbufs[1].data_ptr()
+        if op[0] is None or x0 == x1:
+            return op
+        args, hit = [], False
+        for v in op[1]:
+            if hasattr(v, '_obj') and isinstance(v._obj, (L.RdConv, L.RdWgrad)):
+                d = type(v._obj)()
+                C.memmove(C.byref(d), C.byref(v._obj), C.sizeof(d))
+                srcs = list(d.src) if isinstance(d, L.RdConv) else list(d.a)
+                found = False
+                for sdesc in srcs:
+                    if sdesc.ptr == x0:
+                        sdesc.ptr = x1
+                        found = True
+                if found:
+                    self._slot1_keep.append(d)
+                    args.append(C.byref(d))
+                    hit = True
+                    continue
+            elif isinstance(v, int) and v == x0:
+                args.append(x1)
+                hit = True
+                continue
+            args.append(v)
+        return (op[0], tuple(args)) + tuple(op[2:]) if hit else op
+
+    def lane_layout(self):
+        """Which stream carries which lane and whether it was measured to run beside the others (streams.pick_lanes): diagnostic
+        for the bench line -- on a new stack (the first 8-GPU run) a lane that shares a hardware queue shows up here, not as an
+        unexplained slow step."""
+        out = {'main': {'stream': int(torch.cuda.current_stream(self.bank.device).cuda_stream)}}
+        for name, st in self.lanes().items():
+            out[name] = {'stream': int(st.cuda_stream), 'verified_concurrent': bool(streams.verified.get(id(st), False))}
+        out['budgets'] = {'side_cus': int(self.seg.side_cus), 'rec_cus': int(self.rec.conv_cus), 'dgrad_cus': int(self.seg.dgrad_cus)}
+        return out
 
     def lanes(self):
         if not self.fork:
@@ -201,8 +255,9 @@ class TrainStep:
         """fp32 NCHW device tensors in [-1,1] (what the reference's DataLoader yields, train.py:244)."""
         lib, B = L.lib(), self.B
         s = self._stream() if stream is None else stream
-        half = self.x.buf[B:]
-        L.check(lib.rd_nchw_to_nhwc(img_nchw.data_ptr(), self.x.buf.data_ptr(), B, self.c, self.H, self.W, self.x.Cs, self.dt, s), 'load img')
+        xb = self.x_current()
+        half = xb[B:]
+        L.check(lib.rd_nchw_to_nhwc(img_nchw.data_ptr(), xb.data_ptr(), B, self.c, self.H, self.W, self.x.Cs, self.dt, s), 'load img')
         L.check(lib.rd_nchw_to_nhwc(img_freq_nchw.data_ptr(), half.data_ptr(), B, self.c, self.H, self.W, self.x.Cs, self.dt, s), 'load img_freq')
 
     def load_raw(self, src_nhwc, trg_nhwc, lam):
@@ -214,8 +269,8 @@ class TrainStep:
         self._x_ready, self._next_loaded = False, False
 
     def load_raw_next(self, src_nhwc, trg_nhwc, lam):
-        """The RAM inputs of the NEXT step, into the other input slot: the following step() then mixes them in its tail (beside Adam
-        and the weight repack) instead of opening the step after it with three latency-bound RAM launches.  Call order per
+        """The RAM inputs of the NEXT step, into the other input slot: the following step() then mixes them on the restoration lane while
+        its encoder backward runs, instead of opening the step after it with three latency-bound RAM launches.  Call order per
         iteration: load_raw_next(batch N+1); step(); load_target(mask N+1) -- the target buffer is single: it is read by step N's
         loss, so the next mask is uploaded after step N has been enqueued (stream order does the rest)."""
         self._copy_raw(1 - self._slot, src_nhwc, trg_nhwc, lam)
@@ -289,6 +344,7 @@ class TrainStep:
         main = torch.cuda.current_stream() if main is None else main
         lanes = self.lanes() if lanes is None else lanes
         ll = self.native_list(names, lanes, join_before_last)
+        L.lib().rd_run_list_threads(1 if self.launch_threads else 0)      # process-wide switch: set per call, this step's choice
         mask = ll.run(main, lanes, open_mask)
         if join and mask:
             ll.join(main, lanes, mask)
@@ -301,14 +357,24 @@ class TrainStep:
         self.launch(('zero', 'seg_a', 'seg_b', 'seg_c'), lanes=lanes, join_before_last=True)
 
     def head_names(self):
-        """Segment names of the step's head: the reset, RAM of the current slot unless the previous step's tail has mixed it already."""
-        return ('zero',) + (() if (self._x_ready or self.ram is None) else ('seg_ram%d' % self._slot,)) + ('seg_a_noram',)
+        """Segment names of the step's first part: the reset, RAM of the current slot unless the previous step has mixed it already,
+        forward + losses + decoder backwards on the current slot's x."""
+        k = self._slot
+        return ('zero',) + (() if (self._x_ready or self.ram is None) else ('seg_ram_s%d' % k,)) + ('seg_a_noram_s%d' % k,)
 
-    def tail_name(self):
-        return 'seg_c_pf%d' % (1 - self._slot) if (self._next_loaded and self.ram is not None) else 'seg_c'
+    def backward_names(self, split=False):
+        """Encoder backward on the current slot -- with the next batch's RAM beside it when load_raw_next() has provided one;
+        split: the data-parallel step's two parts."""
+        k = self._slot
+        pf = '_pf' if (self._next_loaded and self.ram is not None) else ''
+        return ('seg_b1%s_s%d' % (pf, k), 'seg_b2_s%d' % k) if split else ('seg_b%s_s%d' % (pf, k),)
+
+    def x_current(self):
+        """The network input [img ; img_freq] of the current slot (NHWC, channel vector padded to one 16-byte slot)."""
+        return self.xbufs[self._slot]
 
     def advance(self):
-        """Bookkeeping after a step has been enqueued: a pipelined tail has left the next batch's x ready and flips the slots."""
+        """Bookkeeping after a step has been enqueued: a pipelined step has left the next batch's x ready and flips the slots."""
         if self._next_loaded and self.ram is not None:
             self._slot, self._x_ready = 1 - self._slot, True
             self.src, self.trg, self.lam = self.raw_slots[self._slot]
@@ -358,14 +424,14 @@ class TrainStep:
         self.wpack.refresh(self._stream())
 
     def step(self):
-        """One training step on the current input slot.  If load_raw_next() has been called, the tail also mixes the next batch
-        (pipelined form); a captured graph always replays the classical list on slot 0."""
+        """One training step on the current input slot.  If load_raw_next() has been called, the step also mixes the next batch
+        (RAM on the restoration lane, beside the encoder backward); a captured graph always replays the classical list on slot 0."""
         if self.graph is not None:
             if self._slot != 0 or self._x_ready or self._next_loaded:
                 raise RuntimeError('a captured hipGraph replays the classical step on input slot 0: do not mix it with load_raw_next()')
             self.graph.replay()
             return
-        self.launch(self.head_names() + ('seg_b', self.tail_name()), join_before_last=True)
+        self.launch(self.head_names() + self.backward_names() + ('seg_c',), join_before_last=True)
         self.advance()
 
     def loss_dict(self):

@@ -25,13 +25,20 @@ DEFAULTS = dict(
     fork=True,            # eager launch over main / side / rec streams (False: one stream)
     rec_lane=True,        # the restoration decoder branch on its own stream
     graph_fork=False,     # capture(): keep the forks as graph branches (slower on ROCm 7: DESIGN.md section 3)
-    ddp_own_comm_stream=False,  # data parallel: launch the all-reduces from a stream of their own instead of the weight-gradient
-                          # lane (a fifth stream: aliases a lane's hardware queue on a 4-queue stack, ddp.py; UNMEASURED on a
-                          # multi-GPU node either way -- SCALE_r0x were skipped -- hence selectable)
+    ddp_own_comm_stream=-1,     # data parallel: where the all-reduces are launched from.  0: the weight-gradient lane (RCCL runs them on
+                          # its own stream anyway); 1: a stream of their own (a fifth stream: it can alias a lane's hardware queue on a
+                          # 4-queue stack, ddp.py); -1: MEASURED at start-up like the lanes are (DataParallelStep.pick_comm: a few
+                          # steps each way on this rank's real process group, the slower rank decides) -- no multi-GPU node was
+                          # available to fix the choice at build time
+    dgrad_cus=160,        # compute-unit budget of the seg plan's >= 64-channel gradient launches (they run on the persistent whole-CU
+                          # kernel conv_ws_kernel<2> since round 4): leaves 96 CUs to the weight-gradient / restoration lanes beside
+                          # them.  0 (all): 4.48 ms/step, 224: 4.46, 192: 4.44, 160: 4.43, 128: 4.51 (scripts/sweep_ws2.sh)
+    launch_threads=False, # rd_run_list_threads: the side / rec lanes' launches are enqueued by worker threads of the library, in parallel
+                          # with the main lane's (host enqueue 0.85 -> ~0.4 ms per step; the GPU executes the same graph)
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
 )
 _ENV = dict(split_wide_dgrad='RD_SPLIT_WIDE_DGRAD', mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
-            ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', rec_lane='RD_REC_LANE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
+            ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', launch_threads='RD_LAUNCH_THREADS', dgrad_cus='RD_DGRAD_CUS', rec_lane='RD_REC_LANE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
 
 
 def options(over=None):

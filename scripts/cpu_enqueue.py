@@ -46,6 +46,24 @@ for _ in range(5):
     t0 = time.perf_counter(); ts.step(); t1 = time.perf_counter(); torch.cuda.synchronize()
     best.append((t1 - t0) * 1e3)
 print('native launch list (rd_run_list), single step on an idle GPU: enqueue %.2f ms (min of 5: %.2f)' % (sum(best) / 5, min(best)))
+ts.launch_threads = True
+for _ in range(5):
+    ts.step()
+torch.cuda.synchronize()
+best = []
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); ts.step(); t1 = time.perf_counter(); torch.cuda.synchronize()
+    best.append((t1 - t0) * 1e3)
+print('native launch list + lane worker threads (rd_run_list_threads), single step on an idle GPU: enqueue %.2f ms (min of 5: %.2f)' % (sum(best) / 5, min(best)))
+t0 = time.perf_counter()
+for _ in range(n):
+    ts.step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print('... back to back: CPU enqueue %.2f ms/step, until GPU done %.2f ms/step' % ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
+ts.launch_threads = False
 # one chain: rebuilt without the lane budgets (TrainStep.capture refuses them)
 ts = S.TrainStep(bank, mods, torch.bfloat16, [2, 3, 3], 400, 400, ram='u8', options=dict(side_cus=0, rec_cus=0))
 ts.wpack.refresh(); ts.load_raw(src, trg, lam); ts.load_target(mask)

@@ -8,8 +8,11 @@ import torch.nn.functional as F
 from ramdsir import _lib as L
 
 DT = {'f32': (L.RD_F32, torch.float32), 'bf16': (L.RD_BF16, torch.bfloat16)}
-# per-op tolerance relative to the RMS of the reference tensor
+# per-op tolerances relative to the RMS of the reference tensor: max |diff| <= 4 * RTOL * rms (fp32: 8e-5) AND the RMS of the
+# element errors <= RMS_TOL * rms (fp32: 1e-5 -- BASELINE.md 3.5's "fp32 <= 1e-5 rel per op" is this bound; the max bound is wider
+# because the largest of ~10^6 rounding errors of a K ~ 10^3 accumulation sits several sigma out)
 RTOL = {'f32': 2e-5, 'bf16': 1e-2}
+RMS_TOL = {'f32': 1e-5, 'bf16': 5e-3}
 
 
 def dev():
@@ -60,6 +63,8 @@ def assert_close(got, ref, dtype, name='', scale=1.0):
     err = float((got - ref).abs().max())
     assert np.isfinite(err), name
     assert err <= RTOL[dtype] * scale * rms * 4 + 1e-30, '%s: max|diff| %.3e vs rms %.3e (dtype %s)' % (name, err, rms, dtype)
+    rms_err = float((got - ref).double().pow(2).mean().sqrt())
+    assert rms_err <= RMS_TOL[dtype] * scale * rms + 1e-30, '%s: rms(diff) %.3e vs rms %.3e (dtype %s)' % (name, rms_err, rms, dtype)
 
 
 def group_rows(param_gc, gstart, N):

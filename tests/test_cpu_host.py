@@ -162,7 +162,7 @@ def test_dataloader_worker_cap_divides_the_host_between_ranks_and_domains():
 def test_tuning_options_and_cu_budget_defaults():
     from ramdsir import tuning as T
     o = T.options(dict(side_cus=0, rec_cus=None))
-    assert o['side_cus'] == 0 and o['rec_cus'] == -1 and o['ddp_own_comm_stream'] is False
+    assert o['side_cus'] == 0 and o['rec_cus'] == -1 and o['ddp_own_comm_stream'] == -1 and o['dgrad_cus'] == 160
     assert T.cu_budget(96, None) == 96 and T.cu_budget(0, None) == 0
     with pytest.raises(KeyError):
         T.options(dict(no_such_option=1))

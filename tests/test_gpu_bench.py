@@ -1,0 +1,34 @@
+"""-m gpu: bench.py's data-parallel path on one GPU (RD_FORCE_DDP=1: a one-rank RCCL process group), so that the four-segment launch
+with the three gradient-bucket exchanges (ramdsir/ddp.py; reference: nn.DataParallel's gradient reduction, code/train.py:205-208) is
+run and TIMED on every driver round even when no multi-GPU node is available, and the bench line's multi-GPU fields are exercised."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_on_the_forced_data_parallel_path():
+    env = dict(os.environ, RD_FORCE_DDP='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '3', '--no-cpu-baseline', '--no-fp32-leg',
+                        '--no-ablation'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    cfg = d['config']
+    assert d['n_gpus'] == 1 and d['steps'] == 6 and d['value'] > 0 and d['unit'] == 'images/s'
+    assert cfg['process_group'] == 'nccl world 1' and cfg['parallelism'] == 'dp1'
+    ex = cfg['gradient_exchange']                                   # decoders, encoder levels 3-5, encoder levels 1-2, in launch order
+    assert [e['bucket'] for e in ex] == [2, 1, 0] and sum(e['bytes'] for e in ex) == 4 * 3800021
+    assert all(e['allreduce_us'] > 0 for e in ex)
+    assert cfg['ddp_comm']['own_comm_stream'] is False              # one rank: nothing to measure, the weight-gradient lane
+    lay = cfg['lane_layout']
+    assert len(lay) == 1 and set(lay[0]) >= {'main', 'side0', 'rec', 'budgets'} and lay[0]['budgets']['side_cus'] == 128
+    assert cfg['ram_pipelined'] is True and abs(cfg['final_loss']) < 10
+    # the exchange path costs little on one rank: within 15 % of the plain step of the same run's roofline block
+    assert d['roofline']['bound'] in ('hbm', 'mfma') and d['roofline_step']['algorithmic_bytes_per_step'] > 8e9

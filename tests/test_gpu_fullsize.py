@@ -19,8 +19,8 @@ Tolerances and where they come from
          with fp32 is not defined (logits 12 %, gradients ~40 % relative L2 -- and the SAME numbers separate the fp32 oracle
          from the oracle run with bf16 rounding at the HIP path's rounding points, oracle.unet.rounding).  Asserted instead:
          losses within 2e-3 of that rounding-model oracle (measured 5e-4) and 3e-2 of fp32; logits closer to the rounding
-         model than the rounding model is to fp32; the full gradient's direction (cosine >= 0.93 vs the model; measured 0.97) and
-         its distance from the model's own one-ulp self-distance, at every configuration;
+         model than the rounding model is to fp32; the full gradient's direction (cosine >= 0.97 vs the model; measured 0.986-0.991) and
+         its distance from the model's own one-ulp self-distance, at every configuration (C2 / C3 / C5 / F256);
          and a 20-step fixed-batch loss trajectory inside a band around the fp32 oracle's (torch-Adam restatement).
 """
 import functools
@@ -117,9 +117,12 @@ def test_fullsize_bf16_step_against_the_rounding_model_oracle(name):
     bp = _flat(refp['grads'], keys)
     print('bf16 %s: median grad rel-L2 %.3f (dtype %.3f, self %.3f), cos(hip, model) %.4f cos(hip, fp32) %.4f cos(model, fp32) %.4f '
           'cos(self, model) %.4f' % (name, med, med_dtype, med_self, cos(a, b), cos(a, c), cos(b, c), cos(bp, b)))
-    # gates at what is measured (round 4, MI355X): median 0.19-0.23, cos(hip, model) 0.96-0.98 -- round 3 asserted 0.35 / 0.85
+    # gates at what is measured (round 4, MI355X; C2 / C3 / C5 / F256): median 0.217 / 0.254 / 0.187 / 0.200 (the model's own one-ulp
+    # self-distance: 0.158 / 0.259 / 0.164 / 0.193), cos(hip, model) 0.986 / 0.988 / 0.991 / 0.986, cos(hip, fp32) 0.949 / 0.961 /
+    # 0.969 / 0.950 (cos(model, fp32) the same to 0.002) -- round 3 asserted 0.35 / 0.85 / 0.80
     assert med < 0.8 * med_dtype and med < 0.30, (med, med_dtype)    # the kernels add less than the dtype itself does
-    assert cos(a, b) >= 0.93 and cos(a, c) >= 0.88, (cos(a, b), cos(a, c), cos(b, c))
+    assert cos(a, b) >= 0.97 and cos(a, c) >= 0.93, (cos(a, b), cos(a, c), cos(b, c))
+    assert abs(cos(a, c) - cos(b, c)) <= 0.01, (cos(a, c), cos(b, c))   # as far from fp32 as the rounding model is, not further
     assert abs(float(a.norm() / b.norm()) - 1.0) < 0.1
     assert med <= 1.6 * med_self + 0.02, (med, med_self)
     assert cos(a, b) >= cos(bp, b) - 0.05, (cos(a, b), cos(bp, b))

@@ -828,6 +828,7 @@ def test_layout_boundary_kernels(dtype):
 @pytest.mark.parametrize('env', [
     {'RD_CONV_WS': '3', 'RD_CONV_WS_MIN2': '0', 'RD_CONV_NB1_BELOW': '0'},          # conv_ws_kernel: forward AND gradient launches
     {'RD_CONV_WS': '3', 'RD_CONV_WS_MIN2': '0', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_WS_FLAT': '0'},   # ... on 8 x 32 tiles only
+    {'RD_CONV_WS': '3', 'RD_CONV_WS_MIN2': '1073741824', 'RD_CONV_NB1_BELOW': '0'},  # conv_ws_kernel forward, gradients on conv_pf_kernel (the round-3 default)
     {'RD_CONV_WS': '0', 'RD_CONV_PP_ALL': '1', 'RD_CONV_NB1_BELOW': '0'},           # conv_pp_kernel (LDS-staged epilogue) everywhere
     {'RD_CONV_PP_OFF': '1', 'RD_CONV_NB1_BELOW': '0'},                              # conv_pf_kernel with the register epilogues
     {'RD_CONV_PP_OFF': '1', 'RD_CONV_NB1_BELOW': '0', 'RD_CONV_FLAT_TILES': '0'},   # ... on 8 x 32 tiles only (default: 10 x 25 where more lanes are live)
@@ -836,7 +837,7 @@ def test_layout_boundary_kernels(dtype):
     {'RD_SW_TPW': '5'},                                                             # conv_small_fwd_kernel: 5 tiles per workgroup (+ ghosts)
     {'RD_SW_TPW': '2'},                                                             # ... fewer tiles than register sets
     {'RD_CONV_SMALL_FWD': '0'},                                                      # conv_small_kernel for the forward launches
-], ids=['ws_fwd_bwd', 'ws_fwd_bwd_8x32', 'pp_staged', 'pf_lean', 'pf_lean_8x32', 'pf_staged', 'nb1_everywhere', 'small_fwd_tpw5', 'small_fwd_tpw2', 'small_fwd_off'])
+], ids=['ws_fwd_bwd', 'ws_fwd_bwd_8x32', 'ws_fwd_pf_bwd', 'pp_staged', 'pf_lean', 'pf_lean_8x32', 'pf_staged', 'nb1_everywhere', 'small_fwd_tpw5', 'small_fwd_tpw2', 'small_fwd_off'])
 def test_conv_kernels_under_forced_dispatch(env):
     """Which kernel a 64-wide launch takes depends on its size (csrc/conv_pp.hip, conv_big.hip), and the cases above are small.
     The dispatch switches (debug build of the library only) are read once per process: re-run the conv parity tests in a child
