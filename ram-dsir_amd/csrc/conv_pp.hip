@@ -589,8 +589,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     M.tile = tile_begin;
     M.c = 0;
     pp_decode(M, q, gm);
-    // WMFMA: this wave's share of the weight chunk (thread -> row nn_w, channel slot sw, all nine taps), one step ahead in
-    // LDS and one more in registers, exactly as the loader does it in the other mode
+    // WMFMA: this wave's share of the weight chunk (thread -> row nn_w, channel slot sw, all nine taps), one step ahead in LDS
     uint4 wq[PP_WIT] = {};
     PpStage Lw = M;                                        // the step whose weights are in flight
     const int sw_w = tid & 3, nn_w = tid >> 2;
@@ -602,10 +601,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     if constexpr (WMFMA) {
 #pragma unroll
         for (int t = 0; t < PP_WIT; ++t) w_issue(t);       // step 0
-        pp_advance(Lw, q, gm);
 #pragma unroll
-        for (int t = 0; t < PP_WIT; ++t) { w_store(t, 0); w_issue(t); }   // step 0 -> buffer 0, step 1 requested
-        pp_advance(Lw, q, gm);                             // Lw = step 2: what the first loop iteration requests
+        for (int t = 0; t < PP_WIT; ++t) w_store(t, 0);    // step 0 -> buffer 0
+        pp_advance(Lw, q, gm);                             // Lw = step 1: what the first loop iteration requests AND stores
     }
 
     // operand fragments of one (tap, k-step) group: A = 2 x (32 pixels x 16 channels), B = 2 x (32 outputs x 16 channels);
@@ -738,9 +736,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
 #pragma unroll
         for (int grp = 0; grp < 18; ++grp) {
             if constexpr (WMFMA) {
-                // weights of step s+1 (in registers since the previous step) -> the other buffer, step s+2 requested: one
-                // tap per (tap, k-step) group pair, between the MFMA groups
-                if ((grp & 1) == 0) { w_store(grp >> 1, par ^ 1); w_issue(grp >> 1); }
+                // weights of step s+1: requested one tap per group in the first half of the step, written to the other buffer in
+                // the second half (an L2 hit has ~9 groups = 1 600 cycles to land).  Round 3 carried them in registers ACROSS the
+                // step boundary (requested in step s, stored in step s+1): the loop's back edge then needed all nine vectors in
+                // their loop-header registers -- `s_waitcnt vmcnt(8) .. vmcnt(0)` + 18 v_mov_b64 behind every barrier, i.e. every
+                // step waited for the loads it had just issued (ISA of conv_ws_kernel<1, *>)
+                if (grp < PP_WIT) w_issue(grp);
+                else w_store(grp - PP_WIT, par ^ 1);
             }
             if (grp + 1 < 18 && !WS_EXP(64)) load_group(grp + 1, par, fr[(grp + 1) & 1]);
             const Frag& f = fr[grp & 1];

@@ -297,6 +297,7 @@ class Plan:
         self.dgrad_cus = 0              # >0: ... of its >= 64-channel gradient launches only (tuning.py dgrad_cus)
         self.materialize_min_c = None   # channels from which BN+ReLU outputs are stored once (rd_bn_apply)
         self.materialize_dz_min_c = None  # ... and from which the BN-backward gradients dz are
+        self.materialize_dz_wide = bool(T.options()['mat_dz_wide'])
         self.fused_bwd = bool(T.options()['fused_bwd'])   # small-channel 3x3 convs: dgrad + weight gradient in one launch
         self.split_wide_dgrad = bool(T.options()['split_wide_dgrad'])   # _dgrad_halves below
         self._unit = {}
@@ -523,7 +524,12 @@ class Plan:
                     q.dbias = self.bank.g(node.mname, node.name + '.bias').data_ptr()
                 self.keep.append(q)
                 self.bwd.append((lib.rd_gn_finalize_bwd if o.norm.kind == 'gn' else lib.rd_bn_finalize_bwd, (C.byref(q),)))
-                if (not o.up and self.materialize_dz_min_c is not None and o.C >= self.materialize_dz_min_c):
+                # dz stored once: every >= 64-channel layer, and (round 4) a 32-channel layer whose gradient launch is 64-wide (more
+                # than 32 input channels: dec.convu1.conv1, rec.convu2.conv1) -- a BatchNorm-backward source keeps that launch on the
+                # two-operand conv_pf_kernel (110 us, the slowest gradient launch of the step); with a stored dz it runs on the
+                # persistent conv_ws_kernel like the other 64-wide gradients
+                wide_dgrad = self.materialize_dz_wide and isinstance(node, ConvNode) and node.taps == 9 and node.Cin > 32 and o.C >= 32
+                if (not o.up and self.materialize_dz_min_c is not None and (o.C >= self.materialize_dz_min_c or wide_dgrad)):
                     o.dz_buf = self.alloc_act((N, H, W, o.C))
                     self.bwd.append((lib.rd_bn_apply, (o.grad_buf().data_ptr(), o.buf.data_ptr(), o.dz_buf.data_ptr(), o.P.data_ptr(),
                                                        o.Q.data_ptr(), o.R.data_ptr(), 1.0, N, H, W, o.C, self.G, self.gs_arr, dt)))

@@ -46,6 +46,7 @@ class TrainStep:
         self.seg.dgrad_cus = int(opt['dgrad_cus']) if budget else 0
         self.seg.materialize_min_c = opt['mat_min_c'] if opt['mat_min_c'] > 0 else None
         self.seg.materialize_dz_min_c = opt['mat_dz_min_c'] if opt['mat_dz_min_c'] > 0 else None
+        self.seg.materialize_dz_wide = bool(opt['mat_dz_wide'])
         slot = self.seg.slot_channels()
         self.x = E.Act(self.seg, 2 * B, H, W, in_channels, name='input', cstride=slot if in_channels < slot else None)
         self.feats = E.build_encoder(self.seg, self.x, n=n)
@@ -62,6 +63,7 @@ class TrainStep:
         self.rec.conv_cus = T.cu_budget(opt['rec_cus'], dev) if lane else 0
         self.rec.materialize_min_c = self.seg.materialize_min_c
         self.rec.materialize_dz_min_c = self.seg.materialize_dz_min_c
+        self.rec.materialize_dz_wide = self.seg.materialize_dz_wide
         self.rec_logits = E.build_rec_decoder(self.rec, self.feats[4], n_off=B, g_fixed=1, domains=list(range(len(batch_sizes))),
                                               n=n, num_classes=in_channels)
         self.seg.build(self.wpack)

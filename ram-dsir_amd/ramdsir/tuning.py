@@ -7,6 +7,7 @@ import os
 DEFAULTS = dict(
     mat_min_c=0,          # >0: store relu(bn(z)) once for layers with at least this many channels (measured a net loss: off)
     mat_dz_min_c=64,      # store the BN-backward gradient dz once for layers with at least this many channels
+    mat_dz_wide=True,     # ... and for a 32-channel layer whose gradient launch is 64-wide (engine.Plan.build)
     pool_mat=True,        # store the 2x2 max-pool in front of ConvD levels 2-5 once (rd_pool_fwd / rd_pool_bwd)
     fused_bwd=True,       # <= 32-channel 3x3 convs (bf16): dgrad + weight gradient in one launch (csrc/conv_fused.hip)
     split_wide_dgrad=False,  # a one-chunk gradient launch with 33..64 output channels as two launches of the small-channel kernel
@@ -37,7 +38,7 @@ DEFAULTS = dict(
                           # with the main lane's (host enqueue 0.85 -> ~0.4 ms per step; the GPU executes the same graph)
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
 )
-_ENV = dict(split_wide_dgrad='RD_SPLIT_WIDE_DGRAD', mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
+_ENV = dict(split_wide_dgrad='RD_SPLIT_WIDE_DGRAD', mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', mat_dz_wide='RD_MAT_DZ_WIDE', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
             ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', launch_threads='RD_LAUNCH_THREADS', dgrad_cus='RD_DGRAD_CUS', rec_lane='RD_REC_LANE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
 
 
