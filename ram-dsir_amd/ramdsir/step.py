@@ -168,12 +168,23 @@ class TrainStep:
         a = []
         a += self.seg.fwd[:fdec]                                     # encoder
         a.append(E.sync_op('fork', 'rec'))
-        rec_branch = E.tag_lane(self.rec.fwd + [rec_loss] + self.rec.bwd[:-1], 'rec')
+        # The restoration lane's STAND-ALONE weight gradients (its >= 64-channel and 1x1 layers, their split reductions, the bias
+        # column sum) are taken out of its dgrad chain and enqueued behind the join (opt rec_wgrad_late): nothing but Adam needs them,
+        # while the main lane waits at the join for the chain (scripts/join_probe.py: main arrives at 3.07 ms, the lane at 3.16).
+        # They then run on the same stream during the encoder backward, when that lane has nothing else to do.
+        late = bool(self.opt['rec_wgrad_late'])
+        is_late = lambda op: late and len(op) > 2 and bool(op[2].get('side'))
+        rec_bwd = self.rec.bwd[:-1]
+        rec_branch = E.tag_lane(self.rec.fwd + [rec_loss] + [op for op in rec_bwd if not is_late(op)], 'rec')
+        rec_late = E.tag_lane([op for op in rec_bwd if is_late(op)], 'rec')
         dec_branch = self.seg.fwd[fdec:] + [seg_loss] + self.seg.bwd[:split]
         a += E.interleave(dec_branch, rec_branch)
         a.append(E.sync_op('join', 'rec'))
         a.append(self.rec.bwd[-1])                                   # rec.convu4.conv1 dgrad: += into the bottleneck gradient
         assert self.rec.bwd[-1][2].get('what') == 'dgrad', self.rec.bwd[-1][2]
+        if rec_late:
+            a.append(E.sync_op('fork', 'rec'))                       # (re-opens the lane: the join in front of Adam covers it)
+            a += rec_late
         b = list(self.seg.bwd[split:])
         # encoder backward in two parts (data parallel: the deep levels hold 98 % of the encoder's parameters and finish
         # first, so their gradients are all-reduced while the 200x200 / 400x400 levels are still running)

@@ -25,6 +25,7 @@ DEFAULTS = dict(
                           # (144: 5.69, 112: 5.68, 96: 5.75, 64: 6.4); the HBM-bound 16-channel launches keep the whole GPU
     fork=True,            # eager launch over main / side / rec streams (False: one stream)
     rec_lane=True,        # the restoration decoder branch on its own stream
+    rec_wgrad_late=True,  # its stand-alone weight gradients behind the join with the main lane instead of inside its dgrad chain
     graph_fork=False,     # capture(): keep the forks as graph branches (slower on ROCm 7: DESIGN.md section 3)
     ddp_own_comm_stream=-1,     # data parallel: where the all-reduces are launched from.  0: the weight-gradient lane (RCCL runs them on
                           # its own stream anyway); 1: a stream of their own (a fifth stream: it can alias a lane's hardware queue on a
@@ -39,7 +40,7 @@ DEFAULTS = dict(
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
 )
 _ENV = dict(split_wide_dgrad='RD_SPLIT_WIDE_DGRAD', mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', mat_dz_wide='RD_MAT_DZ_WIDE', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
-            ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', launch_threads='RD_LAUNCH_THREADS', dgrad_cus='RD_DGRAD_CUS', rec_lane='RD_REC_LANE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
+            ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', launch_threads='RD_LAUNCH_THREADS', dgrad_cus='RD_DGRAD_CUS', rec_lane='RD_REC_LANE', rec_wgrad_late='RD_REC_WGRAD_LATE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
 
 
 def options(over=None):
