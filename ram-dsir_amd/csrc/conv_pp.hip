@@ -338,7 +338,8 @@ template <int TS> struct WsLds {
     static constexpr int TAB = W0 + 2 * PP_W_BYTES;
     static constexpr int TAB_BYTES = 16 * 1024;
     static constexpr int SLOTS = TAB + TAB_BYTES;
-    static constexpr int LDS = SLOTS + PP_MAX_CHUNKS * 4 * 48;
+    static constexpr int SLOTS2 = SLOTS + PP_MAX_CHUNKS * 4 * 48;         // BWD2: second operand + Q row per (chunk, slot), 16 B each
+    static constexpr int LDS = SLOTS2 + PP_MAX_CHUNKS * 4 * 16;
 };
 static_assert(WsLds<0>::LDS <= 160 * 1024 && WsLds<1>::LDS <= 160 * 1024, "conv_ws_kernel: LDS map exceeds the CU");
 #ifdef RD_DEBUG_SWITCHES
@@ -353,11 +354,15 @@ __device__ unsigned long long ws_trace[2][64][4];          // [role][step][event
 #define WS_EXP(bit) false
 #endif
 
-template <int MODE, int TS>
+// BWD2 (MODE 2 only): the source is a BatchNorm-backward pair (g, z) and the loader forms dz = P g + Q z + R while it stages the tile
+// -- two loads and two fused multiply-adds per vector on waves that otherwise wait at the barrier for half of every tile -- instead of
+// reading a dz tensor that a separate rd_bn_apply launch stored (round 4: 15 elementwise launches and 0.86 GB of traffic per step)
+template <int MODE, int TS, bool BWD2 = false>
 __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int tiles_total) {
     typedef bf16_t T;
     constexpr int S = 8;
     static_assert(MODE == 1 || MODE == 2, "register epilogues only");
+    static_assert(!BWD2 || MODE == 2, "two-operand sources exist in the gradient mode only");
     // TS 1: 10 x 25 pixel tiles, flattened row-major onto the 256 MFMA rows (250 live); the 12 x 27 halo tile fits the planes of
     // the 10 x 34 one, only the per-lane pixel of an MFMA row and the halo row pitch change
     constexpr int THt = TileGeo<TS>::H, TWt = TileGeo<TS>::W, PWt = TWt + 2, NPIXt = (THt + 2) * PWt;
@@ -365,6 +370,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     // this kernel's own LDS map (WsLds<TS>): the planes hold the halo tile at the conflict-free row pitch of its shape
     typedef WsLds<TS> LM;
     constexpr int PLt = LM::PL, WS_PLANE_A = LM::PLANE_A, WS_IN_BYTES = LM::IN_BYTES, WS_W0 = LM::W0, WS_TAB = LM::TAB, WS_SLOTS = LM::SLOTS;
+    constexpr int WS_SLOTS2 = LM::SLOTS2;
     // who stages the weight chunk of the next step: the MFMA waves in the forward mode (they have ~1.5 issue slots per MFMA
     // gap to spare and 36 registers of headroom; the loader's nine weight vectors cost 1000-3000 cycles per step on top of
     // its ~3000 for the halo items against ~3300 of MFMAs: traces in profiles/r02_ws_trace.txt), the loader waves in the
@@ -415,6 +421,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         e.flags = (live ? 1 : 0) | (rawm ? 2 : 0);
         e.pad_ = 0;
         reinterpret_cast<PpSlot*>(smem + WS_SLOTS)[t] = e;
+        if constexpr (BWD2) {
+            const bool bwd = sd.mode == RD_SRC_BNBWD;
+            struct { const T* ptr2; const float* q; } e2;
+            e2.ptr2 = bwd ? reinterpret_cast<const T*>(sd.ptr2) + cc : e.ptr;                 // a plain source aliases its own tensor, Q = 0
+            e2.q = bwd ? sd.q + cc : nullptr;
+            *reinterpret_cast<decltype(e2)*>(smem + WS_SLOTS2 + t * 16) = e2;
+        }
     }
     {
         float* tab = reinterpret_cast<float*>(smem + WS_TAB);
@@ -450,10 +463,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         const T* wbase = reinterpret_cast<const T*>(p.w) + nn_w * 32 + sw * S;
         const size_t w_tap = (size_t)p.CoutPad * 32;            // elements between the taps of one chunk
         uint4 raw[PP_NIT] = {}, wr[PP_WIT] = {};
+        uint4 raw2[BWD2 ? PP_NIT : 1] = {};                  // BWD2: the second operand (z) of every halo item
         float scC[S], shC[S], scL[S], shL[S];
+        float qC[BWD2 ? S : 1] = {}, qL[BWD2 ? S : 1] = {};
         float slopeC = 1.f, slopeL = 1.f;
         bool copyC = false, copyL = false;   // raw source without activation: the 16 bytes go to LDS as they are
         const T* ldbase = nullptr;
+        const T* ldbase2 = nullptr;
         int ldC = 0;
         int offL[PP_NIT];                    // stage L's tile: pixel index (clamped into the image) of each halo item
         int inL = 0, inC = 0;                // bit b: halo item b lies inside the image (and this slot carries a channel)
@@ -479,6 +495,18 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             ldbase = e.ptr + (size_t)(L.n + e.n_off) * H * W * e.C;
             slopeL = e.slope;
             copyL = rawm && e.slope == 1.f;
+            if constexpr (BWD2) {
+                struct E2 { const T* ptr2; const float* q; };
+                const E2 e2 = *reinterpret_cast<const E2*>(smem + WS_SLOTS2 + (L.c * 4 + sw) * 16);
+                ldbase2 = e2.ptr2 + (size_t)(L.n + e.n_off) * H * W * e.C;
+                const bool hasq = e2.q != nullptr;
+                const float* qp = hasq ? e2.q + (e.g_fixed >= 0 ? e.g_fixed : L.g) * e.C : reinterpret_cast<const float*>(p.w);
+                const float4 q0 = ldf4g(qp), q1 = ldf4g(qp + 4);
+                qL[0] = q0.x; qL[1] = q0.y; qL[2] = q0.z; qL[3] = q0.w; qL[4] = q1.x; qL[5] = q1.y; qL[6] = q1.z; qL[7] = q1.w;
+#pragma unroll
+                for (int e3 = 0; e3 < S; ++e3) qL[e3] = hasq ? qL[e3] : 0.f;
+                copyL = copyL && !hasq;
+            }
             const int g = e.g_fixed >= 0 ? e.g_fixed : L.g;
             const float* sp = e.scale + (rawm ? 0 : g * e.C);
             const float* hp = e.shift + (rawm ? 0 : g * e.C);
@@ -493,6 +521,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         };
         auto issue_item = [&](int b) {
             if (!WS_EXP(2)) raw[b] = ld16g(ldbase + (size_t)(unsigned)offL[b] * (unsigned)ldC);
+            if constexpr (BWD2) raw2[b] = ld16g(ldbase2 + (size_t)(unsigned)offL[b] * (unsigned)ldC);
         };
         const T* wptr = nullptr;
         auto begin_w = [&]() { wptr = wbase + ((size_t)(L.c * 9) * p.CoutPad + L.n0) * 32; };
@@ -506,8 +535,15 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             if (xform) {
                 float v[S];
                 Slot<T>::unpack(u, v);
+                if constexpr (BWD2) {
+                    float z2[S];
+                    Slot<T>::unpack(raw2[b], z2);
 #pragma unroll
-                for (int e = 0; e < S; ++e) v[e] = act_fn(scC[e] * v[e] + shC[e], slopeC);
+                    for (int e = 0; e < S; ++e) v[e] = bn_bwd_value(scC[e], v[e], qC[e], z2[e], shC[e]);      // dz = P g + Q z + R
+                } else {
+#pragma unroll
+                    for (int e = 0; e < S; ++e) v[e] = act_fn(scC[e] * v[e] + shC[e], slopeC);
+                }
                 u = Slot<T>::pack(v);
             }
             const bool in = ((maskC >> b) & 1) != 0;
@@ -523,6 +559,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             copyC = copyL;
 #pragma unroll
             for (int e = 0; e < S; ++e) { scC[e] = scL[e]; shC[e] = shL[e]; }
+            if constexpr (BWD2) {
+#pragma unroll
+                for (int e = 0; e < S; ++e) qC[e] = qL[e];
+            }
             const int tile0 = L.tile;
             pp_advance(L, q, gm);
             if (L.tile != tile0) tile_geom();
@@ -532,7 +572,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         begin_issue();
         begin_w();
 #pragma unroll
-        for (int b = 0; b < PP_NIT; ++b) raw[b] = ld16g(ldbase + (size_t)(unsigned)offL[b] * (unsigned)ldC);
+        for (int b = 0; b < PP_NIT; ++b) issue_item(b);
         if constexpr (!WMFMA) {
 #pragma unroll
             for (int t = 0; t < PP_WIT; ++t) wr[t] = ld16(wptr + t * w_tap);
@@ -541,7 +581,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         begin_issue();
         begin_w();
 #pragma unroll
-        for (int b = 0; b < PP_NIT; ++b) { consume_item(b, 0, true); raw[b] = ld16g(ldbase + (size_t)(unsigned)offL[b] * (unsigned)ldC); }
+        for (int b = 0; b < PP_NIT; ++b) { consume_item(b, 0, true); issue_item(b); }
         if constexpr (!WMFMA) {
 #pragma unroll
             for (int t = 0; t < PP_WIT; ++t) { consume_w(t, 0); wr[t] = ld16(wptr + t * w_tap); }
@@ -850,13 +890,19 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
 }
 
 // plain per-pixel single-operand sources made of whole 16-byte channel slots (the fill above is branch-free)
-bool pp_sources_ok(const rd_conv_t& p) {
+// 0: not for these kernels; 1: single-operand sources; 2: a BatchNorm-backward source (conv_ws_kernel<2, *, true> only)
+int pp_sources_kind(const rd_conv_t& p) {
+    int kind = 1;
     for (int i = 0; i < p.nsrc; ++i) {
         const int m = p.src[i].mode;
-        if (!(m == RD_SRC_RAW || m == RD_SRC_AFF || m == RD_SRC_AFFACT) || p.src[i].C % 8) return false;
-        if (m != RD_SRC_RAW && (((uintptr_t)p.src[i].scale | (uintptr_t)p.src[i].shift) & 15)) return false;   // float4 coefficient reads
+        if (!(m == RD_SRC_RAW || m == RD_SRC_AFF || m == RD_SRC_AFFACT || m == RD_SRC_BNBWD) || p.src[i].C % 8) return 0;
+        if (m != RD_SRC_RAW && (((uintptr_t)p.src[i].scale | (uintptr_t)p.src[i].shift) & 15)) return 0;   // float4 coefficient reads
+        if (m == RD_SRC_BNBWD) {
+            if (p.emode != 1 || (((uintptr_t)p.src[i].q | (uintptr_t)p.src[i].ptr2) & 15)) return 0;
+            kind = 2;
+        }
     }
-    return p.Cin % 8 == 0;
+    return p.Cin % 8 == 0 ? kind : 0;
 }
 
 }  // namespace
@@ -868,7 +914,8 @@ extern "C" int rd_debug_ws_trace(unsigned long long* out) {             // debug
 #endif
 
 int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
-    if (p.taps != 9 || p.CoutPad % PP_NT || p.CinPad > 32 * PP_MAX_CHUNKS || !pp_sources_ok(p)) return RD_CONV_PP_NA;
+    const int skind = pp_sources_kind(p);
+    if (p.taps != 9 || p.CoutPad % PP_NT || p.CinPad > 32 * PP_MAX_CHUNKS || !skind) return RD_CONV_PP_NA;
     static int n_cu = 0;
     if (!n_cu) {
         n_cu = rd_num_cus();
@@ -877,6 +924,8 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<0>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<1>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<1>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<0>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<1>::LDS);
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / PP_NT);
     const int cus = (p.cu_limit > 0 && p.cu_limit < n_cu) ? p.cu_limit : n_cu;     // a side lane's budget (ramdsir.h)
@@ -903,6 +952,8 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     bool accumulates = false;                                  // gradient launches that add to an existing gradient stay with conv_pf_kernel
     if (mode == 2)
         for (int i = 0; i < 2; ++i) accumulates = accumulates || (p.dst[i].kind != RD_DST_NONE && p.dst[i].accumulate);
+    if (skind == 2 && !(mode == 2 && (ws & 2) && tiles >= ws_min2 && !accumulates && tab <= (size_t)WsLds<0>::TAB_BYTES))
+        return RD_CONV_PP_NA;                                  // a two-operand source runs on conv_ws_kernel<2, *, true> or not here at all
     if (mode && (ws & mode) && (mode == 1 || (tiles >= ws_min2 && !accumulates)) && tab <= (size_t)WsLds<0>::TAB_BYTES) {
         // debug build only: RD_CONV_WS_EXP = timing experiments (-DRD_WS_EXP), RD_CONV_WS_TRACE_MIN = launches with at least
         // that many tiles record the s_memtime trace (scripts/ws_trace.py); both ride in the high bits of the tile count
@@ -919,6 +970,9 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         if (mode == 1) {
             if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
             else hipLaunchKernelGGL((conv_ws_kernel<1, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
+        } else if (skind == 2) {
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
+            else hipLaunchKernelGGL((conv_ws_kernel<2, 0, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
         } else {
             if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
             else hipLaunchKernelGGL((conv_ws_kernel<2, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);

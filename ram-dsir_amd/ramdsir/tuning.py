@@ -6,8 +6,11 @@ import os
 
 DEFAULTS = dict(
     mat_min_c=0,          # >0: store relu(bn(z)) once for layers with at least this many channels (measured a net loss: off)
-    mat_dz_min_c=64,      # store the BN-backward gradient dz once for layers with at least this many channels
-    mat_dz_wide=True,     # ... and for a 32-channel layer whose gradient launch is 64-wide (engine.Plan.build)
+    mat_dz_min_c=0,       # >0: store the BN-backward gradient dz once (rd_bn_apply) for layers with at least this many channels.  Off since
+                          # round 4: conv_ws_kernel<2,TS,true> computes dz from (z, g) in its loader warps, so the gradient launch and the
+                          # weight gradient both read the two operands and the extra pass (14 launches, 0.25 ms of main-lane time) is gone:
+                          # 4.36 -> 4.23 ms/step together with side_cus 128 -> 96 (docs/experiments.md, round-4 rows)
+    mat_dz_wide=True,     # with mat_dz_min_c > 0: ... and for a 32-channel layer whose gradient launch is 64-wide (engine.Plan.build)
     pool_mat=True,        # store the 2x2 max-pool in front of ConvD levels 2-5 once (rd_pool_fwd / rd_pool_bwd)
     fused_bwd=True,       # <= 32-channel 3x3 convs (bf16): dgrad + weight gradient in one launch (csrc/conv_fused.hip)
     split_wide_dgrad=False,  # a one-chunk gradient launch with 33..64 output channels as two launches of the small-channel kernel
@@ -19,10 +22,10 @@ DEFAULTS = dict(
     rec_cus=-1,           # compute units the restoration-decoder lane's persistent launches may take (0: all, -1: half of
                           # the device = 128 on MI355X, where the numbers below were measured); the lane ends
                           # 1.4 ms before the main one, so it can run narrower: 5.59 -> 5.55 ms/step (96: 5.57, 64: 5.70)
-    side_cus=-1,          # compute units a weight-gradient launch may take while it runs beside the dgrad chain (fork=True;
-                          # 0: all, -1: half of the device);
-                          # its persistent workgroups cannot share a CU with the chain's kernels: 256 -> 128 = 5.70 -> 5.63 ms/step
-                          # (144: 5.69, 112: 5.68, 96: 5.75, 64: 6.4); the HBM-bound 16-channel launches keep the whole GPU
+    side_cus=96,          # compute units a weight-gradient launch may take while it runs beside the dgrad chain (fork=True;
+                          # 0: all, -1: half of the device); its persistent workgroups cannot share a CU with the chain's kernels.
+                          # Round-4 sweep with the gradient chain on conv_ws_kernel<2> at dgrad_cus=160 (160 + 96 = the device):
+                          # 64: 4.29, 80: 4.23, 96: 4.23 / 4.20, 112: 4.36, 128: 4.36 ms/step; the HBM-bound 16-channel launches keep the whole GPU
     fork=True,            # eager launch over main / side / rec streams (False: one stream)
     rec_lane=True,        # the restoration decoder branch on its own stream
     rec_wgrad_late=True,  # its stand-alone weight gradients behind the join with the main lane instead of inside its dgrad chain
