@@ -797,9 +797,18 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             // Keep the fragment double buffer REAL: without these the compiler sinks the four ds_read_b128 of group grp+1 below the group
             // boundary, next to their MFMAs (sched_barrier does not order memory operations at instruction selection), and every group
             // waits lgkmcnt(0) twice for reads it has just issued -- 3 100-3 400 cycles per step against 2 304 of MFMA issue.  The
-            // memory clobber holds the reads in their group, the group barriers put them in front of its four MFMAs (ISA: rx4 W[l5] M W[l4] M M M)
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            // memory clobber holds the reads in their group; the group barriers interleave them with its four MFMAs (ISA: W[l1] M r W[l1] M r L M r
+            // M r): each read (and the weight load / store of the group) issues in the shadow of a running MFMA instead of all of them
+            // behind the fourth one -- forward launches another -1.5...-3.5 % alone, gradient launches -1...-5 %
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -188,8 +188,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int Cout
 // MFMA operands come from gfx950's transposing LDS read: in a 16-lane group lane i points ds_read_b64_tr_b16 at
 // pixel (i/4), channels 4*(i%4)..+3 of a 4-pixel x 16-channel block and receives channel i of the four pixels
 // (probe: scripts/probe/tr_probe.hip).  The three horizontal taps of a kernel row share three such reads of 4
-// pixels each (12 >= 8+2), the odd tap is 4 v_alignbit as before.  Row pitches are 144 B (64 channels) / 96 B (32):
-// the four pixel rows of a group then fall into disjoint 8-bank spans.  Plain sources only (PlainSrc), tile-ahead prefetch.
+// pixels each (12 >= 8+2), the odd tap is 4 v_alignbit as before.  Plain sources only (PlainSrc), tile-ahead prefetch.
+// ROW PITCH AND SWIZZLE.  The LDS serves a ds_read_b64_tr_b16 in two 32-lane halves over 64 banks (bank = (a/4) mod 64: 256 B), and the
+// 32 lanes of a half are the 16-lane groups of channel sub-blocks 0-15 and 16-31 of the SAME four pixels: 4 pixel rows x 64 contiguous
+// bytes.  They are conflict-free only if the four rows tile the 256 B exactly.  Rounds 1-3 used pitches 144 B / 96 B (reasoned per
+// 16-lane group: 4 x 32 B): rows 2 and 3 then overlapped rows 0 and 1 by half -- every transpose read took 3 LDS cycles instead of 2
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33 in wgrad_ws_kernel, profiles/r04_sq_counters.txt).  Now: 32-channel tiles at pitch
+// 64 B (no padding: four pixels = 256 contiguous bytes); 64-channel tiles at pitch 128 B with the two 64-byte halves of a pixel
+// SWAPPED where bit 1 of the pixel index is set -- of four consecutive pixels (any start) two then put the wanted half at 0 / 128 and
+// two at 64 / 192 (mod 256).  A padded pitch of 192 B is conflict-free too but costs 32 KB more LDS per workgroup, and that cost
+// 0.03 ms of step time (other lanes' workgroups no longer fit beside it; docs/experiments.md) for no gain of the kernel alone.
+constexpr int tr_pitch(int channels) { return channels == 32 ? 64 : 128; }
+// byte offset of 16-byte channel slot `slot` of pixel `pix` in a [pixel][C channels] tile
+template <int C>
+__device__ __forceinline__ int tr_off(int pix, int slot) {
+    if constexpr (C == 32) return pix * 64 + slot * 16;
+    else return pix * 128 + ((((slot >> 2) ^ (pix >> 1)) & 1) << 6) + (slot & 3) * 16;
+}
+// a lane's fragment base: pixel pix0 of the tile, 32-channel block blk, `sub` bytes into the block; flip = 1 where the pixels actually
+// read sit an odd multiple of 2 further on (halo rows of odd index at a row length of 34: +34 r)
+template <int C>
+__device__ __forceinline__ int tr_frag(int pix0, int blk, int sub, int flip) {
+    if constexpr (C == 32) return pix0 * 64 + sub;
+    else return pix0 * 128 + (((blk ^ (pix0 >> 1) ^ flip) & 1) << 6) + sub;
+}
 typedef __attribute__((ext_vector_type(4))) short tr_s4;
 typedef __attribute__((address_space(3))) tr_s4 tr_lds_s4;
 __device__ __forceinline__ uint2 lds_tr(const char* p) {
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
     constexpr int NPIX = PH * PW;
     constexpr int CA = NB * 32, CZ = MB * 32;
-    constexpr int PA = CA * 2 + (CA == 32 ? 32 : 16), PZ = CZ * 2 + (CZ == 32 ? 32 : 16);   // bytes per pixel row
+    constexpr int PA = tr_pitch(CA), PZ = tr_pitch(CZ);     // bytes per pixel row
     constexpr int KS = 4 / (MB * NB);
     constexpr int ROWS = TH / KS;
     constexpr int NSA = CA / S, NSZ = CZ / S;               // channel slots per pixel
@@ -253,14 +275,14 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
         const int pix = tid / NSA + (256 / NSA) * b, py = pix / PW, px = pix - py * PW;
         iga.py[b] = (short)py;
         iga.px[b] = (short)px;
-        iga.lds[b] = pix < NPIX ? pix * PA + sla * 16 : -1;
+        iga.lds[b] = pix < NPIX ? tr_off<CA>(pix, sla) : -1;
     }
 #pragma unroll
     for (int b = 0; b < NITZ; ++b) {
         const int pix = tid / NSZ + (256 / NSZ) * b;
         igz.py[b] = (short)(pix / TW);
         igz.px[b] = (short)(pix % TW);
-        igz.lds[b] = pix * PZ + slz * 16;
+        igz.lds[b] = tr_off<CZ>(pix, slz);
     }
     uint4 raw_a[NITA][1], raw_z[NITZ][NQZ];
     auto issue = [&](int tile) {
@@ -281,8 +303,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
 
     // ---- fragment addressing: 16-lane group gq = lane >> 4 -> 16-channel sub-block (gq & 1), K half (gq >> 1)
     const int i16 = lane & 15, gq = lane >> 4;
-    const int zoff = ((gq >> 1) * 8 + (i16 >> 2)) * PZ + (mb * 32 + (gq & 1) * 16 + (i16 & 3) * 4) * 2;
-    const int aoff = ((gq >> 1) * 8 + (i16 >> 2)) * PA + (nb * 32 + (gq & 1) * 16 + (i16 & 3) * 4) * 2;
+    const int pix0 = (gq >> 1) * 8 + (i16 >> 2), sub = ((gq & 1) * 16 + (i16 & 3) * 4) * 2;
+    const int zoff = tr_frag<CZ>(pix0, mb, sub, 0);
+    constexpr bool ROWFLIP = (PW % 4) == 2;                 // a halo row of odd index starts an odd multiple of 2 pixels further on
+    const int aoff0 = tr_frag<CA>(pix0, nb, sub, 0), aoff1 = tr_frag<CA>(pix0, nb, sub, ROWFLIP ? 1 : 0);
 
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         int n, y0, x0;
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
                     x = x0 - HALO + px;
                     return (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
                 },
-                [&](int idx, const uint4& u) { *reinterpret_cast<uint4*>(s_a + (idx / NSA) * PA + sla * 16) = u; });
+                [&](int idx, const uint4& u) { *reinterpret_cast<uint4*>(s_a + tr_off<CA>(idx / NSA, sla)) = u; });
             tile_fill<T, 256, false>(&p.dz, ctx_z, n, H, W, tid, TH * TW * NSZ,
                 [&](int idx, int& y, int& x) -> bool {
                     const int pix = idx / NSZ;
@@ -323,7 +347,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
                     x = x0 + pix % TW;
                     return y < H && x < W;
                 },
-                [&](int idx, const uint4& u) { *reinterpret_cast<uint4*>(s_z + (idx / NSZ) * PZ + slz * 16) = u; });
+                [&](int idx, const uint4& u) { *reinterpret_cast<uint4*>(s_z + tr_off<CZ>(idx / NSZ, slz)) = u; });
         }
         __syncthreads();
         if (tile + (int)gridDim.x < total_tiles) issue(tile + gridDim.x);
@@ -336,7 +360,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
                 const bf16x8 afrag = __builtin_bit_cast(bf16x8, make_uint4(z0.x, z0.y, z1.x, z1.y));
 #pragma unroll
                 for (int kh = 0; kh < KW; ++kh) {
-                    const char* ap = s_a + aoff + ((row + kh) * PW + ks * 16) * PA;     // halo coords: input = output + tap
+                    const char* ap = s_a + (((row + kh) & 1) ? aoff1 : aoff0) + ((row + kh) * PW + ks * 16) * PA;     // halo coords: input = output + tap
                     const uint2 a0 = lds_tr(ap), a1 = lds_tr(ap + 4 * PA);
                     if constexpr (TAPS == 9) {
                         const uint2 a2 = lds_tr(ap + 8 * PA);
@@ -391,7 +415,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int C
 // do nothing but transpose reads + MFMAs; waves 4-7 fill the OTHER LDS buffer with the next tile (BN affine + activation of
 // `a`, the dz operand(s)) and keep the tile after that in flight.  The single-role kernel runs fill and MFMAs back to back
 // at one wave per SIMD (SQ counters: 47% of the wave cycles issuing, 20% issue-stalled: profiles/r02_sq_counters.txt).
-// LDS tiles are 4 rows x 32 pixels (half of the single-role kernel's) so that two buffers fit: 2 x 48 KB.
+// LDS tiles are 4 rows x 32 pixels (half of the single-role kernel's) so that two buffers fit: 2 x 47 KB.
 // XP: timing experiments of the debug build, compile-time so that they do not change the code around them (RD_WGWS_EXP; wrong results
 // when set): 1 no MFMA phase, 4 loader does not transform / write LDS
 #ifdef RD_DEBUG_SWITCHES
@@ -412,9 +436,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
     constexpr int S = 8, TAPS = 9;
     constexpr int THW = 4;
     constexpr int PH = THW + 2, PW = TW + 2, NPIX = PH * PW;
-    constexpr int CA = 64, CZ = 64, PA = 144, PZ = 144;
+    constexpr int CA = 64, CZ = 64, PA = tr_pitch(64), PZ = tr_pitch(64);
     constexpr int NSA = CA / S, NSZ = CZ / S;
-    constexpr int NITA = (NPIX * NSA + 255) / 256, NITZ = (THW * TW * NSZ) / 256;
+    // XP & 8 (timing build): five `a` items per thread instead of seven = what an LDS row ring per vertical strip would leave (only the
+    // four new halo rows per tile)
+    constexpr int NITA = (XP & 8) ? 5 : (NPIX * NSA + 255) / 256, NITZ = (THW * TW * NSZ) / 256;
     // each buffer ends in a 4 KB dummy record (16 bytes per loader thread): items of dead lanes (channel slots beyond Cin / Cout, the
     // last item's pixels beyond the tile) are written THERE, so that the loader's fill has no divergent branch per item
     constexpr int A_BYTES = (NPIX + 4) * PA, Z_BYTES = THW * TW * PZ, DUMMY = 256 * 16, BUF = A_BYTES + Z_BYTES + DUMMY;
@@ -480,14 +506,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             const int pix = tid / NSA + (256 / NSA) * b, py = pix / PW, px = pix - py * PW;
             iga.py[b] = (short)py;
             iga.px[b] = (short)px;
-            iga.lds[b] = (pix < NPIX && live_a) ? pix * PA + sla * 16 : A_BYTES + Z_BYTES + tid * 16;     // (relative to s_a)
+            iga.lds[b] = (pix < NPIX && live_a) ? tr_off<CA>(pix, sla) : A_BYTES + Z_BYTES + tid * 16;     // (relative to s_a)
         }
 #pragma unroll
         for (int b = 0; b < NITZ; ++b) {
             const int pix = tid / NSZ + (256 / NSZ) * b;
             igz.py[b] = (short)(pix / TW);
             igz.px[b] = (short)(pix % TW);
-            igz.lds[b] = live_z ? pix * PZ + slz * 16 : Z_BYTES + tid * 16;                                // (relative to s_z)
+            igz.lds[b] = live_z ? tr_off<CZ>(pix, slz) : Z_BYTES + tid * 16;                               // (relative to s_z)
         }
         // TWO register sets: the tiles after the next are in flight while the next one is transformed.  (With one set the
         // request went out right before the barrier and was consumed right behind it: as the loader is the slower role the
@@ -583,8 +609,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // fragment addressing: 16-lane group gq = lane >> 4 -> 16-channel sub-block (gq & 1), K half (gq >> 1)
     const int i16 = lane & 15, gq = lane >> 4;
-    const int zoff = ((gq >> 1) * 8 + (i16 >> 2)) * PZ + (mb * 32 + (gq & 1) * 16 + (i16 & 3) * 4) * 2;
-    const int aoff = ((gq >> 1) * 8 + (i16 >> 2)) * PA + (nb * 32 + (gq & 1) * 16 + (i16 & 3) * 4) * 2;
+    const int pix0 = (gq >> 1) * 8 + (i16 >> 2), sub = ((gq & 1) * 16 + (i16 & 3) * 4) * 2;
+    const int zoff = tr_frag<CZ>(pix0, mb, sub, 0);
+    static_assert(PW % 4 == 2, "halo rows of odd index flip the half swizzle (tr_frag)");
+    const int aoff_r[2] = {tr_frag<CA>(pix0, nb, sub, 0), tr_frag<CA>(pix0, nb, sub, 1)};
     int it = 0;
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
         WG_T(0, it, 0);
@@ -610,7 +638,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
         for (int r = 0; r < THW + 2; ++r) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const char* ap = s_a + aoff + (r * PW + ks * 16) * PA;                 // halo coords: input row = output row + kernel row
+                const char* ap = s_a + aoff_r[r & 1] + (r * PW + ks * 16) * PA;       // halo coords: input row = output row + kernel row
                 const uint2 a0 = lds_tr(ap), a1 = lds_tr(ap + 4 * PA), a2 = lds_tr(ap + 8 * PA);
                 const uint4 dq = make_uint4(a0.x, a0.y, a1.x, a1.y);
                 const uint4 m1 = make_uint4(__builtin_amdgcn_alignbit(a0.y, a0.x, 16), __builtin_amdgcn_alignbit(a1.x, a0.y, 16),
@@ -936,7 +964,7 @@ template <int TAPS, int MB, int NB>
 int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
-    size_t lds = (size_t)(PH * PW + 4) * (NB * 64 + (NB == 1 ? 32 : 16)) + (size_t)TH * TW * (MB * 64 + (MB == 1 ? 32 : 16));
+    size_t lds = (size_t)(PH * PW + 4) * tr_pitch(NB * 32) + (size_t)TH * TW * tr_pitch(MB * 32);
     const size_t lds_red = (size_t)(4 / (MB * NB) - 1) * (MB * NB) * 16 * 64 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
     dim3 grid(g.gx, g.CoutPadW / (MB * 32), g.CinPadW / (NB * 32));
@@ -954,7 +982,7 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
         // 64 x 64 blocks, plain sources: the warp-specialised kernel (4-row LDS tiles: twice the tile count)
         static const int ws = rd_switch("RD_WG_WS", 1);
         if (ws && wgrad_pf_ok(p)) {
-            const int ws_lds = 2 * ((6 * PW + 4) * 144 + 4 * TW * 144 + 256 * 16) + p.G * 2 * 3 * 64 * (int)sizeof(float);
+            const int ws_lds = 2 * ((6 * PW + 4) * tr_pitch(64) + 4 * TW * tr_pitch(64) + 256 * 16) + p.G * 2 * 3 * 64 * (int)sizeof(float);
             const int tiles_ws = p.N * ((p.H + 3) / 4) * ((p.W + TW - 1) / TW);
 #define RD_WGWS_LAUNCH(NQZ, XP) do { \
                 static int attr_lds = 0; \
@@ -966,6 +994,8 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
                 return (int)hipGetLastError(); \
             } while (0)
 #ifdef RD_DEBUG_SWITCHES
+            if (p.dz.mode == RD_SRC_BNBWD && rd_switch("RD_WGWS_EXP", 0) == 8) RD_WGWS_LAUNCH(2, 8);
+            if (p.dz.mode == RD_SRC_BNBWD && rd_switch("RD_WGWS_EXP", 0) == 9) RD_WGWS_LAUNCH(2, 1);
             if (p.dz.mode != RD_SRC_BNBWD) {
                 switch (rd_switch("RD_WGWS_EXP", 0)) {
                 case 1: RD_WGWS_LAUNCH(1, 1);
