@@ -295,8 +295,6 @@ class Plan:
         self.side_cus = 0               # >0: compute-unit budget of the weight-gradient launches (they run on a side stream)
         self.conv_cus = 0               # >0: compute-unit budget of this plan's persistent conv launches (a side-lane plan)
         self.dgrad_cus = 0              # >0: ... of its >= 64-channel gradient launches only (tuning.py dgrad_cus)
-        self.enc_budget = {}            # {'side': n, 'dgrad': n}: other budgets for the ENCODER's launches (they run when the restoration
-                                        # lane has finished: two lanes instead of three)
         self.materialize_min_c = None   # channels from which BN+ReLU outputs are stored once (rd_bn_apply)
         self.materialize_dz_min_c = None  # ... and from which the BN-backward gradients dz are
         self.materialize_dz_wide = bool(T.options()['mat_dz_wide'])
@@ -549,7 +547,7 @@ class Plan:
             wg.G, wg.gstart = self.G, self.gs_arr
             wg.dW = self.bank.g(node.mname, node.name + '.weight').data_ptr()
             wg.beta = 0.0
-            wg.cu_limit = int(self.enc_budget.get('side', self.side_cus) if node.mname == 'enc' else self.side_cus)
+            wg.cu_limit = int(self.side_cus)
             self.keep.append(wg)
             node.wg = wg
             # algorithmic work of the weight gradient (SURVEY.md 8d convention): the conv's logical input read once + the
@@ -588,7 +586,7 @@ class Plan:
                 p = L.RdConv()
                 p.cu_limit = int(self.conv_cus)
                 if not p.cu_limit and self.dgrad_cus and (node.Cin > 32 or node.Cout > 32):
-                    p.cu_limit = int(self.enc_budget.get('dgrad', self.dgrad_cus) if node.mname == 'enc' else self.dgrad_cus)
+                    p.cu_limit = int(self.dgrad_cus)
                 p.src[0] = self._dz_src(node)
                 p.nsrc, p.taps = 1, node.taps
                 p.w = wpack.ptr(node.mname, node.name, True)

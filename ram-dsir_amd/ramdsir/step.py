@@ -44,8 +44,6 @@ class TrainStep:
         budget = bool(opt['fork']) and dtype == torch.bfloat16
         self.seg.side_cus = T.cu_budget(opt['side_cus'], dev) if budget else 0
         self.seg.dgrad_cus = int(opt['dgrad_cus']) if budget else 0
-        if budget:
-            self.seg.enc_budget = {k: int(opt[o]) for k, o in (('side', 'side_cus_enc'), ('dgrad', 'dgrad_cus_enc')) if opt[o] >= 0}
         self.seg.materialize_min_c = opt['mat_min_c'] if opt['mat_min_c'] > 0 else None
         self.seg.materialize_dz_min_c = opt['mat_dz_min_c'] if opt['mat_dz_min_c'] > 0 else None
         self.seg.materialize_dz_wide = bool(opt['mat_dz_wide'])
@@ -61,7 +59,7 @@ class TrainStep:
         self.rec.materialize_pool = self.seg.materialize_pool
         self.rec.fused_bwd = self.seg.fused_bwd
         lane = bool(budget and opt['rec_lane'])
-        self.rec.side_cus = (T.cu_budget(opt['rec_cus'], dev) if opt['rec_wgrad_cus'] < 0 else int(opt['rec_wgrad_cus'])) if lane else 0    # its weight gradients run on its own lane
+        self.rec.side_cus = T.cu_budget(opt['rec_cus'], dev) if lane else 0    # its weight gradients run inline on its own lane
         self.rec.conv_cus = T.cu_budget(opt['rec_cus'], dev) if lane else 0
         self.rec.materialize_min_c = self.seg.materialize_min_c
         self.rec.materialize_dz_min_c = self.seg.materialize_dz_min_c

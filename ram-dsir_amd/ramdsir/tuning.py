@@ -26,9 +26,6 @@ DEFAULTS = dict(
                           # 0: all, -1: half of the device); its persistent workgroups cannot share a CU with the chain's kernels.
                           # Round-4 sweep with the gradient chain on conv_ws_kernel<2> at dgrad_cus=160 (160 + 96 = the device):
                           # 64: 4.29, 80: 4.23, 96: 4.23 / 4.20, 112: 4.36, 128: 4.36 ms/step; the HBM-bound 16-channel launches keep the whole GPU
-    side_cus_enc=-1,      # >= 0: another weight-gradient budget for the ENCODER's layers (the restoration lane has finished by then); -1: side_cus
-    dgrad_cus_enc=-1,     # >= 0: another budget for the encoder's >= 64-channel gradient launches; -1: dgrad_cus
-    rec_wgrad_cus=-1,     # >= 0: budget of the restoration lane's stand-alone weight gradients (they run late, beside the encoder backward); -1: rec_cus
     fork=True,            # eager launch over main / side / rec streams (False: one stream)
     rec_lane=True,        # the restoration decoder branch on its own stream
     rec_wgrad_late=True,  # its stand-alone weight gradients behind the join with the main lane instead of inside its dgrad chain
