@@ -54,6 +54,11 @@ typedef struct {
     const float* scale;  /* [G][C]  (BNBWD: P)                                            */
     const float* shift;  /* [G][C]  (BNBWD: R)                                            */
     const float* q;      /* [G][C]  BNBWD only                                            */
+    void* out;           /* NULL, or a tensor of ptr's shape: the launch also WRITES the values it stages from this source --
+                          * act(scale x + shift), or dz = P g + Q z + R -- there (storage dtype), every pixel once.  Honoured by
+                          * the launches for which rd_conv_honours_src_out() returns 1, ignored by all others.  The weight
+                          * gradient of the same layer then reads stored operands (RD_SRC_RAW) instead of repeating the
+                          * transform in its loader, which is what bounds it                          */
     int32_t mode;
     int32_t C;
     float slope;         /* 0 = ReLU, 0.01 = LeakyReLU (unet.py:47-50)                    */
@@ -111,6 +116,8 @@ typedef struct {
 } rd_conv_t;
 
 int rd_conv(const rd_conv_t* p, int dtype, void* stream);
+/* 1 if rd_conv(p, dtype) will write the src[i].out tensors it is given (a pure function of the descriptor and the device) */
+int rd_conv_honours_src_out(const rd_conv_t* p, int dtype);
 
 /* rd_wgrad: replaces cudnn's wgrad for the same convs.  partial is a caller workspace of
  * rd_wgrad_workspace() bytes; the result is accumulated (beta=1) or stored (beta=0) into dW, fp32

@@ -123,6 +123,14 @@ int rd_conv(const rd_conv_t* p, int dtype, void* stream) {
     return rd_conv_big_dispatch(*p, dtype, st);
 }
 
+int rd_conv_honours_src_out(const rd_conv_t* p, int dtype) {
+    if (!p || (p->taps != 9 && p->taps != 1) || p->G < 1 || p->G > RD_MAX_GROUPS || p->nsrc < 1 || p->nsrc > 2) return 0;
+    const int ck = dtype == RD_BF16 ? 32 : 16;
+    if (p->CinPad % ck || p->CoutPad % 32 || p->CinPad < p->Cin || p->CoutPad < p->Cout || p->w_tap_rows) return 0;
+    if (p->CinPad == ck && p->CoutPad == 32) return 0;           // the small-channel kernels
+    return rd_conv_big_takes_ws(*p, dtype) ? 1 : 0;
+}
+
 int64_t rd_wgrad_workspace(const rd_wgrad_t* p, int dtype) {
     return rd_wgrad_ws_bytes(*p, dtype);
 }

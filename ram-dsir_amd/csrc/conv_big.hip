@@ -148,14 +148,22 @@ int launch_conv(const rd_conv_t& p, hipStream_t st) {
 
 }  // namespace
 
-int rd_conv_big_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
+static bool conv_big_nb2(const rd_conv_t& p, int dtype) {
     bool nb2 = (p.CoutPad % 64) == 0;
-    {
-        // small grids (the 25x25 / 50x50 levels): 32-channel tiles double the number of workgroups
-        static const int nb1_below = rd_switch("RD_CONV_NB1_BELOW", 300);
-        const int wgs64 = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / 64);
-        if (nb2 && dtype == RD_BF16 && wgs64 < nb1_below) nb2 = false;
-    }
+    // small grids (the 25x25 / 50x50 levels): 32-channel tiles double the number of workgroups
+    static const int nb1_below = rd_switch("RD_CONV_NB1_BELOW", 300);
+    const int wgs64 = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / 64);
+    if (nb2 && dtype == RD_BF16 && wgs64 < nb1_below) nb2 = false;
+    return nb2;
+}
+
+bool rd_conv_big_takes_ws(const rd_conv_t& p, int dtype) {
+    static const bool pp_off = rd_switch("RD_CONV_PP_OFF", 0) != 0;
+    return dtype == RD_BF16 && p.taps == 9 && conv_big_nb2(p, dtype) && !pp_off && rd_conv_ws_takes(p);
+}
+
+int rd_conv_big_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
+    const bool nb2 = conv_big_nb2(p, dtype);
     if (dtype == RD_BF16) {
         if (p.taps == 9) return nb2 ? launch_conv<bf16_t, 9, 2>(p, st) : launch_conv<bf16_t, 9, 1>(p, st);
         return nb2 ? launch_conv<bf16_t, 1, 2>(p, st) : launch_conv<bf16_t, 1, 1>(p, st);

@@ -209,6 +209,7 @@ __device__ __forceinline__ rd_src_t select_src(const rd_src_t* src, int si) {
     s.scale = si ? src[1].scale : src[0].scale;
     s.shift = si ? src[1].shift : src[0].shift;
     s.q = si ? src[1].q : src[0].q;
+    s.out = si ? src[1].out : src[0].out;
     s.mode = si ? src[1].mode : src[0].mode;
     s.C = si ? src[1].C : src[0].C;
     s.slope = si ? src[1].slope : src[0].slope;

@@ -20,6 +20,8 @@ constexpr int RD_CONV_PP_NA = -1000;
 // forward kernel of the small-channel 3x3 convs with whole channel slots (conv_small_fwd.hip); RD_CONV_PP_NA when the launch does not qualify
 int rd_conv_small_fwd_dispatch(const rd_conv_t& p, int dtype, hipStream_t st);
 int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st);
+bool rd_conv_ws_takes(const rd_conv_t& p);           // conv_pp.hip: the launch runs on conv_ws_kernel (the kernel that writes rd_src_t.out)
+bool rd_conv_big_takes_ws(const rd_conv_t& p, int dtype);   // conv_big.hip: ... after conv_big's own routing (64-wide tiles, bf16, 3x3)
 
 // Register ("lean") epilogues: accumulators leave as 16-byte NHWC vectors straight from registers (MFMA roles swapped:
 // weights x pixels, v_permlane32_swap regroup) instead of through the LDS-staged epilogue of conv_epilogue.h.

@@ -55,7 +55,13 @@ __device__ __forceinline__ float4 ldf4g(const void* q) {
     const f32x4_t v = *(const __attribute__((address_space(1))) f32x4_t*)(uintptr_t)q;
     return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ void st16g(void* q, const uint4& u) {
+    u32x4_t v;
+    v.x = u.x; v.y = u.y; v.z = u.z; v.w = u.w;
+    *(__attribute__((address_space(1))) u32x4_t*)(uintptr_t)q = v;
+}
 #else
+__device__ __forceinline__ void st16g(void* q, const uint4& u) { *reinterpret_cast<uint4*>(q) = u; }
 __device__ __forceinline__ uint4 ld16g(const void* q) { return *reinterpret_cast<const uint4*>(q); }
 __device__ __forceinline__ float4 ldf4g(const void* q) { return *reinterpret_cast<const float4*>(q); }
 #endif
@@ -339,7 +345,8 @@ template <int TS> struct WsLds {
     static constexpr int TAB_BYTES = 16 * 1024;
     static constexpr int SLOTS = TAB + TAB_BYTES;
     static constexpr int SLOTS2 = SLOTS + PP_MAX_CHUNKS * 4 * 48;         // BWD2: second operand + Q row per (chunk, slot), 16 B each
-    static constexpr int LDS = SLOTS2 + PP_MAX_CHUNKS * 4 * 16;
+    static constexpr int SLOTS3 = SLOTS2 + PP_MAX_CHUNKS * 4 * 16;        // SOUT: where the transformed source is written as well, 8 B each
+    static constexpr int LDS = SLOTS3 + PP_MAX_CHUNKS * 4 * 8;
 };
 static_assert(WsLds<0>::LDS <= 160 * 1024 && WsLds<1>::LDS <= 160 * 1024, "conv_ws_kernel: LDS map exceeds the CU");
 #ifdef RD_DEBUG_SWITCHES
@@ -357,7 +364,13 @@ __device__ unsigned long long ws_trace[2][64][4];          // [role][step][event
 // BWD2 (MODE 2 only): the source is a BatchNorm-backward pair (g, z) and the loader forms dz = P g + Q z + R while it stages the tile
 // -- two loads and two fused multiply-adds per vector on waves that otherwise wait at the barrier for half of every tile -- instead of
 // reading a dz tensor that a separate rd_bn_apply launch stored (round 4: 15 elementwise launches and 0.86 GB of traffic per step)
-template <int MODE, int TS, bool BWD2 = false>
+// SOUT (rd_src_t.out): the loader waves also WRITE what they stage -- act(bn(z)) of a forward launch, dz of a gradient launch -- to a
+// tensor of the source's shape, interior pixels of every tile once (first output-channel block only): the weight gradient of the same
+// layer then reads both of its operands as stored tensors and its loader, which is that kernel's pole, only copies (wgrad.hip).  The
+// stores are unconditional (items outside the tile interior / the image, sources without an `out`: a per-lane trash record) so that
+// the loader's vector-memory operations stay countable.
+__device__ uint4 ws_trash[256];
+template <int MODE, int TS, bool BWD2 = false, bool SOUT = false>
 __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int tiles_total) {
     typedef bf16_t T;
     constexpr int S = 8;
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     // this kernel's own LDS map (WsLds<TS>): the planes hold the halo tile at the conflict-free row pitch of its shape
     typedef WsLds<TS> LM;
     constexpr int PLt = LM::PL, WS_PLANE_A = LM::PLANE_A, WS_IN_BYTES = LM::IN_BYTES, WS_W0 = LM::W0, WS_TAB = LM::TAB, WS_SLOTS = LM::SLOTS;
-    constexpr int WS_SLOTS2 = LM::SLOTS2;
+    constexpr int WS_SLOTS2 = LM::SLOTS2, WS_SLOTS3 = LM::SLOTS3;
     // who stages the weight chunk of the next step: the MFMA waves in the forward mode (they have ~1.5 issue slots per MFMA
     // gap to spare and 36 registers of headroom; the loader's nine weight vectors cost 1000-3000 cycles per step on top of
     // its ~3000 for the halo items against ~3300 of MFMAs: traces in profiles/r02_ws_trace.txt), the loader waves in the
@@ -428,6 +441,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             e2.q = bwd ? sd.q + cc : nullptr;
             *reinterpret_cast<decltype(e2)*>(smem + WS_SLOTS2 + t * 16) = e2;
         }
+        if constexpr (SOUT) *reinterpret_cast<T**>(smem + WS_SLOTS3 + t * 8) = (live && sd.out) ? reinterpret_cast<T*>(sd.out) + cc : nullptr;
     }
     {
         float* tab = reinterpret_cast<float*>(smem + WS_TAB);
@@ -473,6 +487,18 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         int ldC = 0;
         int offL[PP_NIT];                    // stage L's tile: pixel index (clamped into the image) of each halo item
         int inL = 0, inC = 0;                // bit b: halo item b lies inside the image (and this slot carries a channel)
+        // SOUT: stage C's pixel indices / channel stride / destination, and which of this thread's items are tile-interior pixels
+        int offC[SOUT ? PP_NIT : 1] = {};
+        int stCs = 0, intr = 0;
+        T* stL = nullptr;
+        T* stC = nullptr;
+        if constexpr (SOUT) {
+#pragma unroll
+            for (int b = 0; b < PP_NIT; ++b) {
+                const int py = it_yx[b] >> 16, px = it_yx[b] & 0xffff;
+                intr |= (py >= 1 && py <= THt && px >= 1 && px <= TWt) ? (1 << b) : 0;
+            }
+        }
         PpStage L, Cs;
         L.tile = tile_begin;
         L.c = 0;
@@ -506,6 +532,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
 #pragma unroll
                 for (int e3 = 0; e3 < S; ++e3) qL[e3] = hasq ? qL[e3] : 0.f;
                 copyL = copyL && !hasq;
+            }
+            if constexpr (SOUT) {
+                T* o = *reinterpret_cast<T* const*>(smem + WS_SLOTS3 + (L.c * 4 + sw) * 8);
+                stL = (o != nullptr && L.n0 == 0) ? o + (size_t)(L.n + e.n_off) * H * W * e.C : nullptr;
             }
             const int g = e.g_fixed >= 0 ? e.g_fixed : L.g;
             const float* sp = e.scale + (rawm ? 0 : g * e.C);
@@ -548,6 +578,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             }
             const bool in = ((maskC >> b) & 1) != 0;
             *reinterpret_cast<uint4*>(smem + par * WS_IN_BYTES + it_lds[b]) = in ? u : make_uint4(0, 0, 0, 0);
+            if constexpr (SOUT) {
+                const bool st = in && ((intr >> b) & 1) != 0 && stC != nullptr;
+                T* dp = st ? stC + (size_t)(unsigned)offC[b] * (unsigned)stCs : reinterpret_cast<T*>(ws_trash + tid);
+                st16g(dp, u);
+            }
         };
         auto consume_w = [&](int t, int par) {
             *reinterpret_cast<uint4*>(smem + par * PP_W_BYTES + w_lds + t * (PP_NT * 16)) = wr[t];
@@ -562,6 +597,12 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             if constexpr (BWD2) {
 #pragma unroll
                 for (int e = 0; e < S; ++e) qC[e] = qL[e];
+            }
+            if constexpr (SOUT) {
+                stC = stL;
+                stCs = ldC;
+#pragma unroll
+                for (int b = 0; b < PP_NIT; ++b) offC[b] = offL[b];
             }
             const int tile0 = L.tile;
             pp_advance(L, q, gm);
@@ -929,6 +970,22 @@ extern "C" int rd_debug_ws_trace(unsigned long long* out) {             // debug
 }
 #endif
 
+// does this launch run on conv_ws_kernel?  ONE definition for the dispatch below and for rd_conv_honours_src_out (conv_api.hip), which
+// tells the host whether a launch will write rd_src_t.out (only this kernel does)
+bool rd_conv_ws_takes(const rd_conv_t& p) {
+    const int skind = pp_sources_kind(p);
+    if (p.taps != 9 || p.CoutPad % PP_NT || p.CinPad > 32 * PP_MAX_CHUNKS || !skind) return false;
+    static const int ws = rd_switch("RD_CONV_WS", 3), ws_min2 = rd_switch("RD_CONV_WS_MIN2", 0);
+    const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / PP_NT);
+    const int mode = rd_conv_lean_mode(p, PP_NT);
+    const size_t tab = (size_t)(mode == 1 ? 1 : 2 * p.G) * p.CoutPad * sizeof(float);
+    bool accumulates = false;                                  // gradient launches that add to an existing gradient stay with conv_pf_kernel
+    if (mode == 2)
+        for (int i = 0; i < 2; ++i) accumulates = accumulates || (p.dst[i].kind != RD_DST_NONE && p.dst[i].accumulate);
+    if (skind == 2 && mode != 2) return false;
+    return mode && (ws & mode) && (mode == 1 || (tiles >= ws_min2 && !accumulates)) && tab <= (size_t)WsLds<0>::TAB_BYTES;
+}
+
 int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     const int skind = pp_sources_kind(p);
     if (p.taps != 9 || p.CoutPad % PP_NT || p.CinPad > 32 * PP_MAX_CHUNKS || !skind) return RD_CONV_PP_NA;
@@ -942,6 +999,10 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<1>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<0>::LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<1>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<0>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<1, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<1>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<0>::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<2, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WsLds<1>::LDS);
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.N * (p.CoutPad / PP_NT);
     const int cus = (p.cu_limit > 0 && p.cu_limit < n_cu) ? p.cu_limit : n_cu;     // a side lane's budget (ramdsir.h)
@@ -968,9 +1029,9 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     bool accumulates = false;                                  // gradient launches that add to an existing gradient stay with conv_pf_kernel
     if (mode == 2)
         for (int i = 0; i < 2; ++i) accumulates = accumulates || (p.dst[i].kind != RD_DST_NONE && p.dst[i].accumulate);
-    if (skind == 2 && !(mode == 2 && (ws & 2) && tiles >= ws_min2 && !accumulates && tab <= (size_t)WsLds<0>::TAB_BYTES))
-        return RD_CONV_PP_NA;                                  // a two-operand source runs on conv_ws_kernel<2, *, true> or not here at all
-    if (mode && (ws & mode) && (mode == 1 || (tiles >= ws_min2 && !accumulates)) && tab <= (size_t)WsLds<0>::TAB_BYTES) {
+    const bool takes = rd_conv_ws_takes(p);
+    if (skind == 2 && !takes) return RD_CONV_PP_NA;            // a two-operand source runs on conv_ws_kernel<2, *, true> or not here at all
+    if (takes) {
         // debug build only: RD_CONV_WS_EXP = timing experiments (-DRD_WS_EXP), RD_CONV_WS_TRACE_MIN = launches with at least
         // that many tiles record the s_memtime trace (scripts/ws_trace.py); both ride in the high bits of the tile count
         static const int ws_exp = rd_switch("RD_CONV_WS_EXP", 0), ws_trace_min = rd_switch("RD_CONV_WS_TRACE_MIN", 1 << 30);
@@ -983,9 +1044,17 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         const bool flat = ws_flat && tiles1 * 1.04 < tiles;
         const int nt = flat ? tiles1 : tiles, grid_ws = nt < cus ? nt : cus;
         const int arg = nt | (ws_exp << 26) | (tiles >= ws_trace_min ? 1 << 25 : 0);
-        if (mode == 1) {
+        bool sout = false;                                     // a source asks for its staged values to be stored as well (ramdsir.h)
+        for (int i = 0; i < p.nsrc; ++i) sout = sout || p.src[i].out != nullptr;
+        if (mode == 1 && sout) {
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1, false, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
+            else hipLaunchKernelGGL((conv_ws_kernel<1, 0, false, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
+        } else if (mode == 1) {
             if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
             else hipLaunchKernelGGL((conv_ws_kernel<1, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
+        } else if (skind == 2 && sout) {
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1, true, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
+            else hipLaunchKernelGGL((conv_ws_kernel<2, 0, true, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
         } else if (skind == 2) {
             if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
             else hipLaunchKernelGGL((conv_ws_kernel<2, 0, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);

@@ -533,6 +533,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             pfu_issue_pre<T, NITZ>(rz, psz, igz, offz, n, H, W, y0, x0, ghost, border);
         };
         const bool z_raw = p.dz.mode == RD_SRC_RAW;             // a stored dz / dlogits: copied, not transformed
+        const bool a_raw = p.a[0].mode == RD_SRC_RAW && (p.na == 1 || p.a[1].mode == RD_SRC_RAW);
         int g_ctx = -1;
         const int stride = gridDim.x;
         auto fill = [&](uint4 (&ra)[NITA][1], uint4 (&rz)[NITZ][NQZ], int tile, int it) {
@@ -561,8 +562,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             char* s_a = smem + (it & 1) * BUF;
             char* s_z = s_a + A_BYTES;
             if constexpr (!(XP & 4)) {
-                pfu_consume<T, NITA, 1, true>(ra, psa, iga, H, W, y0 - 1, x0 - 1,
-                                        [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
+                if (a_raw)             // stored operand (rd_src_t.out of the forward launch): copied, like a stored dz
+                    pfu_consume<T, NITA, 1, true, 2>(ra, psa, iga, H, W, y0 - 1, x0 - 1,
+                                                     [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
+                else
+                    pfu_consume<T, NITA, 1, true>(ra, psa, iga, H, W, y0 - 1, x0 - 1,
+                                                  [&](int l, const uint4& u) { *reinterpret_cast<uint4*>(s_a + l) = u; });
                 if (z_raw && NQZ == 1) {
 #pragma unroll
                     for (int b = 0; b < NITZ; ++b) {
@@ -996,6 +1001,8 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
 #ifdef RD_DEBUG_SWITCHES
             if (p.dz.mode == RD_SRC_BNBWD && rd_switch("RD_WGWS_EXP", 0) == 8) RD_WGWS_LAUNCH(2, 8);
             if (p.dz.mode == RD_SRC_BNBWD && rd_switch("RD_WGWS_EXP", 0) == 9) RD_WGWS_LAUNCH(2, 1);
+            if (p.dz.mode == RD_SRC_BNBWD && rd_switch("RD_WGWS_EXP", 0) == 4) RD_WGWS_LAUNCH(1, 4);     // one operand, no transform: "both operands stored"
+
             if (p.dz.mode != RD_SRC_BNBWD) {
                 switch (rd_switch("RD_WGWS_EXP", 0)) {
                 case 1: RD_WGWS_LAUNCH(1, 1);

@@ -18,7 +18,7 @@ vp, fp, i32, i64, f32 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
 class RdSrc(C.Structure):
-    _fields_ = [('ptr', vp), ('ptr2', vp), ('scale', fp), ('shift', fp), ('q', fp), ('mode', i32), ('C', i32),
+    _fields_ = [('ptr', vp), ('ptr2', vp), ('scale', fp), ('shift', fp), ('q', fp), ('out', vp), ('mode', i32), ('C', i32),
                 ('slope', f32), ('n_off', i32), ('g_fixed', i32), ('pad_', i32)]
 
 
@@ -101,6 +101,7 @@ _SIGS = {
     'rd_conv': (C.c_int, [C.POINTER(RdConv), C.c_int, vp]),
     'rd_wgrad_workspace': (i64, [C.POINTER(RdWgrad), C.c_int]),
     'rd_wgrad': (C.c_int, [C.POINTER(RdWgrad), C.c_int, vp]),
+    'rd_conv_honours_src_out': (C.c_int, [C.POINTER(RdConv), C.c_int]),
     'rd_conv_bwd_fused_ok': (C.c_int, [C.POINTER(RdConv), C.POINTER(RdWgrad), C.c_int]),
     'rd_conv_bwd_fused_workspace': (i64, [C.POINTER(RdConv), C.POINTER(RdWgrad), C.c_int]),
     'rd_conv_bwd_fused': (C.c_int, [C.POINTER(RdConv), C.POINTER(RdWgrad), C.c_int, vp]),

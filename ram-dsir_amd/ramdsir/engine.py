@@ -299,6 +299,11 @@ class Plan:
         self.materialize_dz_min_c = None  # ... and from which the BN-backward gradients dz are
         self.materialize_dz_wide = bool(T.options()['mat_dz_wide'])
         self.fused_bwd = bool(T.options()['fused_bwd'])   # small-channel 3x3 convs: dgrad + weight gradient in one launch
+        # True: a conv launch that runs on the warp-specialised 64-wide kernel also STORES what its loader waves stage (rd_src_t.out:
+        # act(bn(z)) in the forward launch, dz in the gradient launch), and the layer's weight gradient reads those stored operands
+        # (RD_SRC_RAW: its loader copies instead of repeating the transforms, and the loader is that kernel's pole)
+        self.store_operands = int(T.options()['store_wgrad_operands'])     # bit 0: the forward operand, bit 1: dz
+        self.store_min_c = int(T.options()['store_wgrad_min_c'])           # ... of tensors with at least this many channels only
         self.split_wide_dgrad = bool(T.options()['split_wide_dgrad'])   # _dgrad_halves below
         self._unit = {}
         self.nodes = []
@@ -453,6 +458,14 @@ class Plan:
             p.G, p.gstart = self.G, self.gs_arr
             p.emode, p.out = 0, o.buf.data_ptr()
             p.stats = o.plan.stat_ptr(o.stats) if (o.norm is not None and not o.up) else None
+            node.a_store = [None] * len(node.inputs)
+            if ((self.store_operands & 1) and self.training and self.dtype == torch.bfloat16 and node.taps == 9 and node.Cin >= self.store_min_c
+                    and lib.rd_conv_honours_src_out(C.byref(p), dt)):
+                for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
+                    if p.src[i].mode in (L.SRC_AFF, L.SRC_AFFACT):
+                        src_t = a.y_buf if (mode == L.SRC_UP and a.y_buf is not None) else a.buf
+                        node.a_store[i] = self.alloc_act(tuple(src_t.shape))
+                        p.src[i].out = node.a_store[i].data_ptr()
             self.keep.append(p)
             self.fwd.append((lib.rd_conv, (C.byref(p), dt), self._conv_meta(node, N, H, W, node.Cin, node.Cout, 'fwd')))
             if o.norm is not None:
@@ -541,6 +554,8 @@ class Plan:
             wg = L.RdWgrad()
             for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
                 wg.a[i] = self._src(a, mode, n_off, g_fixed)
+                if getattr(node, 'a_store', None) and node.a_store[i] is not None:      # stored by the forward launch (rd_src_t.out)
+                    wg.a[i].ptr, wg.a[i].mode, wg.a[i].scale, wg.a[i].shift = node.a_store[i].data_ptr(), L.SRC_RAW, None, None
             wg.na, wg.taps = len(node.inputs), node.taps
             wg.dz = self._dz_src(node)
             wg.N, wg.H, wg.W, wg.Cin, wg.Cout = N, H, W, node.Cin, node.Cout
@@ -605,6 +620,7 @@ class Plan:
                 self.keep.append(p)
             dmeta = self._conv_meta(node, N, H, W, node.Cout, node.Cin, 'dgrad') if p is not None else None
             node.fused = bool(p is not None and self.fused_bwd and lib.rd_conv_bwd_fused_ok(C.byref(p), C.byref(wg), dt))
+            dgrad_first = False
             if node.fused:
                 # small-channel 3x3 conv: dgrad + weight gradient in ONE launch on the dgrad chain (csrc/conv_fused.hip: both are
                 # HBM-bound and read the same tensors); its per-workgroup dW sums are reduced on the weight-gradient lane, from a
@@ -616,6 +632,15 @@ class Plan:
                 node.side_meta = [dict(kernel='wgrad_reduce', side=True, side_idx=0, layer='%s.%s' % (node.mname, node.name))]
                 self.bwd.append((lib.rd_conv_bwd_fused_reduce, (C.byref(p), C.byref(wg), dt), node.side_meta[0]))
             else:
+                # the gradient launch stores the dz its loader forms (rd_src_t.out) and the weight gradient, enqueued BEHIND it, reads that
+                dgrad_first = bool(p is not None and (self.store_operands & 2) and self.dtype == torch.bfloat16 and p.src[0].mode == L.SRC_BNBWD and node.Cout >= self.store_min_c
+                                   and not self.split_wide_dgrad and lib.rd_conv_honours_src_out(C.byref(p), dt))
+                if dgrad_first:
+                    o.dz_store = self.alloc_act((N, H, W, o.C))
+                    p.src[0].out = o.dz_store.data_ptr()
+                    wg.dz.ptr, wg.dz.ptr2, wg.dz.mode = o.dz_store.data_ptr(), None, L.SRC_RAW
+                    wg.dz.scale = wg.dz.shift = wg.dz.q = None
+                    self.bwd.append((lib.rd_conv, (C.byref(p), dt), dmeta))
                 ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
                 node.side_meta = [dict(kernel='wgrad', side=True, side_idx=0, layer='%s.%s' % (node.mname, node.name), bytes=wg_bytes, flops=wg_flops)]
                 self.bwd.append((lib.rd_wgrad, (C.byref(wg), dt), node.side_meta[0]))
@@ -624,7 +649,7 @@ class Plan:
                 node.side_meta.append(dict(kernel='colsum', side=True, side_idx=0))
                 self.bwd.append((lib.rd_colsum, (o.grad_buf().data_ptr(), self.bank.g(node.mname, node.name + '.bias').data_ptr(),
                                                  node.bias_ws.data_ptr(), N * H * W, o.C, o.gCs, 0.0, dt), node.side_meta[-1]))
-            if p is not None and not node.fused:
+            if p is not None and not node.fused and not dgrad_first:
                 halves = self._dgrad_halves(p) if self.split_wide_dgrad else None
                 if halves is not None:
                     for q in halves:

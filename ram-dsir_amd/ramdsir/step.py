@@ -39,6 +39,8 @@ class TrainStep:
         self.seg.pad_narrow = self.seg.materialize_up = True
         self.seg.materialize_pool = bool(opt['pool_mat'])
         self.seg.fused_bwd = bool(opt['fused_bwd'])
+        self.seg.store_operands = int(opt['store_wgrad_operands'])
+        self.seg.store_min_c = int(opt['store_wgrad_min_c'])
         # lane budgets are tuned for the bf16 kernels (in fp32 the weight gradients are several times heavier and the side lane
         # itself becomes the critical path when it is narrowed: 315 -> 268 images/s)
         budget = bool(opt['fork']) and dtype == torch.bfloat16
@@ -58,6 +60,8 @@ class TrainStep:
         self.rec.pad_narrow = self.rec.materialize_up = True
         self.rec.materialize_pool = self.seg.materialize_pool
         self.rec.fused_bwd = self.seg.fused_bwd
+        self.rec.store_operands = self.seg.store_operands
+        self.rec.store_min_c = self.seg.store_min_c
         lane = bool(budget and opt['rec_lane'])
         self.rec.side_cus = T.cu_budget(opt['rec_cus'], dev) if lane else 0    # its weight gradients run inline on its own lane
         self.rec.conv_cus = T.cu_budget(opt['rec_cus'], dev) if lane else 0

@@ -26,6 +26,12 @@ DEFAULTS = dict(
                           # 0: all, -1: half of the device); its persistent workgroups cannot share a CU with the chain's kernels.
                           # Round-4 sweep with the gradient chain on conv_ws_kernel<2> at dgrad_cus=160 (160 + 96 = the device):
                           # 64: 4.29, 80: 4.23, 96: 4.23 / 4.20, 112: 4.36, 128: 4.36 ms/step; the HBM-bound 16-channel launches keep the whole GPU
+    store_wgrad_operands=0,      # bit 0 / bit 1: launches on conv_ws_kernel also store what their loaders stage (act(bn(z)) of the forward launch / dz of
+                          # the gradient launch: rd_src_t.out) and the layer's weight gradient copies stored operands instead of transforming.
+                          # MEASURED A LOSS in the step and therefore off: the >= 64-channel weight gradients get 25-30 % faster (lane 1.91 ->
+                          # 1.62 ms alone) but the stores cost the main lane's launches as much HBM time (64-wide convs 1.22 -> 1.39 ms alone):
+                          # 4.283 (>= 128 channels) / 4.358 (all) / 4.291 (forward operand only) against 4.269 ms/step without
+    store_wgrad_min_c=128,       # ... for operands of at least this many channels
     fork=True,            # eager launch over main / side / rec streams (False: one stream)
     rec_lane=True,        # the restoration decoder branch on its own stream
     rec_wgrad_late=True,  # its stand-alone weight gradients behind the join with the main lane instead of inside its dgrad chain
@@ -43,7 +49,7 @@ DEFAULTS = dict(
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
 )
 _ENV = dict(split_wide_dgrad='RD_SPLIT_WIDE_DGRAD', mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', mat_dz_wide='RD_MAT_DZ_WIDE', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
-            ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', launch_threads='RD_LAUNCH_THREADS', dgrad_cus='RD_DGRAD_CUS', rec_lane='RD_REC_LANE', rec_wgrad_late='RD_REC_WGRAD_LATE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
+            ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', store_wgrad_operands='RD_STORE_WGRAD_OPS', launch_threads='RD_LAUNCH_THREADS', dgrad_cus='RD_DGRAD_CUS', rec_lane='RD_REC_LANE', rec_wgrad_late='RD_REC_WGRAD_LATE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
 
 
 def options(over=None):

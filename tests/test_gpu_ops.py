@@ -270,6 +270,100 @@ def test_conv_bnbwd_loader_and_image_offsets(dtype):
     np.testing.assert_allclose(bst.sum(1)[1, :, 0].cpu(), y.grad.sum((0, 2, 3)), rtol=0, atol=(0.5 if dtype == 'bf16' else 5e-3))
 
 
+def _assert_bf16_rounding_of(got, ref, terms, what):
+    """got == round-to-nearest-bf16(ref) up to the fp32 rounding of the expression: |got - ref| <= half a bf16 spacing at |ref| plus a
+    few fp32 ulps of the TERMS that were added (an fma chain against separate multiplies and adds; results that cancel to ~0)."""
+    m = torch.maximum(got.abs(), ref.abs()).clamp_min(1e-30)
+    tol = 0.5 * 2.0 ** (torch.floor(torch.log2(m)) - 7) * 1.001 + 4 * 2.0 ** -24 * terms
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), '%s: %d values off, worst %.3g' % (what, int(bad.sum()), float(((got - ref).abs() - tol).max()))
+
+
+@pytest.mark.parametrize('case', ['affact64', 'cat_aff64_affact64'])
+def test_conv_forward_also_stores_its_staged_sources(case):
+    """rd_src_t.out (ramdsir.h): a forward launch that runs on the warp-specialised 64-wide kernel also writes act(scale x + shift)
+    of every source that asks for it -- every pixel once, images and channels of the source's own layout -- and
+    rd_conv_honours_src_out() says so beforehand.  The conv result itself is unchanged.  (Geometry large enough for the product
+    library's routing: >= 300 workgroups of 64 output channels, ragged right and bottom tiles.)"""
+    gen = torch.Generator().manual_seed(5)
+    keep = U.Keep()
+    N, H, W, Cout, gstart, dtype = 8, 103, 95, 64, [0, 3, 8], 'bf16'
+    spec = [(L.SRC_AFFACT, 64, 0.0)] if case == 'affact64' else [(L.SRC_AFF, 64, 0.0), (L.SRC_AFFACT, 64, 0.01)]
+    srcs, virt, outs, terms = [], [], [], []
+    for mode, Cc, slope in spec:
+        x = U.rnd(torch.randn(N, Cc, H, W, generator=gen), dtype)
+        sc, sh = _params(2, Cc, gen)
+        terms.append((x * U.group_rows(sc, gstart, N)).abs() + U.group_rows(sh, gstart, N).abs())
+        src = U.make_src(keep, x, mode, dtype, sc, sh, slope)
+        outs.append(torch.full((N, H, W, Cc), float('nan'), dtype=torch.bfloat16, device=U.dev()))
+        src.out = outs[-1].data_ptr()
+        srcs.append(src)
+        virt.append(U.virtual_input(x, mode, sc, sh, slope, gstart))
+    a = torch.cat(virt, 1)
+    w = U.rnd(torch.randn(Cout, a.shape[1], 3, 3, generator=gen) / np.sqrt(a.shape[1] * 9), dtype)
+    bias = 0.1 * torch.randn(Cout, generator=gen)
+    p = _conv_desc(keep, srcs, w, bias, N, H, W, gstart, dtype, 9)
+    out = torch.full((N, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=U.dev())
+    p.emode, p.out, p.stats = 0, out.data_ptr(), None
+    if os.environ.get('RAMDSIR_DEBUG_LIB') == '1' and not L.lib().rd_conv_honours_src_out(C.byref(p), L.RD_BF16):
+        pytest.skip('forced dispatch routes this launch away from the kernel that stores its sources')
+    assert L.lib().rd_conv_honours_src_out(C.byref(p), L.RD_BF16) == 1
+    L.check(L.lib().rd_conv(C.byref(p), L.RD_BF16, None), case)
+    torch.cuda.synchronize()
+    U.assert_close(U.from_nhwc(out), F.conv2d(a, w, bias, padding=1), dtype, case)
+    for o, v, t in zip(outs, virt, terms):
+        got = U.from_nhwc(o)
+        assert torch.isfinite(got).all()                          # every pixel of every image was written
+        _assert_bf16_rounding_of(got, v, t, case)
+    # a launch that goes to another kernel (32 output channels) says so, and leaves `out` alone
+    w32 = U.rnd(torch.randn(32, a.shape[1], 3, 3, generator=gen) / 24, dtype)
+    q = _conv_desc(keep, srcs, w32, None, N, H, W, gstart, dtype, 9)
+    o32 = torch.zeros((N, H, W, 32), dtype=torch.bfloat16, device=U.dev())
+    q.emode, q.out, q.stats = 0, o32.data_ptr(), None
+    assert L.lib().rd_conv_honours_src_out(C.byref(q), L.RD_BF16) == 0
+
+
+def test_conv_gradient_also_stores_the_dz_it_forms():
+    """The gradient launch on a BatchNorm-backward pair (g, z) writes dz = P g + Q z + R to rd_src_t.out; the weight gradient of the
+    layer reads it as a stored operand (engine.Plan.store_operands)."""
+    gen = torch.Generator().manual_seed(12)
+    keep = U.Keep()
+    N, H, W, Cz, Ca, dtype = 7, 100, 104, 64, 64, 'bf16'
+    gstart = [0, 2, 7]
+    g = U.rnd(torch.randn(N, Cz, H, W, generator=gen), dtype)
+    z = U.rnd(torch.randn(N, Cz, H, W, generator=gen), dtype)
+    P, R = _params(2, Cz, gen)
+    Q = 0.1 * torch.randn(2, Cz, generator=gen)
+    dz = g * U.group_rows(P, gstart, N) + z * U.group_rows(Q, gstart, N) + U.group_rows(R, gstart, N)
+    w = U.rnd(torch.randn(Cz, Ca, 3, 3, generator=gen) / 24, dtype)
+    zprod = U.rnd(torch.randn(N, Ca, H, W, generator=gen), dtype)
+    sc, sh = _params(2, Ca, gen)
+    y = (zprod * U.group_rows(sc, gstart, N) + U.group_rows(sh, gstart, N)).requires_grad_(True)
+    (F.conv2d(F.relu(y), w, None, padding=1) * dz).sum().backward()
+    src = U.make_src(keep, g, L.SRC_BNBWD, dtype, scale=P, shift=R, ptr2=z, q=Q)
+    dz_out = torch.full((N, H, W, Cz), float('nan'), dtype=torch.bfloat16, device=U.dev())
+    src.out = dz_out.data_ptr()
+    p = _conv_desc(keep, [src], w, None, N, H, W, gstart, dtype, 9, transpose=True)
+    p.emode, p.c_split = 1, Ca
+    gbuf = torch.zeros((N, H, W, Ca), dtype=torch.bfloat16, device=U.dev())
+    bst = torch.zeros(2, L.STAT_SLOTS, Ca, 2, dtype=torch.float64, device=U.dev())
+    d = L.RdDst()
+    d.g, d.z = gbuf.data_ptr(), keep(U.nhwc(zprod, dtype)).data_ptr()
+    d.scale, d.shift = keep(U.fdev(sc)).data_ptr(), keep(U.fdev(sh)).data_ptr()
+    d.bstats, d.kind, d.act, d.accumulate, d.Cd, d.slope, d.n_off, d.g_fixed = bst.data_ptr(), L.DST_PLAIN, 1, 0, Ca, 0.0, 0, -1
+    p.dst[0] = d
+    p.dst[1].kind = L.DST_NONE
+    if os.environ.get('RAMDSIR_DEBUG_LIB') == '1' and not L.lib().rd_conv_honours_src_out(C.byref(p), L.RD_BF16):
+        pytest.skip('forced dispatch routes this launch away from the kernel that stores its sources')
+    assert L.lib().rd_conv_honours_src_out(C.byref(p), L.RD_BF16) == 1
+    L.check(L.lib().rd_conv(C.byref(p), L.RD_BF16, None), 'dz_out')
+    torch.cuda.synchronize()
+    U.assert_close(U.from_nhwc(gbuf), y.grad, dtype, 'dz_out dgrad', scale=3.0)
+    got = U.from_nhwc(dz_out)
+    assert torch.isfinite(got).all()
+    _assert_bf16_rounding_of(got, dz, (g * U.group_rows(P, gstart, N)).abs() + (z * U.group_rows(Q, gstart, N)).abs() + U.group_rows(R, gstart, N).abs(), 'dz')
+
+
 # ------------------------------------------------------------------------------------ wgrad
 WG_CASES = [
     ('img3_16', 9, [(L.SRC_RAW, 3)], 16, 2, 20, 36, 0),
@@ -280,6 +374,8 @@ WG_CASES = [
     ('cat16_aff16_16', 9, [(L.SRC_AFFACT, 16), (L.SRC_AFFACT, 16)], 16, 2, 16, 40, 1),
     ('cat64_aff64_64_rawdz', 9, [(L.SRC_AFFACT, 64), (L.SRC_AFFACT, 64)], 64, 3, 10, 12, 0),
     ('c64_64_many_tiles', 9, [(L.SRC_AFFACT, 64)], 64, 4, 40, 70, 1),
+    ('raw64_64_rawdz_many_tiles', 9, [(L.SRC_RAW, 64)], 64, 4, 40, 70, 0),          # both operands stored (rd_src_t.out): the loader only copies
+    ('cat_raw64_raw64_64', 9, [(L.SRC_RAW, 64), (L.SRC_RAW, 64)], 64, 3, 25, 25, 1),
     ('c256_128', 9, [(L.SRC_AFFACT, 256)], 128, 2, 6, 7, 1),
     ('c64_64_25x25', 9, [(L.SRC_AFFACT, 64)], 64, 3, 25, 25, 1),       # 4-row tiles of the warp-specialised kernel: one live row in the last
     ('c128_64_25x25_rawdz', 9, [(L.SRC_AFFACT, 128)], 64, 3, 25, 25, 0),

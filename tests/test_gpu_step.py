@@ -324,6 +324,46 @@ def test_native_launch_list_equals_the_python_launch_loop(fork):
     assert len(ts._native) == 1                                   # compiled once, reused
 
 
+def test_stored_weight_gradient_operands_give_identical_bits():
+    """TrainStep(options=dict(store_wgrad_operands=3)): the 64-wide forward / gradient launches also write act(bn(z)) / dz as they stage
+    them (rd_src_t.out) and the weight gradients of those layers read the stored tensors.  The stored values are the ones the
+    weight-gradient loader would have formed itself (same expression, same rounding), so gradients, parameters and losses after two
+    steps are bit-identical to the default (opt-in: measured a loss in step time, ramdsir/tuning.py)."""
+    torch.manual_seed(0)
+    bs, S = [2, 3, 3], 256
+    B = sum(bs)
+    outs = []
+    for store in (0, 3):
+        bank, mods = S_.make_bank(DEV, 3, 16, 2, len(bs))
+        g = torch.Generator().manual_seed(1)
+        for (m, k), (off, shape) in bank.index.items():
+            v = bank.p(m, k)
+            if len(shape) == 4:
+                v.copy_((torch.randn(shape, generator=g) * (2.0 / (shape[0] * shape[2] * shape[3])) ** 0.5).to(DEV))
+            elif '.bn' in k and k.endswith('weight'):
+                v.fill_(1.0)
+        ts = S_.TrainStep(bank, mods, torch.bfloat16, bs, S, S, dataset='fundus', consistency='kd', lr=1e-3, total_iters=100, ram='u8',
+                          options=dict(store_wgrad_operands=store, store_wgrad_min_c=64))
+        stored = [n for n in ts.seg.nodes + ts.rec.nodes if any(t is not None for t in getattr(n, 'a_store', []))]
+        assert bool(stored) == bool(store)                         # the option reaches launches of this geometry
+        ts.wpack.refresh()
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        src = (torch.rand(B, S, S, 3, device=DEV, generator=gen) * 255).to(torch.uint8)
+        trg = (torch.rand(B, S, S, 3, device=DEV, generator=gen) * 255).to(torch.uint8)
+        tgt = (torch.rand(B, 2, S, S, device=DEV, generator=gen) > 0.5).float()
+        lam = torch.tensor([0.1 * (1 + i % 9) for i in range(B)], device=DEV)
+        ts.load_raw(src, trg, lam)
+        ts.load_target(tgt)
+        for _ in range(2):
+            ts.step()
+        torch.cuda.synchronize()
+        outs.append((bank.grads.clone(), bank.params.clone(), ts.losses.clone(), ts.rec_mse.clone()))
+        del ts
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[0][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize('dataset', ['fundus', 'prostate'])
 def test_pipelined_ram_steps_equal_classical_steps(dataset):
     """TrainStep.load_raw_next(): the NEXT batch is uploaded into the other input slot and mixed (RAM) into that slot's copy of the
