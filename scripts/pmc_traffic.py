@@ -67,5 +67,19 @@ if min(nsteps.values()) > 0:
 out['collected'] = 'rocprofv3 PMC passes of scripts/collect_profiles.sh, tag %s' % tag
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'dominant_kernel_pmc.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
+# the committed bench line carries the traffic figures of THIS collection (bench.py reads them from the json that was committed when it
+# ran, i.e. the previous collection's): rewrite the fields that are copies of the json, nothing measured inside the bench run
+bl = json.loads(line)
+for key, r in bl.items():
+    if isinstance(r, dict) and r.get('family') in out and 'traffic' in r:
+        r['traffic'] = int(out[r['family']]['traffic_bytes_per_launch'])
+        r['traffic_over_algorithmic'] = round(r['traffic'] / r['avg_algorithmic_bytes'], 3)
+if 'step' in out and 'roofline_step' in bl:
+    rs = bl['roofline_step']
+    rs['traffic'] = int(out['step']['traffic_bytes_per_step'])
+    rs['traffic_over_algorithmic'] = round(rs['traffic'] / rs['algorithmic_bytes_per_step'], 3)
+    rs['traffic_gbs'] = round(rs['traffic'] / (bl['ms_per_step'] * 1e-3) / 1e9, 1)
+line = json.dumps(bl) + '\n'
+open(os.path.join(ROOT, 'profiles', tag + '_bench.json'), 'w').write(line)
 print('shares of the summed kernel time:', {f: round(out[f]['rocprof_share_percent'], 1) for f in FAMILIES})
 print(line)
