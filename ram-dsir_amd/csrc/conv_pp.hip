@@ -799,17 +799,17 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     if (trace_ && blockIdx.x == 5 && tid == 0) { ws_trace[0][63][0] = __builtin_readcyclecounter(); ws_trace[0][63][1] = wall_clock64(); }
 #endif
     __syncthreads();                     // buffer 0 filled (the loader waves' prologue)
+    // the accumulators are cleared BEHIND each tile's epilogue (and here for the first tile), not at the head of a tile: the compiler then
+    // sees them dead across the epilogue and regroups them in place instead of copying 64 registers per tile first
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
     for (int s = 0; s < nsteps; ++s) {
         const int par = s & 1;
         WS_T(0, s, 0);
-        if (M.c == 0) {
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
-        }
         if constexpr (MODE == 2) {
             if (M.c == q.nch - 1) dgrad_prefetch();
         }
@@ -933,6 +933,12 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                         }
                     }
             }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
         }
         WS_T(0, s, 2);
         pp_advance(M, q, gm);
