@@ -93,11 +93,99 @@ def init_weights(bank):
             v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * bound).to(v.device))
 
 
+_PMC_LIVE = None            # filled by collect_live_pmc(): the same structure as the committed json, measured by THIS run
+
+
 def _pmc_json():
+    if _PMC_LIVE is not None:
+        return _PMC_LIVE
     if not os.path.exists(PMC_JSON):
         return {}
     with open(PMC_JSON) as f:
         return json.load(f)
+
+
+def _traffic_source():
+    if _PMC_LIVE is not None:
+        return _PMC_LIVE['collected']
+    return 'profiles/dominant_kernel_pmc.json (%s)' % _pmc_json().get('collected', 'rocprofv3 PMC, offline')
+
+
+def pmc_aggregate(pmc_rows, B, dtype, size):
+    """rocprofv3 counter rows (Kernel_Name, Counter_Name in FETCH_SIZE / WRITE_SIZE, Counter_Value in KB; the two counters from
+    separate passes) -> HBM bytes per launch of every kernel family and per step, corrected as MI355X_MICROARCH.md prescribes:
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  One launch of a family = the kernels its 'count' symbols name (a weight-gradient
+    launch = MFMA kernel + its reduce).  Shared by scripts/pmc_traffic.py (the committed summary) and collect_live_pmc()."""
+    out = {'correction': 'HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: FETCH_SIZE reports half of 16-B/lane '
+                         'streaming reads on gfx950; counters in KB); FETCH_SIZE and WRITE_SIZE collected in separate passes'}
+    for fam, spec in FAMILIES.items():
+        member = lambda n: any(f in n for f in spec['symbols'])
+        counted = lambda n: any(f in n for f in (spec['count'] or spec['symbols']))
+        kb = {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0}
+        nl = {'FETCH_SIZE': 0, 'WRITE_SIZE': 0}
+        for r in pmc_rows:
+            if member(r['Kernel_Name']):
+                kb[r['Counter_Name']] += float(r['Counter_Value'])
+                if counted(r['Kernel_Name']):
+                    nl[r['Counter_Name']] += 1
+        if min(nl.values()) == 0:
+            continue
+        fk, wk = kb['FETCH_SIZE'] / nl['FETCH_SIZE'], kb['WRITE_SIZE'] / nl['WRITE_SIZE']
+        out[fam] = {'family': fam, 'kernels': ' + '.join(spec['symbols']), 'launches_profiled': nl['FETCH_SIZE'],
+                    'fetch_size_kb_per_launch': fk, 'write_size_kb_per_launch': wk, 'traffic_bytes_per_launch': (2 * fk + wk) * 1024}
+    # every kernel of a step: all dispatches of the library's kernels (torch's allocation fills excluded: they run once, before the
+    # first step) divided by the number of steps the profiled command ran (= dispatches of the once-per-step Adam kernel)
+    ours = lambda n: not n.startswith('_ZN2at') and 'at::native' not in n
+    nsteps = {c: sum(1 for r in pmc_rows if r['Counter_Name'] == c and 'adam_update_kernel' in r['Kernel_Name']) for c in ('FETCH_SIZE', 'WRITE_SIZE')}
+    if min(nsteps.values()) > 0:
+        tot_kb = {c: sum(float(r['Counter_Value']) for r in pmc_rows if r['Counter_Name'] == c and ours(r['Kernel_Name'])) for c in nsteps}
+        fk, wk = tot_kb['FETCH_SIZE'] / nsteps['FETCH_SIZE'], tot_kb['WRITE_SIZE'] / nsteps['WRITE_SIZE']
+        per_kernel = {}
+        for r in pmc_rows:
+            if ours(r['Kernel_Name']):
+                k = r['Kernel_Name'].split('(')[0][:60]
+                per_kernel.setdefault(k, {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})[r['Counter_Name']] += float(r['Counter_Value'])
+        top = sorted(per_kernel.items(), key=lambda kv: -(2 * kv[1]['FETCH_SIZE'] / nsteps['FETCH_SIZE'] + kv[1]['WRITE_SIZE'] / nsteps['WRITE_SIZE']))[:12]
+        out['step'] = {'steps_profiled': nsteps['FETCH_SIZE'], 'fetch_size_kb_per_step': fk, 'write_size_kb_per_step': wk,
+                       'traffic_bytes_per_step': (2 * fk + wk) * 1024, 'size': size, 'dtype': dtype, 'batch': B,
+                       'top_kernels_mb_per_step': {k: round((2 * v['FETCH_SIZE'] / nsteps['FETCH_SIZE'] + v['WRITE_SIZE'] / nsteps['WRITE_SIZE']) / 1024, 1) for k, v in top}}
+    return out
+
+
+def collect_live_pmc(B, dtype, size, timeout=240):
+    """HBM traffic measured BY THIS RUN: the same command (3 steps, no baselines) as a child process under `rocprofv3 -i scripts/pmc_hbm.txt
+    --kernel-trace` (FETCH_SIZE and WRITE_SIZE in separate passes, kernel trace only: the guide's recipe), its counter files
+    aggregated by pmc_aggregate().  Returns True when the figures of the line come from it; on any failure (no rocprofv3, a
+    time-out, unreadable output) the line falls back to the committed profiles/dominant_kernel_pmc.json and says so."""
+    global _PMC_LIVE
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None or os.environ.get('RD_BENCH_CHILD') == '1':
+        return False
+    outdir = tempfile.mkdtemp(prefix='rd_pmc_', dir='/tmp')
+    try:
+        cmd = [exe, '-i', os.path.join(ROOT, 'scripts', 'pmc_hbm.txt'), '--kernel-trace', '-M', '--output-format', 'csv', '-d', outdir, '-o', 'p',
+               '--', sys.executable, os.path.abspath(__file__), '--steps', '3', '--warmup', '1', '--size', str(size), '--dtype', dtype,
+               '--no-cpu-baseline', '--no-fp32-leg', '--no-ablation', '--no-live-pmc']
+        env = dict(os.environ, TMPDIR='/tmp', RD_BENCH_CHILD='1')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'RD_FORCE_DDP'):
+            env.pop(k, None)
+        r = subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        rows = []
+        for f in glob.glob(os.path.join(outdir, '**', '*counter_collection.csv'), recursive=True):
+            with open(f) as fh:
+                rows += [x for x in csv.DictReader(fh) if x['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE')]
+        agg = pmc_aggregate(rows, B, dtype, size)
+        if r.returncode != 0 or 'step' not in agg:
+            return False
+        agg['collected'] = ('live: rocprofv3 -i scripts/pmc_hbm.txt --kernel-trace around a %d-step child run of this command '
+                            '(FETCH_SIZE / WRITE_SIZE in separate passes)' % agg['step']['steps_profiled'])
+        _PMC_LIVE = agg
+        return True
+    except Exception:
+        return False
+    finally:
+        shutil.rmtree(outdir, ignore_errors=True)
 
 
 def kernel_roofline(ts, fam, eager=True):
@@ -138,12 +226,10 @@ def kernel_roofline(ts, fam, eager=True):
     # FETCH_SIZE / WRITE_SIZE passes) on this command, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 for
     # 16-B/lane streaming reads, KB -> B); `traffic_source` names the file, profiles/README.md the procedure
     traffic, traffic_source = None, None
-    tj = _pmc_json()
-    collected = tj.get('collected', 'rocprofv3 PMC, offline')
-    tj = tj.get(fam, {})
+    tj = _pmc_json().get(fam, {})
     if tj.get('family') == fam and 'traffic_bytes_per_launch' in tj:
         traffic = int(tj['traffic_bytes_per_launch'])
-        traffic_source = 'profiles/dominant_kernel_pmc.json (%s)' % collected
+        traffic_source = _traffic_source()
     if intensity >= ridge:
         out = dict(bound='mfma', achieved=round(tfs, 1), peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tfs / MFMA_PEAK_TFLOPS, 4))
     else:
@@ -313,7 +399,7 @@ def whole_step_roofline(B, Sz, ms_per_step, dtype):
     if st.get('size') == Sz and st.get('dtype') == dtype and st.get('batch') == B and 'traffic_bytes_per_step' in st:
         out.update(traffic=int(st['traffic_bytes_per_step']), traffic_over_algorithmic=round(st['traffic_bytes_per_step'] / nbytes, 3),
                    traffic_gbs=round(st['traffic_bytes_per_step'] / t / 1e9, 1),
-                   traffic_source='profiles/dominant_kernel_pmc.json (%s)' % _pmc_json().get('collected', ''))
+                   traffic_source=_traffic_source())
     else:
         out.update(traffic=None)
     return out
@@ -332,6 +418,7 @@ def main():
     ap.add_argument('--no-fp32-leg', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='classical step: RAM at the head of every step instead of in the previous step\'s tail')
     ap.add_argument('--no-ablation', action='store_true', help='skip the in-run ablation that picks the headline roofline family')
+    ap.add_argument('--no-live-pmc', action='store_true', help='take the HBM traffic figures from the committed profiles/dominant_kernel_pmc.json instead of measuring them in a rocprofv3 child run')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -437,6 +524,10 @@ def main():
                        'ram_pipelined': not (args.graph or args.no_pipeline), 'launch': 'rd_run_list (one native call per step)' if not args.graph else 'hipGraph replay',
                        'final_loss': round(losses['loss'], 4)},
         }
+        # HBM traffic measured by this run (a rocprofv3 child of the same command, after the timed region); single process only: under
+        # torchrun the committed summary is used
+        if world == 1 and runner is None and not args.graph and not args.no_live_pmc:
+            collect_live_pmc(B, args.dtype, Sz)
         out['roofline_step'] = whole_step_roofline(B, Sz, out['ms_per_step'], args.dtype)
         if args.dtype == 'bf16':
             roofs = {}
