@@ -162,6 +162,10 @@ def collect_live_pmc(B, dtype, size, timeout=240):
     exe = shutil.which('rocprofv3')
     if exe is None or os.environ.get('RD_BENCH_CHILD') == '1':
         return False
+    # not from inside a profiler: when this process itself runs under rocprofv3 (the committed --stats / --pmc collections) its
+    # environment carries the tool library, and a nested profiler would inherit it
+    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return False
     outdir = tempfile.mkdtemp(prefix='rd_pmc_', dir='/tmp')
     try:
         cmd = [exe, '-i', os.path.join(ROOT, 'scripts', 'pmc_hbm.txt'), '--kernel-trace', '-M', '--output-format', 'csv', '-d', outdir, '-o', 'p',

@@ -166,3 +166,31 @@ def test_tuning_options_and_cu_budget_defaults():
     assert T.cu_budget(96, None) == 96 and T.cu_budget(0, None) == 0
     with pytest.raises(KeyError):
         T.options(dict(no_such_option=1))
+
+
+def test_pmc_aggregation_of_the_bench_line():
+    """bench.pmc_aggregate (shared by the live PMC child run and scripts/pmc_traffic.py): FETCH_SIZE / WRITE_SIZE rows of separate
+    passes -> bytes = (2 * FETCH + WRITE) * 1024 per launch of a kernel family (a weight-gradient launch = MFMA kernel + its reduce)
+    and per step (= per dispatch of the once-per-step Adam kernel; the tensor library's fills excluded)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('rd_bench_t', os.path.join(ROOT, 'bench.py'))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    ws = 'void (anonymous namespace)::wgrad_ws_kernel<2, 0>(rd_wgrad_t, int, int, int)'
+    red = 'void (anonymous namespace)::wgrad_reduce_kernel<32>(float const*, float*, int)'
+    adam = 'void (anonymous namespace)::adam_update_kernel(rd_adam_t)'
+    fill = '_ZN2at6native29vectorized_elementwise_kernelIfill'
+    rows = []
+    for step in range(2):
+        for c, (v_ws, v_red, v_adam) in (('FETCH_SIZE', (100.0, 10.0, 5.0)), ('WRITE_SIZE', (40.0, 2.0, 3.0))):
+            rows += [dict(Kernel_Name=ws, Counter_Name=c, Counter_Value=str(v_ws)), dict(Kernel_Name=ws, Counter_Name=c, Counter_Value=str(v_ws)),
+                     dict(Kernel_Name=red, Counter_Name=c, Counter_Value=str(v_red)), dict(Kernel_Name=red, Counter_Name=c, Counter_Value=str(v_red)),
+                     dict(Kernel_Name=adam, Counter_Name=c, Counter_Value=str(v_adam)), dict(Kernel_Name=fill, Counter_Name=c, Counter_Value='1000')]
+    out = B.pmc_aggregate(rows, 8, 'bf16', 400)
+    w = out['wgrad']
+    assert w['launches_profiled'] == 4                                        # the reduce kernels are not launches of their own
+    assert w['traffic_bytes_per_launch'] == (2 * 110.0 + 42.0) * 1024
+    st = out['step']
+    assert st['steps_profiled'] == 2 and st['batch'] == 8 and st['dtype'] == 'bf16'
+    assert st['traffic_bytes_per_step'] == (2 * (2 * 110.0 + 5.0) + (2 * 42.0 + 3.0)) * 1024        # the at:: fill is not ours
+    assert 'conv64' not in out                                                # a family without dispatches is absent, not zero
