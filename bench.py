@@ -164,7 +164,7 @@ def collect_live_pmc(B, dtype, size, timeout=240):
         return False
     # not from inside a profiler: when this process itself runs under rocprofv3 (the committed --stats / --pmc collections) its
     # environment carries the tool library, and a nested profiler would inherit it
-    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
+    if _under_profiler():
         return False
     outdir = tempfile.mkdtemp(prefix='rd_pmc_', dir='/tmp')
     try:
@@ -248,17 +248,96 @@ def kernel_roofline(ts, fam, eager=True):
     return out
 
 
+_SQ_LIVE = None             # filled by collect_live_sq()
+
+
+def sq_aggregate(acc):
+    """SQ counter means per (kernel, grid, workgroup size) -> per family: mfma_busy = sum SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel
+    cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs); mfma_busy_occupied divides by the SIMDs of the
+    CUs the launch can occupy; lds_conflict_ratio = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.  Shared with scripts/mfma_busy.py."""
+    dem = {'conv_pf_kernelIDF16bLi9ELi2E': 'conv_pf_kernel<__bf16, 9, 2', '11conv_kernelIDF16bLi9ELi2E': 'conv_kernel<__bf16, 9, 2'}
+    mean = lambda v: sum(v) / len(v)
+    out = {}
+    for fam, spec in FAMILIES.items():
+        busy = cyc = occ = n = conf = ldsact = 0.0
+        for (name, grid, wgs), c in acc.items():
+            if not any(dem.get(sym, sym) in name for sym in spec['symbols']):
+                continue
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' not in c or 'GRBM_GUI_ACTIVE' not in c:
+                continue
+            k = len(c['GRBM_GUI_ACTIVE'])
+            kc = mean(c['GRBM_GUI_ACTIVE']) / 8.0
+            cus = min(int(grid) // max(int(wgs), 1), 256)
+            busy += k * mean(c['SQ_VALU_MFMA_BUSY_CYCLES'])
+            cyc += k * 1024.0 * kc
+            occ += k * 4.0 * cus * kc
+            n += k
+            if 'SQ_LDS_BANK_CONFLICT' in c and 'SQ_LDS_IDX_ACTIVE' in c:
+                conf += k * mean(c['SQ_LDS_BANK_CONFLICT'])
+                ldsact += k * mean(c['SQ_LDS_IDX_ACTIVE'])
+        if n and cyc:
+            out[fam] = dict(mfma_busy=round(busy / cyc, 4), mfma_busy_occupied=round(busy / max(occ, 1.0), 4), dispatches=int(n))
+            if ldsact:
+                out[fam]['lds_conflict_ratio'] = round(conf / ldsact, 4)
+    return out
+
+
+def read_counter_dir(d):
+    import collections, csv, glob
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                acc[(r['Kernel_Name'], r['Grid_Size'], r['Workgroup_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    return acc
+
+
+def _under_profiler():
+    return any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
+
+
+def collect_live_sq(dtype, size, timeout=240):
+    """Matrix-pipe busy fraction and LDS conflict ratio per family measured by THIS run: scripts/pmc_step.py (one eager step on one
+    stream) as a child under `rocprofv3 -i scripts/pmc_sq.txt --kernel-trace`.  False (-> the committed profiles/r04_mfma_busy.json)
+    when it cannot run."""
+    global _SQ_LIVE
+    import shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None or os.environ.get('RD_BENCH_CHILD') == '1' or _under_profiler():
+        return False
+    outdir = tempfile.mkdtemp(prefix='rd_sq_', dir='/tmp')
+    try:
+        cmd = [exe, '-i', os.path.join(ROOT, 'scripts', 'pmc_sq.txt'), '--kernel-trace', '--output-format', 'csv', '-d', outdir, '-o', 'p',
+               '--', sys.executable, os.path.join(ROOT, 'scripts', 'pmc_step.py'), dtype, str(size), '2']
+        env = dict(os.environ, TMPDIR='/tmp', RD_BENCH_CHILD='1')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'RD_FORCE_DDP'):
+            env.pop(k, None)
+        r = subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        agg = sq_aggregate(read_counter_dir(outdir))
+        if r.returncode != 0 or not agg:
+            return False
+        agg['collected'] = 'live: rocprofv3 -i scripts/pmc_sq.txt --kernel-trace around scripts/pmc_step.py %s %d 2 (one eager step, one stream)' % (dtype, size)
+        _SQ_LIVE = agg
+        return True
+    except Exception:
+        return False
+    finally:
+        shutil.rmtree(outdir, ignore_errors=True)
+
+
 def mfma_busy(fam):
-    """MFMA utilisation of a kernel family from the committed SQ-counter summary (scripts/collect_sq.sh -> scripts/mfma_busy.py ->
-    profiles/r04_mfma_busy.json): SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles).  Like `traffic`: collected with rocprofv3
-    around this workload, not inside this run."""
-    if not os.path.exists(SQ_JSON):
-        return None
-    with open(SQ_JSON) as f:
-        j = json.load(f)
+    """MFMA utilisation of a kernel family: SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles), from collect_live_sq() when it ran, else
+    from the committed SQ-counter summary (scripts/collect_sq.sh -> scripts/mfma_busy.py -> profiles/r04_mfma_busy.json)."""
+    if _SQ_LIVE is not None:
+        j, src = _SQ_LIVE, _SQ_LIVE['collected']
+    else:
+        if not os.path.exists(SQ_JSON):
+            return None
+        with open(SQ_JSON) as f:
+            j = json.load(f)
+        src = '%s (%s)' % (os.path.relpath(SQ_JSON, ROOT), j.get('collected', 'rocprofv3 SQ counters, offline'))
     if fam not in j:
         return None
-    src = '%s (%s)' % (os.path.relpath(SQ_JSON, ROOT), j.get('collected', 'rocprofv3 SQ counters, offline'))
     out = dict(mfma_busy=j[fam]['mfma_busy'], mfma_busy_source=src)
     if 'lds_conflict_ratio' in j[fam]:
         out['lds_conflict_ratio'] = j[fam]['lds_conflict_ratio']        # SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
@@ -532,6 +611,7 @@ def main():
         # torchrun the committed summary is used
         if world == 1 and runner is None and not args.graph and not args.no_live_pmc:
             collect_live_pmc(B, args.dtype, Sz)
+            collect_live_sq(args.dtype, Sz)
         out['roofline_step'] = whole_step_roofline(B, Sz, out['ms_per_step'], args.dtype)
         if args.dtype == 'bf16':
             roofs = {}

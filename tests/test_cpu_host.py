@@ -194,3 +194,21 @@ def test_pmc_aggregation_of_the_bench_line():
     assert st['steps_profiled'] == 2 and st['batch'] == 8 and st['dtype'] == 'bf16'
     assert st['traffic_bytes_per_step'] == (2 * (2 * 110.0 + 5.0) + (2 * 42.0 + 3.0)) * 1024        # the at:: fill is not ours
     assert 'conv64' not in out                                                # a family without dispatches is absent, not zero
+
+
+def test_sq_counter_aggregation_of_the_bench_line():
+    """bench.sq_aggregate: matrix-pipe busy fraction = MFMA busy cycles / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8
+    XCDs, weighted over dispatches; LDS conflict ratio = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('rd_bench_s', os.path.join(ROOT, 'bench.py'))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    acc = {('void (anonymous namespace)::conv_ws_kernel<1, 1, false, false>(rd_conv_t, int)', '131072', '512'):
+           {'GRBM_GUI_ACTIVE': [8000.0, 8000.0], 'SQ_VALU_MFMA_BUSY_CYCLES': [256000.0, 256000.0], 'SQ_LDS_BANK_CONFLICT': [10.0, 30.0],
+            'SQ_LDS_IDX_ACTIVE': [1000.0, 1000.0]},
+           ('void (anonymous namespace)::adam_update_kernel(rd_adam_t)', '1048576', '256'): {'GRBM_GUI_ACTIVE': [800.0], 'SQ_VALU_MFMA_BUSY_CYCLES': [0.0]}}
+    out = B.sq_aggregate(acc)
+    c = out['conv64']
+    assert c['dispatches'] == 2 and c['mfma_busy'] == round(256000.0 / (1024 * 1000.0), 4) == 0.25
+    assert c['mfma_busy_occupied'] == 0.25 and c['lds_conflict_ratio'] == 0.02          # 256 workgroups occupy the whole device
+    assert 'wgrad' not in out
