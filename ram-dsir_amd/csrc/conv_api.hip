@@ -128,7 +128,7 @@ int rd_conv_honours_src_out(const rd_conv_t* p, int dtype) {
     const int ck = dtype == RD_BF16 ? 32 : 16;
     if (p->CinPad % ck || p->CoutPad % 32 || p->CinPad < p->Cin || p->CoutPad < p->Cout || p->w_tap_rows) return 0;
     if (p->CinPad == ck && p->CoutPad == 32) return 0;           // the small-channel kernels
-    return rd_conv_big_takes_ws(*p, dtype) ? 1 : 0;
+    return rd_conv_big_stores_sources(*p, dtype) ? 1 : 0;
 }
 
 int64_t rd_wgrad_workspace(const rd_wgrad_t* p, int dtype) {

@@ -162,6 +162,10 @@ bool rd_conv_big_takes_ws(const rd_conv_t& p, int dtype) {
     return dtype == RD_BF16 && p.taps == 9 && conv_big_nb2(p, dtype) && !pp_off && rd_conv_ws_takes(p);
 }
 
+bool rd_conv_big_stores_sources(const rd_conv_t& p, int dtype) {
+    return rd_conv_big_takes_ws(p, dtype) && rd_conv_ws_stores_sources(p);
+}
+
 int rd_conv_big_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
     const bool nb2 = conv_big_nb2(p, dtype);
     if (dtype == RD_BF16) {

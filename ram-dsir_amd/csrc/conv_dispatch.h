@@ -22,6 +22,8 @@ int rd_conv_small_fwd_dispatch(const rd_conv_t& p, int dtype, hipStream_t st);
 int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st);
 bool rd_conv_ws_takes(const rd_conv_t& p);           // conv_pp.hip: the launch runs on conv_ws_kernel (the kernel that writes rd_src_t.out)
 bool rd_conv_big_takes_ws(const rd_conv_t& p, int dtype);   // conv_big.hip: ... after conv_big's own routing (64-wide tiles, bf16, 3x3)
+bool rd_conv_ws_stores_sources(const rd_conv_t& p);  // conv_pp.hip: ... on an instantiation that WRITES rd_src_t.out (dispatch and query share it)
+bool rd_conv_big_stores_sources(const rd_conv_t& p, int dtype);
 
 // Register ("lean") epilogues: accumulators leave as 16-byte NHWC vectors straight from registers (MFMA roles swapped:
 // weights x pixels, v_permlane32_swap regroup) instead of through the LDS-staged epilogue of conv_epilogue.h.

@@ -992,6 +992,14 @@ bool rd_conv_ws_takes(const rd_conv_t& p) {
     return mode && (ws & mode) && (mode == 1 || (tiles >= ws_min2 && !accumulates)) && tab <= (size_t)WsLds<0>::TAB_BYTES;
 }
 
+// does this launch also WRITE the rd_src_t.out tensors it is given?  Only the SOUT instantiations of conv_ws_kernel do: forward launches
+// (mode 1) and gradient launches on a BatchNorm-backward source (mode 2, two-operand loader).  A gradient launch on plain sources runs
+// conv_ws_kernel<2, TS>, which never stores what it stages.  ONE definition for the dispatch below and for rd_conv_honours_src_out.
+bool rd_conv_ws_stores_sources(const rd_conv_t& p) {
+    if (!rd_conv_ws_takes(p)) return false;
+    return rd_conv_lean_mode(p, PP_NT) == 1 || pp_sources_kind(p) == 2;
+}
+
 int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     const int skind = pp_sources_kind(p);
     if (p.taps != 9 || p.CoutPad % PP_NT || p.CinPad > 32 * PP_MAX_CHUNKS || !skind) return RD_CONV_PP_NA;
@@ -1052,6 +1060,7 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         const int arg = nt | (ws_exp << 26) | (tiles >= ws_trace_min ? 1 << 25 : 0);
         bool sout = false;                                     // a source asks for its staged values to be stored as well (ramdsir.h)
         for (int i = 0; i < p.nsrc; ++i) sout = sout || p.src[i].out != nullptr;
+        sout = sout && rd_conv_ws_stores_sources(p);
         if (mode == 1 && sout) {
             if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1, false, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
             else hipLaunchKernelGGL((conv_ws_kernel<1, 0, false, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);

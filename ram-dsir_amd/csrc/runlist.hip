@@ -12,9 +12,10 @@
 
 namespace {
 
-// Events for the cross-stream edges.  An event can be recorded again as soon as the hipStreamWaitEvent that uses it has been
-// enqueued (the wait captures the record it was called after), so a small ring per device is enough; the ring only keeps an event
-// from being re-recorded while the runtime may still be processing the previous wait call on another thread of its own.
+// Events for the cross-stream edges of the SINGLE-THREADED walk (record and wait are issued back to back by the caller).  An event can
+// be recorded again as soon as the hipStreamWaitEvent that uses it has been enqueued (the wait captures the record it was called
+// after), so a small ring per device is enough there.  Edges that pass through a lane worker thread use the worker's own pool
+// (worker_event below), whose slots are reused only after the worker has executed the command that carries them.
 constexpr int EV_RING = 64, EV_MAX_DEV = 16;
 struct EvRing {
     hipEvent_t ev[EV_RING];
@@ -124,15 +125,26 @@ struct Cmd {
     hipStream_t stream;
 };
 constexpr unsigned RING = 4096;
+// Events of the edges that go THROUGH a worker come from a pool of the worker's own (not from the per-device ring above): the caller
+// records (or reserves) an event and the worker uses it later, asynchronously, so a slot may only be reused once the worker has
+// executed the command that carries it.  ev_used counts those commands as the worker executes them; the caller hands out slot
+// ev_issued % EV_POOL only while ev_issued - ev_used < EV_POOL (it waits otherwise: the worker is behind by a whole pool).
+constexpr unsigned EV_POOL = 256;
 struct Worker {
     Cmd ring[RING];
     std::atomic<unsigned> head{0}, tail{0};     // single producer (the caller), single consumer (the worker)
     std::atomic<int> err{0};
     std::atomic<int> asleep{0};
+    std::atomic<int> poisoned{0};               // a push / drain timed out: the worker discards what it still holds and is never used again
+    std::atomic<unsigned> ev_used{0};
+    unsigned ev_issued = 0;                     // caller side only
+    hipEvent_t evpool[EV_POOL];
+    bool ev_ready = false;
     std::mutex m;
     std::condition_variable cv;
 };
-Worker* g_workers[32] = {};
+Worker* g_workers[EV_MAX_DEV][32] = {};          // keyed by (device, lane): two devices never share a single-producer ring
+std::mutex g_workers_mutex;
 std::atomic<int> g_threads_enabled{0};
 
 void worker_main(Worker* w) {
@@ -151,31 +163,38 @@ void worker_main(Worker* w) {
         }
         const Cmd c = w->ring[h % RING];
         int rc = 0;
-        switch (c.kind) {
-        case 0: rc = call(ops[c.idx], (void*)stream); break;
-        case 1: rc = (int)hipStreamWaitEvent(stream, c.ev, 0); break;
-        case 2: rc = (int)hipEventRecord(c.ev, stream); break;
-        case 3: rc = (int)hipSetDevice(c.idx); ops = c.ops; stream = c.stream; break;
+        // a poisoned worker (the caller gave up on it and may have freed the list, its descriptors and streams) executes nothing:
+        // it only consumes its ring
+        if (!w->poisoned.load(std::memory_order_acquire)) {
+            switch (c.kind) {
+            case 0: rc = call(ops[c.idx], (void*)stream); break;
+            case 1: rc = (int)hipStreamWaitEvent(stream, c.ev, 0); break;
+            case 2: rc = (int)hipEventRecord(c.ev, stream); break;
+            case 3: rc = (int)hipSetDevice(c.idx); ops = c.ops; stream = c.stream; break;
+            }
         }
+        if (c.kind == 1 || c.kind == 2) w->ev_used.fetch_add(1, std::memory_order_release);
         if (rc && !w->err.load()) w->err.store(rc);
         w->head.store(h + 1, std::memory_order_release);
     }
 }
 
-Worker* worker_for(int lane) {
-    if (!g_workers[lane]) {
+Worker* worker_for(int dev, int lane) {
+    std::lock_guard<std::mutex> lk(g_workers_mutex);
+    Worker*& slot = g_workers[dev][lane];
+    if (!slot || slot->poisoned.load()) {
         Worker* w = new Worker();                                  // never freed: the thread outlives every static destructor
         std::thread(worker_main, w).detach();
-        g_workers[lane] = w;
+        slot = w;                                                  // (a poisoned worker is abandoned with its thread)
     }
-    return g_workers[lane];
+    return slot;
 }
 
 int push(Worker* w, const Cmd& c) {
     const unsigned t = w->tail.load(std::memory_order_relaxed);
     int spins = 0;
     while (t - w->head.load(std::memory_order_acquire) >= RING) {   // ring full: the worker is behind
-        if (++spins > 200000000) return -2;
+        if (++spins > 200000000) { w->poisoned.store(1, std::memory_order_release); return -2; }
         __builtin_ia32_pause();
     }
     w->ring[t % RING] = c;
@@ -187,14 +206,38 @@ int push(Worker* w, const Cmd& c) {
     return 0;
 }
 
-// wait until the worker has executed everything pushed so far (bounded: a stuck runtime call must not hang the caller for ever)
+// the next event of the worker's pool, once the worker has executed the command that used the slot the last time round
+int worker_event(Worker* w, hipEvent_t* out) {
+    if (!w->ev_ready) {
+        for (unsigned i = 0; i < EV_POOL; ++i) RD_CHECK(hipEventCreateWithFlags(&w->evpool[i], hipEventDisableTiming));
+        w->ev_ready = true;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (w->ev_issued - w->ev_used.load(std::memory_order_acquire) >= EV_POOL) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+            w->poisoned.store(1, std::memory_order_release);
+            return -2;
+        }
+    }
+    *out = w->evpool[w->ev_issued % EV_POOL];
+    ++w->ev_issued;
+    return 0;
+}
+
+// wait until the worker has executed everything pushed so far (bounded: a stuck runtime call must not hang the caller for ever; the
+// worker is poisoned then -- it still holds commands that point into the caller's list)
 int drain(Worker* w) {
     const unsigned t = w->tail.load(std::memory_order_relaxed);
     const auto t0 = std::chrono::steady_clock::now();
     int spins = 0;
     while ((int)(w->head.load(std::memory_order_acquire) - t) < 0) {
         __builtin_ia32_pause();
-        if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return -2;
+        if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+            w->poisoned.store(1, std::memory_order_release);
+            return -2;
+        }
     }
     return w->err.exchange(0);
 }
@@ -204,11 +247,12 @@ int run_list_threaded(const rd_launch_t* ops, int n, void* const* streams, int n
     hipStream_t main_s = (hipStream_t)streams[0];
     int dev = 0;
     RD_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= EV_MAX_DEV) return -1;
     Worker* ws[32] = {};
     int rc = 0, i = 0;
     auto lane_worker = [&](int lane) -> Worker* {
         if (!ws[lane]) {
-            ws[lane] = worker_for(lane);
+            ws[lane] = worker_for(dev, lane);
             Cmd c{3, dev, nullptr, ops, (hipStream_t)streams[lane]};
             if (push(ws[lane], c)) return nullptr;
         }
@@ -219,7 +263,7 @@ int run_list_threaded(const rd_launch_t* ops, int n, void* const* streams, int n
         if (!w) return -2;
         if ((hipStream_t)streams[lane] == main_s) return 0;
         hipEvent_t e;
-        const int err = next_event(&e);
+        const int err = worker_event(w, &e);
         if (err) return err;
         RD_CHECK(hipEventRecord(e, main_s));
         return push(w, Cmd{1, 0, e, nullptr, nullptr});
@@ -238,7 +282,7 @@ int run_list_threaded(const rd_launch_t* ops, int n, void* const* streams, int n
                 if (!w) { rc = -2; break; }
                 if ((hipStream_t)streams[o.lane] != main_s) {
                     hipEvent_t e;
-                    rc = next_event(&e);
+                    rc = worker_event(w, &e);
                     if (rc) break;
                     rc = push(w, Cmd{2, 0, e, nullptr, nullptr});
                     if (rc) break;

@@ -304,9 +304,10 @@ class TrainStep:
             if src.dtype == torch.uint8 and t.dtype != torch.uint8:
                 raise TypeError('%s images are %s but this TrainStep was built with ram=\'u8\' (uint8 buffers): pass uint8 '
                                 'pixels or build the step with ram=True (float32 buffers)' % (name, t.dtype))
-        src.copy_(src_nhwc, non_blocking=True)
-        trg.copy_(trg_nhwc, non_blocking=True)
-        lm.copy_(lam, non_blocking=True)
+        # asynchronous only for sources that are already on the device: a pinned HOST buffer the caller reuses after this call
+        # (DataLoader pinned memory, a bench loop) would race with a non-blocking H2D copy
+        for dst, t in ((src, src_nhwc), (trg, trg_nhwc), (lm, lam)):
+            dst.copy_(t, non_blocking=bool(t.is_cuda))
 
     def load_target(self, mask):
         self.target.copy_(mask)

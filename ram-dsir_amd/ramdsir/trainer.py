@@ -27,7 +27,7 @@ class FusedTrainer:
                               # a captured graph replays one chain: no lane to leave compute units to (tuning.py)
                               options=dict(side_cus=0, rec_cus=0) if use_graph else None)
         self.ts.wpack.refresh()
-        self._primed, self._graphs = False, bool(use_graph)
+        self._primed, self._graphs, self._announced = False, bool(use_graph), None
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         if self.world > 1:
             # identical initial weights on every rank (DataParallel broadcasts replica 0's, train.py:205-208)
@@ -55,6 +55,11 @@ class FusedTrainer:
         if not self._primed:
             self.ts.load_raw(src_nhwc, trg_nhwc, lam)
             self.ts.load_target(target)
+        elif not all(a is b for a, b in zip((src_nhwc, trg_nhwc, lam, target), self._announced)):
+            # the previous call uploaded `next_batch` and this step trains on THAT: a caller that now passes other tensors would
+            # silently train on the wrong data
+            raise ValueError('FusedTrainer.step: the previous call announced next_batch; this call must pass the same tensors '
+                             '(src, trg, lam, target) as its current batch')
         pipelined = next_batch is not None and not self._graphs
         if pipelined:
             self.ts.load_raw_next(*next_batch[:3])
@@ -62,6 +67,7 @@ class FusedTrainer:
         if pipelined:
             self.ts.load_target(next_batch[3])            # after the step has been enqueued: its loss still reads the current mask
         self._primed = pipelined
+        self._announced = tuple(next_batch[:4]) if pipelined else None
 
     def losses(self):
         """The five loss terms + per-domain rec losses (names of the tensorboard scalars, train.py:298-304).  Data parallel:

@@ -43,7 +43,7 @@ DEFAULTS = dict(
                           # available to fix the choice at build time
     dgrad_cus=160,        # compute-unit budget of the seg plan's >= 64-channel gradient launches (they run on the persistent whole-CU
                           # kernel conv_ws_kernel<2> since round 4): leaves 96 CUs to the weight-gradient / restoration lanes beside
-                          # them.  0 (all): 4.48 ms/step, 224: 4.46, 192: 4.44, 160: 4.43, 128: 4.51 (scripts/sweep_ws2.sh)
+                          # them.  0 (all): 4.48 ms/step, 224: 4.46, 192: 4.44, 160: 4.43, 128: 4.51 (scripts/attic/sweep_ws2.sh)
     launch_threads=False, # rd_run_list_threads: the side / rec lanes' launches are enqueued by worker threads of the library, in parallel
                           # with the main lane's (host enqueue 0.85 -> ~0.4 ms per step; the GPU executes the same graph)
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)

@@ -362,6 +362,21 @@ def test_conv_gradient_also_stores_the_dz_it_forms():
     got = U.from_nhwc(dz_out)
     assert torch.isfinite(got).all()
     _assert_bf16_rounding_of(got, dz, (g * U.group_rows(P, gstart, N)).abs() + (z * U.group_rows(Q, gstart, N)).abs() + U.group_rows(R, gstart, N).abs(), 'dz')
+    # the same gradient launch on a STORED dz (plain source): it runs on an instantiation that never writes rd_src_t.out, the query says so
+    # beforehand (one predicate for query and dispatch, csrc/conv_pp.hip rd_conv_ws_stores_sources) and the tensor is left alone
+    src2 = U.make_src(keep, dz, L.SRC_RAW, dtype)
+    untouched = torch.full((N, H, W, Cz), 7.0, dtype=torch.bfloat16, device=U.dev())
+    src2.out = untouched.data_ptr()
+    p2 = _conv_desc(keep, [src2], w, None, N, H, W, gstart, dtype, 9, transpose=True)
+    p2.emode, p2.c_split = 1, Ca
+    p2.dst[0] = d
+    p2.dst[1].kind = L.DST_NONE
+    assert L.lib().rd_conv_honours_src_out(C.byref(p2), L.RD_BF16) == 0
+    bst.zero_()
+    L.check(L.lib().rd_conv(C.byref(p2), L.RD_BF16, None), 'raw dz with out')
+    torch.cuda.synchronize()
+    assert bool((untouched == 7.0).all())
+    U.assert_close(U.from_nhwc(gbuf), y.grad, dtype, 'raw dz dgrad', scale=3.0)
 
 
 # ------------------------------------------------------------------------------------ wgrad
