@@ -35,6 +35,18 @@ extern "C" {
  * structural source of |mean| >> sigma -- is added back to the mean by rd_bn_finalize_fwd), and (b) everything across
  * workgroups -- the slot atomics, the slot sum, var = E[x^2]-E[x]^2 and sum g*z - mean * sum g -- is fp64. */
 #define RD_STAT_SLOTS 64
+/* A launch may be told to spread its sums over the FIRST n of the RD_STAT_SLOTS copies only (rd_conv_t.stat_slots, the stat_slots
+ * arguments of rd_up_stats / rd_pool_bwd; 0 = all): the persistent kernels of the training step add once per workgroup, not once per
+ * tile, so 8 copies keep them apart -- and a consumer that derives the BatchNorm coefficients itself (rd_src_t.fin below) then reads 8
+ * copies per channel instead of 64.  The layout [G][RD_STAT_SLOTS][C][2] does not change; unused copies stay zero, and the explicit
+ * finalize launches sum all of them. */
+#define RD_STAT_SLOTS_FOLD 8
+
+/* rd_src_t.fin_flags */
+enum {
+    RD_FIN_OWNER = 1   /* this launch also does what happens once per BatchNorm call: saved mean / invstd, running statistics and
+                          num_batches_tracked (forward); dgamma / dbeta (backward) */
+};
 
 /* how a conv reads one of its (virtual) input tensors -- the producer's BatchNorm + activation
  * (+ max-pool / bilinear x2) are applied while the tile is staged into LDS ("normalise on read") */
@@ -64,7 +76,16 @@ typedef struct {
     float slope;         /* 0 = ReLU, 0.01 = LeakyReLU (unet.py:47-50)                    */
     int32_t n_off;       /* image offset into ptr (rec decoder reads images 8.. of x5)    */
     int32_t g_fixed;     /* >=0: use this group row of scale/shift instead of the image's */
-    int32_t pad_;
+    int32_t fin_flags;   /* RD_FIN_* when fin != NULL */
+    const void* fin;     /* NULL, or the rd_bn_fwd_t (modes AFF / AFFACT / POOL / UP: it produces scale / shift) resp. rd_bn_bwd_t
+                          * (RD_SRC_BNBWD: P / Q / R) that describes the BatchNorm finalize of this source (a HOST struct like this
+                          * one, read when the entry point is called): the launch runs it as its own prologue -- every workgroup derives
+                          * the coefficient vectors from the statistic slots and writes them where the descriptor says, which is
+                          * where scale / shift / q of this source must point -- instead of an rd_bn_finalize_* launch in front of it
+                          * (training mode, BatchNorm only, at most 8 groups, one such source per launch).  Launches that read the same
+                          * coefficients LATER in stream order need no fin; launches that may run CONCURRENTLY (another stream) each
+                          * carry the fin, exactly one of them with RD_FIN_OWNER.  Honoured by rd_conv, rd_wgrad (dz only) and
+                          * rd_conv_bwd_fused (the gradient descriptor's source); -3 for a fin the launch cannot take */
 } rd_src_t;
 
 /* where a dgrad launch puts the gradient w.r.t. its (virtual) input, i.e. w.r.t. the producer's
@@ -112,7 +133,7 @@ typedef struct {
     int32_t w_tap_rows;  /* rows per tap of the packed array `w` points into when that is MORE than CoutPad: a launch over a 32-row
                           * block of a wider pack (w = pack + first_row * CK elements; honoured by the small-channel kernels, which is
                           * where such launches go); 0: CoutPad */
-    int32_t pad_;
+    int32_t stat_slots;  /* >0: `stats` and dst[].bstats are spread over the first stat_slots copies only (RD_STAT_SLOTS_FOLD); 0: all */
 } rd_conv_t;
 
 int rd_conv(const rd_conv_t* p, int dtype, void* stream);
@@ -199,7 +220,7 @@ typedef struct {
     int32_t C, G;
     float eps, momentum;
     int32_t training;     /* 0: eval -- scale/shift from the running statistics, nothing updated */
-    int32_t pad_;
+    int32_t nslots;       /* rd_src_t.fin only: statistic copies the producers used (0 = all); rd_bn_finalize_fwd sums all of them */
 } rd_bn_fwd_t;
 int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream);
 
@@ -221,6 +242,8 @@ typedef struct {
     const double* fstats;   /* [G][RD_STAT_SLOTS][C][2] the forward statistics of this site */
     const float* conv_bias; /* [C] as in rd_bn_fwd_t (NULL: the forward sums already contain it) */
     float* dbias;           /* [C] += */
+    int32_t nslots;         /* rd_src_t.fin only, as in rd_bn_fwd_t */
+    int32_t pad_;
 } rd_bn_bwd_t;
 int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream);
 
@@ -240,7 +263,7 @@ int rd_gn_finalize_bwd(const rd_bn_bwd_t* p, void* stream);
  * y_out NHWC [N][2h][2w][C] in `dtype` and the statistics are those of the STORED (rounded) values, so that
  * plain RD_SRC_AFFACT / RD_DST_PLAIN readers normalise exactly what was measured. */
 int rd_up_stats(const void* t, double* stats, void* y_out, int N, int h, int w, int C, int G, const int32_t* gstart_host,
-                int dtype, void* stream);
+                int dtype, int stat_slots /* 0: all copies */, void* stream);
 
 /* statistics of a plain NHWC tensor x [N][H][W][C]: stats[G][slot][C][2] += (sum x, sum x^2) -- the standalone
  * nn.BatchNorm2d / DomainSpecificBatchNorm2d.forward (code/networks/dsbn.py:24-27), where no conv produced x. */
@@ -250,17 +273,20 @@ int rd_bn_stats(const void* x, double* stats, int N, int H, int W, int C, int G,
 /* backward of y = up2(t) followed by BN: dt = up2^T( P*g + Q*up2(t) + R ), g: NHWC [N][2h][2w][C],
  * dt/t: NHWC [N][h][w][C]. */
 int rd_up_bwd(const void* g, const void* t, void* dt, const float* P, const float* Q, const float* R, int N, int h,
-              int w, int C, int G, const int32_t* gstart_host, int dtype, void* stream);
+              int w, int C, int G, const int32_t* gstart_host, int dtype, const rd_bn_bwd_t* fin /* NULL, or as rd_src_t.fin: produces P, Q, R */,
+              int fin_flags, void* stream);
 
 /* nn.MaxPool2d(2) at the head of ConvD levels 2-5 (unet.py:45,56), materialised: out[N][Ho][Wo][C] = max over the 2x2 window of
  * act(z*scale+shift) (scale == NULL: identity coefficients; slope 1: no activation), z: NHWC [N][2Ho][2Wo][C].  The conv behind
  * it then reads `out` as a plain tensor in forward, dgrad and wgrad. */
 int rd_pool_fwd(const void* z, const float* scale, const float* shift, float slope, void* out, int N, int Ho, int Wo, int C, int G,
-                const int32_t* gstart_host, int dtype, void* stream);
+                const int32_t* gstart_host, int dtype, const rd_bn_fwd_t* fin /* NULL, or as rd_src_t.fin: produces scale, shift */, int fin_flags,
+                void* stream);
 /* its backward: g[N][2Ho][2Wo][C] (+)= gp scattered to the FIRST maximum of each window (ATen's tie rule), times the
  * activation derivative there when act != 0; bstats (or NULL) += (sum g_new, sum g_new*z) of the scattered values. */
 int rd_pool_bwd(const void* gp, const void* z, const float* scale, const float* shift, float slope, int act, void* g, int accumulate,
-                double* bstats, int N, int Ho, int Wo, int C, int G, const int32_t* gstart_host, int dtype, void* stream);
+                double* bstats, int N, int Ho, int Wo, int C, int G, const int32_t* gstart_host, int dtype,
+                int stat_slots /* 0: all copies */, void* stream);
 
 /* Elementwise materialisation  out = act( a*x + b*x2 + c ; slope )  over NHWC [N][H][W][C] with per-(group, channel)
  * coefficients a, b, c [G][C] (b, x2 may be NULL; slope 1 = no activation):
@@ -406,7 +432,7 @@ enum {
     RD_OP_NCHW_TO_NHWC, RD_OP_NHWC_TO_NCHW, RD_OP_GRAD_IN, RD_OP_COLSUM,
     RD_OP_SEG_LOSS, RD_OP_REC_LOSS, RD_OP_ADAM_STEP, RD_OP_ZERO, RD_OP_RAM_MIX
 };
-#define RD_LAUNCH_MAX_ARGS 17
+#define RD_LAUNCH_MAX_ARGS 18
 typedef struct {
     int32_t op;
     int32_t lane;

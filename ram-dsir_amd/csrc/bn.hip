@@ -5,6 +5,7 @@
 // DomainSpecificBatchNorm2d code/networks/dsbn.py:24-27, nn.Upsample(bilinear, x2) unet.py:84,127.
 #include "common.h"
 #include "../../include/ramdsir.h"
+#include "bn_fin.h"
 
 namespace {
 
@@ -44,22 +45,21 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_fwd_kernel(con
     if (p.training) {
         s1 = wave_sum_d(s1);
         s2 = wave_sum_d(s2);
-        const double cnt = (double)p.count[g];
-        const double m0 = s1 / cnt;                            // mean of the bias-free result
-        double vard = s2 / cnt - m0 * m0;                      // fp64: safe against |mean| >> sigma (ramdsir.h, RD_STAT_SLOTS)
-        if (vard < 0.0) vard = 0.0;
-        const float var = (float)vard;
-        mean = (float)(m0 + (double)cbias);
-        invstd = 1.0f / sqrtf(var + p.eps);
-        unb = cnt > 1.0 ? (float)(vard * cnt / (cnt - 1.0)) : var;
+        const rdfin::FwdStat r = rdfin::fwd_stat(s1, s2, p.count[g], cbias, p.eps);     // shared with the folded finalize (bn_fin.h)
+        mean = r.mean;
+        invstd = r.invstd;
+        unb = r.unb;
     } else {
         mean = rm;
         invstd = 1.0f / sqrtf(rv + p.eps);
     }
     if (lane == 0) {
-        const float sc = gam * invstd;
+        rdfin::FwdStat r;
+        r.mean = mean; r.invstd = invstd; r.unb = unb;
+        float sc, sh;
+        rdfin::fwd_coef(gam, bet, r, sc, sh);
         p.scale[g * p.C + c] = sc;
-        p.shift[g * p.C + c] = bet - mean * sc;
+        p.shift[g * p.C + c] = sh;
         p.mean[g * p.C + c] = mean;
         p.invstd[g * p.C + c] = invstd;
         s_mean[g] = mean; s_unb[g] = unb; s_rm[g] = rm; s_rv[g] = rv;
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_fwd_kernel(con
     if (threadIdx.x != 0) return;
     for (int i = 0; i < p.G; ++i) {
         if (!p.running_mean[i]) continue;
-        const float nm = (1.f - p.momentum) * s_rm[i] + p.momentum * s_mean[i];
-        const float nv = (1.f - p.momentum) * s_rv[i] + p.momentum * s_unb[i];
+        const float nm = rdfin::momentum_step(s_rm[i], s_mean[i], p.momentum);
+        const float nv = rdfin::momentum_step(s_rv[i], s_unb[i], p.momentum);
         p.running_mean[i][c] = nm;
         p.running_var[i][c] = nv;
         for (int j = i + 1; j < p.G; ++j)                  // a later group on the same BatchNorm continues from here
@@ -105,15 +105,13 @@ __global__ __launch_bounds__(64 * RD_MAX_GROUPS) void bn_finalize_bwd_kernel(con
     s1d = wave_sum_d(s1d);
     sgzd = wave_sum_d(sgzd);
     if (lane == 0) {
-        const float cnt = p.count[g];
-        const float s1 = (float)s1d;
-        const float s2 = is * (float)(sgzd - (double)mu * s1d);   // sum g * zhat (the subtraction cancels when |mean| >> sigma: fp64)
-        const float P = gam * is;
-        const float Q = -gam * is * is * s2 / cnt;
+        const rdfin::BwdStat r = rdfin::bwd_stat(s1d, sgzd, mu, is);                     // shared with the folded finalize (bn_fin.h)
+        float P, Q, R;
+        rdfin::bwd_coef(gam, is, mu, r, p.count[g], P, Q, R);
         p.P[g * p.C + c] = P;
         p.Q[g * p.C + c] = Q;
-        p.R[g * p.C + c] = -P * s1 / cnt - Q * mu;
-        s_s1[g] = s1; s_s2[g] = s2;
+        p.R[g * p.C + c] = R;
+        s_s1[g] = r.s1; s_s2[g] = r.s2;
     }
     __syncthreads();
     // dgamma / dbeta: groups on one BatchNorm add into the same element, in group order.  Lane i handles group i (the first group of
@@ -284,7 +282,7 @@ __device__ __forceinline__ void reduce_stats_d(double (&A1)[S], double (&A2)[S],
 
 // sum / sum of squares of the virtual upsampled tensor; grid (blocks, N)
 template <typename T>
-__global__ __launch_bounds__(256) void up_stats_kernel(const T* t, double* stats, T* y_out, int h, int w, int C, GroupMap gm) {
+__global__ __launch_bounds__(256) void up_stats_kernel(const T* t, double* stats, T* y_out, int h, int w, int C, GroupMap gm, int nslots) {
     // One item = the 2 x 2 hi-res pixels between four lo-res pixels (i..i+1, j..j+1; i, j from -1: the image border
     // clamps): those four outputs read the SAME four lo-res vectors with row / column weights {0.25, 0.75}, so an item
     // costs 4 loads and 12 flops per channel for 4 outputs (a pixel-per-item loop needs 16 and 24).  Per output the
@@ -356,7 +354,7 @@ __global__ __launch_bounds__(256) void up_stats_kernel(const T* t, double* stats
     double A1[S], A2[S];
 #pragma unroll
     for (int e = 0; e < S; ++e) unshift(a1[e], a2[e], piv[e], cnt, A1[e], A2[e]);
-    const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
+    const int slot = (blockIdx.x + 7 * blockIdx.y) % nslots;
     reduce_stats_d<S>(A1, A2, s_redd, SL, sl, stats + ((size_t)g * RD_STAT_SLOTS + slot) * C * 2, C);
 }
 
@@ -400,9 +398,10 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* x, double* stats
 // in each of them.  grid (blocks, N); one item = one pooled pixel x one 16-byte channel slot.
 template <typename T>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* z, const float* scale, const float* shift, float slope, T* out,
-                                                       int Ho, int Wo, int C, GroupMap gm) {
+                                                       int Ho, int Wo, int C, GroupMap gm, const rdfin::FinArg fa) {
     constexpr int S = Slot<T>::N;
     extern __shared__ float s_cf[];                        // [2][C]
+    rdfin::prologue(fa);                                   // the producer's BatchNorm finalize folded into this launch (bn_fin.h)
     const int n = blockIdx.y, g = group_of(gm, n);
     for (int i = threadIdx.x; i < C; i += blockDim.x) {
         s_cf[i] = scale ? scale[g * C + i] : 1.f;
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* z, const float* 
 template <typename T, bool ACC>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* gp, const T* z, const float* scale, const float* shift, float slope,
                                                        int act, T* gout, double* bstats, int Ho, int Wo, int C,
-                                                       GroupMap gm) {
+                                                       GroupMap gm, int nslots) {
     constexpr int S = Slot<T>::N;
     extern __shared__ double s_redd[];                     // [C][2], then [2][C] floats of coefficients
     float* s_cf = reinterpret_cast<float*>(s_redd + 2 * C);
@@ -499,7 +498,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* gp, const T* z, 
     double A1[S], A2[S];
 #pragma unroll
     for (int e = 0; e < S; ++e) { A1[e] = (double)b1[e]; A2[e] = (double)b2[e]; }
-    const int slot = (blockIdx.x + 7 * blockIdx.y) % RD_STAT_SLOTS;
+    const int slot = (blockIdx.x + 7 * blockIdx.y) % nslots;
     reduce_stats_d<S>(A1, A2, s_redd, SL, sl, bstats + ((size_t)g * RD_STAT_SLOTS + slot) * C * 2, C);
 }
 
@@ -525,8 +524,9 @@ __device__ __forceinline__ void up_adjoint_1d(int y, int h, float* wy, float* A)
 
 template <typename T>
 __global__ __launch_bounds__(256) void up_bwd_kernel(const T* g2, const T* t, T* dt, const float* P, const float* Q,
-                                                     const float* R, int h, int w, int C, GroupMap gm) {
+                                                     const float* R, int h, int w, int C, GroupMap gm, const rdfin::FinArg fa) {
     constexpr int S = Slot<T>::N;
+    rdfin::prologue(fa);                                   // the BatchNorm-backward finalize folded into this launch (bn_fin.h)
     const int n = blockIdx.y, gi = group_of(gm, n);
     const int SL = C / S;
     const int items = h * w * SL;
@@ -761,9 +761,10 @@ int rd_gn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
 }
 
 int rd_up_stats(const void* t, double* stats, void* y_out, int N, int h, int w, int C, int G, const int32_t* gstart_host, int dtype,
-                void* stream) {
+                int stat_slots, void* stream) {
     const int S = dtype == RD_BF16 ? 8 : 4;
-    if (C % S || 256 % (C / S)) return -2;
+    if (C % S || 256 % (C / S) || stat_slots < 0 || stat_slots > RD_STAT_SLOTS) return -2;
+    const int nslots = stat_slots > 0 ? stat_slots : RD_STAT_SLOTS;
     const GroupMap gm = host_gm(G, gstart_host);
     const int items = (h + 1) * (w + 1) * (C / S);                     // 2 x 2 output pixels per item
     static const int us_per = rd_switch("RD_UPS_PER", 2);
@@ -771,10 +772,10 @@ int rd_up_stats(const void* t, double* stats, void* y_out, int N, int h, int w, 
     dim3 grid(bx, N);
     if (dtype == RD_BF16)
         hipLaunchKernelGGL(up_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream,
-                           (const bf16_t*)t, stats, (bf16_t*)y_out, h, w, C, gm);
+                           (const bf16_t*)t, stats, (bf16_t*)y_out, h, w, C, gm, nslots);
     else
         hipLaunchKernelGGL(up_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream,
-                           (const float*)t, stats, (float*)y_out, h, w, C, gm);
+                           (const float*)t, stats, (float*)y_out, h, w, C, gm, nslots);
     return (int)hipGetLastError();
 }
 
@@ -793,25 +794,37 @@ int rd_bn_stats(const void* x, double* stats, int N, int H, int W, int C, int G,
 }
 
 int rd_pool_fwd(const void* z, const float* scale, const float* shift, float slope, void* out, int N, int Ho, int Wo, int C, int G,
-                const int32_t* gstart_host, int dtype, void* stream) {
+                const int32_t* gstart_host, int dtype, const rd_bn_fwd_t* fin, int fin_flags, void* stream) {
     const int S = dtype == RD_BF16 ? 8 : 4;
     if (!z || !out || C % S || C > 1024) return -2;
     if (G < 1 || G > RD_MAX_GROUPS) return -1;
+    rdfin::FinArg fa;
+    rdfin::no_arg(fa);
+    if (fin) {
+        rd_src_t s;
+        memset(&s, 0, sizeof(s));
+        s.fin = fin;
+        s.fin_flags = fin_flags;
+        s.mode = RD_SRC_AFFACT;
+        s.C = C;
+        if (!scale || !shift || fin->scale != scale || fin->shift != shift || rdfin::make_arg(fa, &s, 1)) return -3;
+    }
     const GroupMap gm = host_gm(G, gstart_host);
     dim3 grid(grid_for((size_t)Ho * Wo * (C / S), 256 * 4, 2048), N);
     if (dtype == RD_BF16)
         hipLaunchKernelGGL(pool_fwd_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const bf16_t*)z, scale, shift,
-                           slope, (bf16_t*)out, Ho, Wo, C, gm);
+                           slope, (bf16_t*)out, Ho, Wo, C, gm, fa);
     else
         hipLaunchKernelGGL(pool_fwd_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const float*)z, scale, shift,
-                           slope, (float*)out, Ho, Wo, C, gm);
+                           slope, (float*)out, Ho, Wo, C, gm, fa);
     return (int)hipGetLastError();
 }
 
 int rd_pool_bwd(const void* gp, const void* z, const float* scale, const float* shift, float slope, int act, void* g, int accumulate,
-                double* bstats, int N, int Ho, int Wo, int C, int G, const int32_t* gstart_host, int dtype, void* stream) {
+                double* bstats, int N, int Ho, int Wo, int C, int G, const int32_t* gstart_host, int dtype, int stat_slots, void* stream) {
     const int S = dtype == RD_BF16 ? 8 : 4;
-    if (!gp || !z || !g || C % S || C > 1024 || 256 % (C / S)) return -2;
+    if (!gp || !z || !g || C % S || C > 1024 || 256 % (C / S) || stat_slots < 0 || stat_slots > RD_STAT_SLOTS) return -2;
+    const int nslots = stat_slots > 0 ? stat_slots : RD_STAT_SLOTS;
     if (G < 1 || G > RD_MAX_GROUPS) return -1;
     const GroupMap gm = host_gm(G, gstart_host);
     dim3 grid(grid_for((size_t)Ho * Wo * (C / S), 256 * 4, 2048), N);
@@ -819,17 +832,17 @@ int rd_pool_bwd(const void* gp, const void* z, const float* scale, const float* 
     if (dtype == RD_BF16) {
         if (accumulate)
             hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, true>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale,
-                               shift, slope, act, (bf16_t*)g, bstats, Ho, Wo, C, gm);
+                               shift, slope, act, (bf16_t*)g, bstats, Ho, Wo, C, gm, nslots);
         else
             hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, false>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale,
-                               shift, slope, act, (bf16_t*)g, bstats, Ho, Wo, C, gm);
+                               shift, slope, act, (bf16_t*)g, bstats, Ho, Wo, C, gm, nslots);
     } else {
         if (accumulate)
             hipLaunchKernelGGL((pool_bwd_kernel<float, true>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
-                               slope, act, (float*)g, bstats, Ho, Wo, C, gm);
+                               slope, act, (float*)g, bstats, Ho, Wo, C, gm, nslots);
         else
             hipLaunchKernelGGL((pool_bwd_kernel<float, false>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
-                               slope, act, (float*)g, bstats, Ho, Wo, C, gm);
+                               slope, act, (float*)g, bstats, Ho, Wo, C, gm, nslots);
     }
     return (int)hipGetLastError();
 }
@@ -852,17 +865,28 @@ int rd_bn_apply(const void* x, const void* x2, void* out, const float* a, const 
 }
 
 int rd_up_bwd(const void* g, const void* t, void* dt, const float* P, const float* Q, const float* R, int N, int h, int w,
-              int C, int G, const int32_t* gstart_host, int dtype, void* stream) {
+              int C, int G, const int32_t* gstart_host, int dtype, const rd_bn_bwd_t* fin, int fin_flags, void* stream) {
     const int S = dtype == RD_BF16 ? 8 : 4;
     if (C % S) return -2;
+    rdfin::FinArg fa;
+    rdfin::no_arg(fa);
+    if (fin) {
+        rd_src_t s;
+        memset(&s, 0, sizeof(s));
+        s.fin = fin;
+        s.fin_flags = fin_flags;
+        s.mode = RD_SRC_BNBWD;
+        s.C = C;
+        if (fin->P != P || fin->Q != Q || fin->R != R || rdfin::make_arg(fa, &s, 1)) return -3;
+    }
     const GroupMap gm = host_gm(G, gstart_host);
     dim3 grid(grid_for((size_t)h * w * (C / S), 256, 1024), N);
     if (dtype == RD_BF16)
         hipLaunchKernelGGL(up_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)t,
-                           (bf16_t*)dt, P, Q, R, h, w, C, gm);
+                           (bf16_t*)dt, P, Q, R, h, w, C, gm, fa);
     else
         hipLaunchKernelGGL(up_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)t,
-                           (float*)dt, P, Q, R, h, w, C, gm);
+                           (float*)dt, P, Q, R, h, w, C, gm, fa);
     return (int)hipGetLastError();
 }
 

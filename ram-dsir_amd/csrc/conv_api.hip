@@ -2,6 +2,7 @@
 #include "common.h"
 #include "../../include/ramdsir.h"
 #include "conv_dispatch.h"
+#include "bn_fin.h"
 
 namespace {
 
@@ -68,7 +69,11 @@ __global__ void pack_weights_batched_kernel(const float* params, T* packed, cons
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+thread_local rdfin::FinArg t_fin_arg;                          // the folded-finalize argument of the entry point in progress on this thread
+
 }  // namespace
+
+rdfin::FinArg& rdfin::current() { return t_fin_arg; }
 
 
 extern "C" {
@@ -118,6 +123,7 @@ int rd_conv(const rd_conv_t* p, int dtype, void* stream) {
     const int ck = dtype == RD_BF16 ? 32 : 16;
     if (p->CinPad % ck || p->CoutPad % 32 || p->CinPad < p->Cin || p->CoutPad < p->Cout) return -2;
     hipStream_t st = (hipStream_t)stream;
+    if (rdfin::make_arg(rdfin::current(), p->src, p->nsrc)) return -3;                // rd_src_t.fin: copied into the kernel arguments
     if (p->w_tap_rows && !(p->CinPad == ck && p->CoutPad == 32 && p->emode == 1 && p->w_tap_rows >= p->CoutPad)) return -2;   // ramdsir.h
     if (p->CinPad == ck && p->CoutPad == 32) return rd_conv_small_dispatch(*p, dtype, st);   // one K chunk, one N block
     return rd_conv_big_dispatch(*p, dtype, st);
@@ -137,6 +143,8 @@ int64_t rd_wgrad_workspace(const rd_wgrad_t* p, int dtype) {
 
 int rd_wgrad(const rd_wgrad_t* p, int dtype, void* stream) {
     if (!p || (p->taps != 9 && p->taps != 1) || p->G < 1 || p->G > RD_MAX_GROUPS || p->na < 1 || p->na > 2) return -1;
+    if (p->a[0].fin || (p->na > 1 && p->a[1].fin)) return -3;                         // only dz may carry a folded finalize (ramdsir.h)
+    if (rdfin::make_arg(rdfin::current(), &p->dz, 1)) return -3;
     return rd_wgrad_dispatch(*p, dtype, (hipStream_t)stream);
 }
 
@@ -153,6 +161,7 @@ int64_t rd_conv_bwd_fused_workspace(const rd_conv_t* dgrad, const rd_wgrad_t* wg
 
 int rd_conv_bwd_fused(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype, void* stream) {
     if (!rd_conv_bwd_fused_ok(dgrad, wgrad, dtype) || !wgrad->partial || !wgrad->dW) return -1;
+    if (rdfin::make_arg(rdfin::current(), dgrad->src, dgrad->nsrc)) return -3;          // the gradient descriptor's dz carries it; wgrad->dz.fin is ignored
     return rd_bwd_fused_dispatch(*dgrad, *wgrad, (hipStream_t)stream);
 }
 

@@ -22,7 +22,8 @@ namespace {
 
 // ------------------------------------------------------------------------------------ conv kernel
 template <typename T, int TAPS, int NB>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
+__global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p, const rdfin::FinArg fa) {
+    rdfin::prologue(fa);                                // BatchNorm finalize folded into this launch (bn_fin.h)
     constexpr int S = Slot<T>::N;
     constexpr int CK = 4 * S;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const rd_conv_t p) {
     const GroupMap gm = make_gm(p.gstart, p.G);
     const int g = group_of(gm, n);
     const int H = p.H, W = p.W;
-    const int slot = (bx + 7 * bz) % RD_STAT_SLOTS;
+    const int slot = (bx + 7 * bz) % rd_stat_nslots(p.stat_slots);
 
     f32x16 acc[2][NB];
 #pragma unroll
@@ -137,12 +138,12 @@ int launch_conv(const rd_conv_t& p, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
                 attr_pf = true;
             }
-            if (nq == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1>), grid, dim3(256), lds, st, p);
-            else hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 2>), grid, dim3(256), lds, st, p);
+            if (nq == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1>), grid, dim3(256), lds, st, p, rdfin::current());
+            else hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 2>), grid, dim3(256), lds, st, p, rdfin::current());
             return (int)hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((conv_kernel<T, TAPS, NB>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_kernel<T, TAPS, NB>), grid, dim3(256), lds, st, p, rdfin::current());
     return (int)hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "../../include/ramdsir.h"
+#include "bn_fin.h"
 #include <stdlib.h>
 
 namespace {
@@ -80,6 +81,16 @@ struct SlotCtx {
     int c;         // channel within the source
     float sc[S], sh[S], q[S];
 };
+
+// the geometry part of slot_ctx alone: which source channel c belongs to (no coefficient loads)
+template <typename T>
+__device__ __forceinline__ void slot_geom(SlotCtx<T>& k, const rd_src_t* src, int nsrc, int Cin, int c) {
+    k.si = -1;
+    k.c = 0;
+    if (c >= Cin) return;
+    k.si = (nsrc == 1 || c < src[0].C) ? 0 : 1;
+    k.c = c - (k.si ? src[0].C : 0);
+}
 
 template <typename T>
 __device__ __forceinline__ void slot_ctx(SlotCtx<T>& k, const rd_src_t* src, int nsrc, int Cin, int g_img, int c) {
@@ -215,7 +226,8 @@ __device__ __forceinline__ rd_src_t select_src(const rd_src_t* src, int si) {
     s.slope = si ? src[1].slope : src[0].slope;
     s.n_off = si ? src[1].n_off : src[0].n_off;
     s.g_fixed = si ? src[1].g_fixed : src[0].g_fixed;
-    s.pad_ = 0;
+    s.fin_flags = 0;
+    s.fin = nullptr;
     return s;
 }
 

@@ -56,7 +56,8 @@ constexpr int FZ_IN_BYTES = FZ_NPIX * 64 + 256 * 16;
 __device__ uint4 fz_trash[256];                          // where the gradient stores of lanes without a destination pixel go
 constexpr int FZ_A_BYTES = TH * TW * 64;                                     // one `a` tile buffer
 constexpr int FZ_W_BYTES = 9 * 32 * 64;
-constexpr int FZ_LDS = 3 * FZ_IN_BYTES + 2 * FZ_A_BYTES + FZ_W_BYTES + 64 * 8 + (32 + 32) * 4;
+constexpr int FZ_FIN = 3 * FZ_IN_BYTES + 2 * FZ_A_BYTES + FZ_W_BYTES + 64 * 8 + (32 + 32) * 4;   // coefficient table of a folded finalize (bn_fin.h)
+constexpr int FZ_LDS = FZ_FIN + rdfin::FIN_LDS_FLOATS * 4;
 
 // NSL: live 16-byte channel slots of dz (1, 2 or 4: compile-time item count); NQ: 2 = BatchNorm-backward source (g and z), 1 = a stored
 // dz / dlogits (copied as it is).
@@ -68,7 +69,7 @@ constexpr int FZ_LDS = 3 * FZ_IN_BYTES + 2 * FZ_A_BYTES + FZ_W_BYTES + 64 * 8 + 
 #define FZ_XP(bit) false
 #endif
 template <int NSL, int NQ>
-__global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_conv_t p, const FusedWg w, int tiles_per_wg) {
+__global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_conv_t p, const FusedWg w, int tiles_per_wg, const rdfin::FinArg fa) {
     typedef bf16_t T;
     constexpr int S = 8, NT = 32, NV = 2;
     constexpr int NSH = NSL == 1 ? 0 : (NSL == 2 ? 1 : 2);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
     const int n = blockIdx.z;
     const GroupMap gm = make_gm(p.gstart, p.G);
     const int g = group_of(gm, n);
-    const int slot = (blockIdx.x + 7 * blockIdx.z) % RD_STAT_SLOTS;
+    const int slot = (blockIdx.x + 7 * blockIdx.z) % rd_stat_nslots(p.stat_slots);
 
     // ---- LDS prologue (all 512 threads): zero the tile buffers (channel slots beyond the live ones stay zero), the packed
     //      dgrad weights, the per-channel coefficients of the forward input
@@ -119,13 +120,16 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
             s_dsh[c] = aff ? as.shift[ga * as.C + cdd] : 0.f;
         }
     }
+    // BatchNorm-backward finalize of this layer folded into the launch (bn_fin.h): P / Q / R reach the loader waves through LDS (src[])
+    rd_src_t src[2];
+    rdfin::conv_prologue_lds(p, fa, reinterpret_cast<float*>(smem + FZ_FIN), rdfin::FIN_LDS_FLOATS, src);
     __syncthreads();
 
     if (role == 1) {
         // =============================================================================== loader + weight-gradient waves
         const int sslot = tid & (NSL - 1);
         const bool live_slot = sslot * S < p.Cin;
-        const rd_src_t ssrc = select_src(p.src, 0);
+        const rd_src_t ssrc = select_src(src, 0);
         PlainSrc<T> ps;
         plain_src_init<T>(ps, ssrc, live_slot ? sslot * S : 0);
         plain_src_coef<T>(ps, ssrc, g, live_slot ? sslot * S : 0);
@@ -444,7 +448,7 @@ int fused_launch_one(dim3 grid, hipStream_t st, const rd_conv_t& p, const FusedW
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_bwd_fused_kernel<NSL, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_small_bwd_fused_kernel<NSL, NQ>), grid, dim3(512), FZ_LDS, st, p, fw, tpw);
+    hipLaunchKernelGGL((conv_small_bwd_fused_kernel<NSL, NQ>), grid, dim3(512), FZ_LDS, st, p, fw, tpw, rdfin::current());
     return (int)hipGetLastError();
 }
 int fused_launch(int nsl, int nq, dim3 grid, hipStream_t st, const rd_conv_t& p, const FusedWg& fw, int tpw) {

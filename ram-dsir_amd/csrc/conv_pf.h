@@ -65,7 +65,8 @@ int conv_pf_kind(const rd_conv_t& p) {
 // EP: 0 = LDS-staged epilogue (conv_epilogue), 1 / 2 = register epilogue forward / plain gradient (conv_epilogue_lean)
 // TS: output-tile shape (conv_device.h TileGeo; the LDS-staged epilogue EP 0 knows shape 0 only)
 template <typename T, int TAPS, int NB, int NQ, int EP = 0, int TS = 0>
-__global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
+__global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p, const rdfin::FinArg fa) {
+    rdfin::prologue(fa);                                // BatchNorm finalize folded into this launch (bn_fin.h)
     static_assert(TS == 0 || EP != 0, "tile shapes other than 8x32 need a register epilogue");
     constexpr int S = Slot<T>::N;
     constexpr int CK = 4 * S;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_pf_kernel(const rd_conv_t p) {
     const GroupMap gm = make_gm(p.gstart, p.G);
     const int g = group_of(gm, n);
     const int H = p.H, W = p.W;
-    const int slot = (bx + 7 * bz) % RD_STAT_SLOTS;
+    const int slot = (bx + 7 * bz) % rd_stat_nslots(p.stat_slots);
 
     f32x16 acc[2][NB];
 #pragma unroll

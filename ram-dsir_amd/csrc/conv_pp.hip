@@ -116,7 +116,8 @@ __device__ __forceinline__ void pp_advance(PpStage& s, const PpGeo& q, const Gro
 
 // The epilogue is the LDS-staged one of conv_epilogue.h (any destination kind).  Launches that qualify for a register
 // epilogue (forward, gradient into plain tensors) go to conv_ws_kernel below instead.
-__global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int tiles_total) {
+__global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int tiles_total, const rdfin::FinArg fa) {
+    rdfin::prologue(fa);                                // BatchNorm finalize folded into this launch (bn_fin.h)
     typedef bf16_t T;
     constexpr int S = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int 
             __builtin_amdgcn_sched_barrier(0);
         }
         if (M.c == q.nch - 1) {
-            const int slot = (M.txy + 7 * M.n) % RD_STAT_SLOTS;
+            const int slot = (M.txy + 7 * M.n) % rd_stat_nslots(p.stat_slots);
             conv_epilogue<T, 2>(p, acc, smem + PP_EPI, tid, M.n, M.g, M.y0, M.x0, M.n0, slot);
         }
         M = Cs;
@@ -371,7 +372,10 @@ __device__ unsigned long long ws_trace[2][64][4];          // [role][step][event
 // the loader's vector-memory operations stay countable.
 __device__ uint4 ws_trash[256];
 template <int MODE, int TS, bool BWD2 = false, bool SOUT = false>
-__global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int tiles_total) {
+__global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int tiles_total, const rdfin::FinArg fa) {
+    // BatchNorm finalize folded into this launch (bn_fin.h), global path: the loader waves fetch the coefficients with global loads
+    // every step (ldf4g below: not flat loads, which would tie up the LDS counter), so the vectors must be in memory
+    rdfin::prologue(fa);
     typedef bf16_t T;
     constexpr int S = 8;
     static_assert(MODE == 1 || MODE == 2, "register epilogues only");
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             for (int e = 0; e < S; ++e) sa[nb][v][e] = sb[nb][v][e] = 0.f;
     auto flush_stats = [&]() {
         if (cur_n0 < 0) return;
-        const int slot = blockIdx.x % RD_STAT_SLOTS;
+        const int slot = blockIdx.x % rd_stat_nslots(p.stat_slots);
         // sums over the 32 pixel lanes of each half-wave (conv_device.h half_wave_sums): afterwards every lane holds BOTH statistics
         // of one channel and adds them to the global fp64 slot itself
         float r[64];
@@ -1062,20 +1066,20 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         for (int i = 0; i < p.nsrc; ++i) sout = sout || p.src[i].out != nullptr;
         sout = sout && rd_conv_ws_stores_sources(p);
         if (mode == 1 && sout) {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1, false, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
-            else hipLaunchKernelGGL((conv_ws_kernel<1, 0, false, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1, false, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else hipLaunchKernelGGL((conv_ws_kernel<1, 0, false, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         } else if (mode == 1) {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
-            else hipLaunchKernelGGL((conv_ws_kernel<1, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else hipLaunchKernelGGL((conv_ws_kernel<1, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         } else if (skind == 2 && sout) {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1, true, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
-            else hipLaunchKernelGGL((conv_ws_kernel<2, 0, true, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1, true, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else hipLaunchKernelGGL((conv_ws_kernel<2, 0, true, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         } else if (skind == 2) {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
-            else hipLaunchKernelGGL((conv_ws_kernel<2, 0, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else hipLaunchKernelGGL((conv_ws_kernel<2, 0, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         } else {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg);
-            else hipLaunchKernelGGL((conv_ws_kernel<2, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg);
+            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else hipLaunchKernelGGL((conv_ws_kernel<2, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         }
         return (int)hipGetLastError();
     }
@@ -1084,6 +1088,6 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     // epilogue (2100 VALU per tile and wave at one workgroup per CU) costs more than the pipelined K loop gains.
     static const bool pp_all = rd_switch("RD_CONV_PP_ALL", 0) != 0;
     if (tiles > n_cu && !pp_all) return RD_CONV_PP_NA;
-    hipLaunchKernelGGL(conv_pp_kernel, dim3(grid), dim3(256), PP_LDS, st, p, tiles);
+    hipLaunchKernelGGL(conv_pp_kernel, dim3(grid), dim3(256), PP_LDS, st, p, tiles, rdfin::current());
     return (int)hipGetLastError();
 }

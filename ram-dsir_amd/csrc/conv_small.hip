@@ -9,7 +9,7 @@ namespace {
 // EPI : 0 forward, 1 gradient with plain full-slot destinations only (lean path), 3 plain + upsample-side,
 //       4 plain + max-pool, 2 anything.
 template <typename T, int TAPS, bool SRCG, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, int tiles_per_wg) {
+__global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, int tiles_per_wg, const rdfin::FinArg fa) {
     constexpr int S = Slot<T>::N;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
     double* s_red = reinterpret_cast<double*>(s_w + TAPS * NT * 4);  // [32][2], fp64: see conv_device.h flush_bstats
     float* s_dsc = reinterpret_cast<float*>(s_red + 64);                             // [32] producer scale of the gradient destinations
     float* s_dsh = s_dsc + 32;                             // [32] producer shift
+    float* s_fin = s_dsh + 32;                             // [rdfin::FIN_LDS_FLOATS] coefficient table of a folded finalize (bn_fin.h)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
     const int n = blockIdx.z;
     const GroupMap gm = make_gm(p.gstart, p.G);
     const int g = group_of(gm, n);
-    const int slot = (blockIdx.x + 7 * blockIdx.z) % RD_STAT_SLOTS;
+    const int slot = (blockIdx.x + 7 * blockIdx.z) % rd_stat_nslots(p.stat_slots);
 
     // ---- LDS prologue: zero the input tile once (channel slots beyond Cin stay zero for every tile), packed
     //      weights once per workgroup, destination BN coefficients of the gradient epilogues
@@ -88,9 +89,13 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
         ig.px[b] = (short)(pix - (pix / PW) * PW);
         ig.lds[b] = pixi < NPIX ? pix * 4 + (sslot ^ ((pix >> 2) & 3)) : -1;
     }
+    // BatchNorm finalize of the producer folded into this launch (bn_fin.h), behind the weight loads: the coefficients reach slot_ctx
+    // through LDS (src[] points there)
+    rd_src_t src[2];
+    rdfin::conv_prologue_lds(p, fa, s_fin, rdfin::FIN_LDS_FLOATS, src);
     SlotCtx<T> ctx;
-    slot_ctx<T>(ctx, p.src, p.nsrc, p.Cin, g, sslot * S);
-    const rd_src_t ssrc = select_src(p.src, ctx.si > 0 ? 1 : 0);
+    slot_ctx<T>(ctx, src, p.nsrc, p.Cin, g, sslot * S);
+    const rd_src_t ssrc = select_src(src, ctx.si > 0 ? 1 : 0);
     const bool live_slot = ctx.si >= 0;
     bool pre = true;
     if constexpr (SRCG)
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
                 const int pix = idx >> 2;
                 s_in[pix * 4 + (sslot ^ ((pix >> 2) & 3))] = u;
             };
-            if (live_slot) tile_fill<T>(p.src, ctx, n, H, W, tid, NPIX * 4, map, store);
+            if (live_slot) tile_fill<T>(src, ctx, n, H, W, tid, NPIX * 4, map, store);
         }
         __syncthreads();
         if (pre && live_slot && t + 1 < t_end)
@@ -268,7 +273,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
 // Variant with the accumulators staged through LDS ([256 pixels][32 ch] fp32): used where the register epilogue
 // of conv_small_kernel would spill (max-pool / upsample-side destinations, generic sources).
 template <typename T, int TAPS, bool SRCG, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_t p, int tiles_per_wg) {
+__global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_t p, int tiles_per_wg, const rdfin::FinArg fa) {
+    rdfin::prologue(fa);                                // BatchNorm finalize folded into this launch (bn_fin.h)
     constexpr int S = Slot<T>::N;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_stage_kernel(const rd_conv_
     const int n = blockIdx.z;
     const GroupMap gm = make_gm(p.gstart, p.G);
     const int g = group_of(gm, n);
-    const int slot = (blockIdx.x + 7 * blockIdx.z) % RD_STAT_SLOTS;
+    const int slot = (blockIdx.x + 7 * blockIdx.z) % rd_stat_nslots(p.stat_slots);
 
     // ---- packed weights: once per workgroup
     {
@@ -484,7 +490,8 @@ int launch_conv_small(const rd_conv_t& p, hipStream_t st) {
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
     constexpr bool REG_EPI = !SRCG && EPI <= 1;            // register epilogue where it stays spill-free
     const size_t lds = (size_t)(PH * PW * 4 + TAPS * 32 * 4) * sizeof(uint4) +
-                       (REG_EPI ? (size_t)64 * sizeof(double) + 64 * sizeof(float) : (size_t)TH * TW * 32 * sizeof(float) + 64 * sizeof(double));
+                       (REG_EPI ? (size_t)64 * sizeof(double) + 64 * sizeof(float) + rdfin::FIN_LDS_FLOATS * sizeof(float)
+                                : (size_t)TH * TW * 32 * sizeof(float) + 64 * sizeof(double));
     const int ntiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
     static int tpw_env = -1;
     if (tpw_env < 0) tpw_env = rd_switch("RD_TPW", 0);
@@ -514,14 +521,14 @@ int launch_conv_small(const rd_conv_t& p, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_small_kernel<T, TAPS, SRCG, EPI>), grid, dim3(256), lds, st, p, tpw);
+        hipLaunchKernelGGL((conv_small_kernel<T, TAPS, SRCG, EPI>), grid, dim3(256), lds, st, p, tpw, rdfin::current());
     } else {
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_stage_kernel<T, TAPS, SRCG, EPI>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_small_stage_kernel<T, TAPS, SRCG, EPI>), grid, dim3(256), lds, st, p, tpw);
+        hipLaunchKernelGGL((conv_small_stage_kernel<T, TAPS, SRCG, EPI>), grid, dim3(256), lds, st, p, tpw, rdfin::current());
     }
     return (int)hipGetLastError();
 }

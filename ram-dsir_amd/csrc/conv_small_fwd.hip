@@ -31,7 +31,8 @@ namespace {
 
 constexpr int SW_PH = TH + 2, SW_PW = TW + 2, SW_NPIX = SW_PH * SW_PW;      // 10 x 34 halo tile
 constexpr int SW_BUF_BYTES = SW_NPIX * 64 + 64;                             // + one dummy record (items that do not exist)
-constexpr int SW_LDS = 2 * SW_BUF_BYTES + 64 * 8 + 32 * 4;
+constexpr int SW_FIN = 2 * SW_BUF_BYTES + 64 * 8 + 32 * 4;                   // coefficient table of a folded BatchNorm finalize (bn_fin.h)
+constexpr int SW_LDS = SW_FIN + rdfin::FIN_LDS_FLOATS * 4;
 constexpr int SW_NSET = 3;                                                 // 2: the same step (4.85 ms), 5 for the <=16-channel inputs: 4.91
 
 __device__ uint4 sw_trash[1024];                         // where the stores of lanes without an output pixel go
@@ -43,7 +44,7 @@ __device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // NSL: live 16-byte channel slots of the input: 1, 2 or 4.  OUTV: 16-byte output vectors per lane: 2 (Cout 32), 1 (Cout 16), 3 (Cout <= 4:
 // the network's output layers, four unconditional scalar stores per lane), 0 (any other Cout, element-wise conditional stores)
 template <int NSL, int OUTV, int XP>
-__global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t p, int tiles_per_wg) {
+__global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t p, int tiles_per_wg, const rdfin::FinArg fa) {
     typedef bf16_t T;
     constexpr int S = 8, NV = 2;
     constexpr int NKS = NSL <= 2 ? 1 : 2;                // k-steps of 16 channels
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     const int n = blockIdx.z;
     const GroupMap gm = make_gm(p.gstart, p.G);
     const int g = group_of(gm, n);
-    const int slot = (blockIdx.x + 7 * blockIdx.z) % RD_STAT_SLOTS;
+    const int slot = (blockIdx.x + 7 * blockIdx.z) % rd_stat_nslots(p.stat_slots);
 
     // ---- prologue: zero the tile buffers (channel slots beyond Cin stay zero), bias table, this lane's weight fragments
     {
@@ -82,20 +83,17 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
             for (int ks = 0; ks < NKS; ++ks) wreg[tap][ks] = ld16(wbase + (size_t)tap * p.CoutPad * p.CinPad + ks * 2 * S);
     }
 
-    // ---- loader constants
+    // ---- loader constants.  The geometry first (which source and channel this thread's slot is): the BatchNorm coefficients sc / sh are
+    //      filled in below, BEHIND the first tile requests -- with a folded finalize (bn_fin.h) they come out of this launch's own prologue,
+    //      whose memory round trip then runs beside the tiles'
     const int sslot = tid & (NSL - 1);
     SlotCtx<T> ctx;
-    slot_ctx<T>(ctx, p.src, p.nsrc, p.Cin, g, sslot * S);
+    slot_geom<T>(ctx, p.src, p.nsrc, p.Cin, sslot * S);
     const bool live_slot = ctx.si >= 0;
     const rd_src_t ssrc = select_src(p.src, ctx.si > 0 ? 1 : 0);
     const bool rawm = ssrc.mode == RD_SRC_RAW;
     const float slope = ssrc.mode == RD_SRC_AFFACT ? ssrc.slope : 1.f;
     float sc[S], sh[S];
-#pragma unroll
-    for (int e = 0; e < S; ++e) {
-        sc[e] = rawm ? 1.f : ctx.sc[e];
-        sh[e] = rawm ? 0.f : ctx.sh[e];
-    }
     // wave-uniform transform kind: 0 copy (raw tensors), 1 affine + ReLU (every BatchNorm + ReLU producer), 2 general
     const int kind = __builtin_amdgcn_ballot_w64(!(rawm || !live_slot)) == 0 ? 0
                    : (__builtin_amdgcn_ballot_w64(live_slot && !(ssrc.mode == RD_SRC_AFFACT && ssrc.slope == 0.f)) == 0 ? 1 : 2);
@@ -344,6 +342,17 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     };
 #pragma unroll
     for (int k = 0; k < SW_NSET; ++k) { issue(raw[k], qi); advance(qi); if (k) fake_stores(); }
+    {
+        // BatchNorm finalize of the producer folded into this launch: the coefficients reach slot_ctx through LDS (src[] points there)
+        rd_src_t src[2];
+        rdfin::conv_prologue_lds(p, fa, reinterpret_cast<float*>(smem + SW_FIN), rdfin::FIN_LDS_FLOATS, src);
+        slot_ctx<T>(ctx, src, p.nsrc, p.Cin, g, sslot * S);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            sc[e] = rawm ? 1.f : ctx.sc[e];
+            sh[e] = rawm ? 0.f : ctx.sh[e];
+        }
+    }
     __syncthreads();                                         // zero-fill done before the first transformed tile lands
     consume(raw[0], ql);
     advance(ql);
@@ -435,7 +444,7 @@ int rd_conv_small_fwd_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_fwd_kernel<NSL, OUTV, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS); \
             attr_set = true; \
         } \
-        hipLaunchKernelGGL((conv_small_fwd_kernel<NSL, OUTV, XP>), grid, dim3(512), SW_LDS, st, p, tpw); \
+        hipLaunchKernelGGL((conv_small_fwd_kernel<NSL, OUTV, XP>), grid, dim3(512), SW_LDS, st, p, tpw, rdfin::current()); \
         return (int)hipGetLastError(); \
     } while (0)
 #ifdef RD_DEBUG_SWITCHES

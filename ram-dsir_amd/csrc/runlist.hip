@@ -74,13 +74,17 @@ int call(const rd_launch_t& o, void* st) {
     case RD_OP_BN_FINALIZE_BWD: NARGS(1); return rd_bn_finalize_bwd(CP(rd_bn_bwd_t, 0), st);
     case RD_OP_GN_FINALIZE_FWD: NARGS(1); return rd_gn_finalize_fwd(CP(rd_bn_fwd_t, 0), st);
     case RD_OP_GN_FINALIZE_BWD: NARGS(1); return rd_gn_finalize_bwd(CP(rd_bn_bwd_t, 0), st);
-    case RD_OP_UP_STATS: NARGS(10); return rd_up_stats(P(0), (double*)P(1), P(2), I(3), I(4), I(5), I(6), I(7), CP(int32_t, 8), I(9), st);
+    case RD_OP_UP_STATS: NARGS(11); return rd_up_stats(P(0), (double*)P(1), P(2), I(3), I(4), I(5), I(6), I(7), CP(int32_t, 8), I(9), I(10), st);
     case RD_OP_BN_STATS: NARGS(9); return rd_bn_stats(P(0), (double*)P(1), I(2), I(3), I(4), I(5), I(6), CP(int32_t, 7), I(8), st);
-    case RD_OP_UP_BWD: NARGS(13); return rd_up_bwd(P(0), P(1), P(2), CP(float, 3), CP(float, 4), CP(float, 5), I(6), I(7), I(8), I(9), I(10), CP(int32_t, 11), I(12), st);
-    case RD_OP_POOL_FWD: NARGS(12); return rd_pool_fwd(P(0), CP(float, 1), CP(float, 2), F(3), P(4), I(5), I(6), I(7), I(8), I(9), CP(int32_t, 10), I(11), st);
+    case RD_OP_UP_BWD:
+        NARGS(15);
+        return rd_up_bwd(P(0), P(1), P(2), CP(float, 3), CP(float, 4), CP(float, 5), I(6), I(7), I(8), I(9), I(10), CP(int32_t, 11), I(12), CP(rd_bn_bwd_t, 13), I(14), st);
+    case RD_OP_POOL_FWD:
+        NARGS(14);
+        return rd_pool_fwd(P(0), CP(float, 1), CP(float, 2), F(3), P(4), I(5), I(6), I(7), I(8), I(9), CP(int32_t, 10), I(11), CP(rd_bn_fwd_t, 12), I(13), st);
     case RD_OP_POOL_BWD:
-        NARGS(16);
-        return rd_pool_bwd(P(0), P(1), CP(float, 2), CP(float, 3), F(4), I(5), P(6), I(7), (double*)P(8), I(9), I(10), I(11), I(12), I(13), CP(int32_t, 14), I(15), st);
+        NARGS(17);
+        return rd_pool_bwd(P(0), P(1), CP(float, 2), CP(float, 3), F(4), I(5), P(6), I(7), (double*)P(8), I(9), I(10), I(11), I(12), I(13), CP(int32_t, 14), I(15), I(16), st);
     case RD_OP_BN_APPLY:
         NARGS(14);
         return rd_bn_apply(P(0), P(1), P(2), CP(float, 3), CP(float, 4), CP(float, 5), F(6), I(7), I(8), I(9), I(10), I(11), CP(int32_t, 12), I(13), st);

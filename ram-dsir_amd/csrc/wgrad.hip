@@ -12,7 +12,8 @@ namespace {
 // its 4 waves are MB*NB output blocks x KS = 4/(MB*NB) pixel-row splits.  Each wave stores its partial
 // block; a second kernel reduces the splits in a fixed order (deterministic, no atomics).
 template <typename T, int TAPS, int MB, int NB>
-__global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles, const rdfin::FinArg fa) {
+    rdfin::prologue(fa);                               // BatchNorm-backward finalize folded into this launch (bn_fin.h)
     constexpr int S = Slot<T>::N;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
@@ -220,7 +221,8 @@ __device__ __forceinline__ uint2 lds_tr(const char* p) {
 }
 
 template <int TAPS, int MB, int NB, int NQZ, bool PF>
-__global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles, const rdfin::FinArg fa) {
+    rdfin::prologue(fa);                               // BatchNorm-backward finalize folded into this launch (bn_fin.h)
     typedef bf16_t T;
     constexpr int S = 8;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -431,7 +433,8 @@ __device__ int wg_trace_key;
 #define WG_T(role, it, ev) do { } while (0)
 #endif
 template <int NQZ, int XP>
-__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles, const rdfin::FinArg fa) {
+    rdfin::prologue(fa);                               // BatchNorm-backward finalize folded into this launch (bn_fin.h)
     typedef bf16_t T;
     constexpr int S = 8, TAPS = 9;
     constexpr int THW = 4;
@@ -679,7 +682,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
 // 16-channel twin of wgrad_tr_kernel (v_mfma_f32_16x16x32_bf16, K = the 32 pixels of a tile row, one 16x16 block,
 // the 4 waves split the 8 rows): 32 bytes of channels per pixel, pitch 48 B (disjoint 8-bank spans for 4 pixel rows).
 template <int TAPS, int NQZ>
-__global__ __launch_bounds__(256, 3) void wgrad_c16_tr_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles) {
+__global__ __launch_bounds__(256, 3) void wgrad_c16_tr_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles, const rdfin::FinArg fa) {
+    rdfin::prologue(fa);                               // BatchNorm-backward finalize folded into this launch (bn_fin.h)
     typedef bf16_t T;
     typedef __attribute__((ext_vector_type(4))) float f32x4v;
     constexpr int S = 8;
@@ -947,7 +951,7 @@ int launch_wgrad(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+    hipLaunchKernelGGL((wgrad_kernel<T, TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     return (int)hipGetLastError();
 }
 
@@ -959,9 +963,9 @@ int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     const size_t lds_red = (size_t)3 * TAPS * 4 * 64 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
     if (p.dz.mode == RD_SRC_BNBWD)
-        hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 2>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 2>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     else
-        hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 1>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 1>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     return (int)hipGetLastError();
 }
 
@@ -995,7 +999,7 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<NQZ, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds); \
                     attr_lds = ws_lds; \
                 } \
-                hipLaunchKernelGGL((wgrad_ws_kernel<NQZ, XP>), grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws); \
+                hipLaunchKernelGGL((wgrad_ws_kernel<NQZ, XP>), grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws, rdfin::current()); \
                 return (int)hipGetLastError(); \
             } while (0)
 #ifdef RD_DEBUG_SWITCHES
@@ -1018,11 +1022,11 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
         }
     }
     if (!wgrad_pf_ok(p))
-        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     else if (p.dz.mode == RD_SRC_BNBWD)
-        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 2, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 2, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     else
-        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles);
+        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     return (int)hipGetLastError();
 }
 

@@ -11,6 +11,9 @@ LIB_PATH = os.path.join(_HERE, 'libramdsir_hip_dbg.so' if os.environ.get('RAMDSI
 RD_F32, RD_BF16 = 0, 1
 MAXG = 16
 STAT_SLOTS = 64
+STAT_SLOTS_FOLD = 8
+FIN_OWNER = 1
+FIN_MAX_G = 8          # groups a folded finalize may have (csrc/bn_fin.h)
 SRC_RAW, SRC_AFF, SRC_AFFACT, SRC_POOL, SRC_UP, SRC_BNBWD = range(6)
 DST_PLAIN, DST_POOL, DST_UPY, DST_NONE = range(4)
 
@@ -19,7 +22,7 @@ vp, fp, i32, i64, f32 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 class RdSrc(C.Structure):
     _fields_ = [('ptr', vp), ('ptr2', vp), ('scale', fp), ('shift', fp), ('q', fp), ('out', vp), ('mode', i32), ('C', i32),
-                ('slope', f32), ('n_off', i32), ('g_fixed', i32), ('pad_', i32)]
+                ('slope', f32), ('n_off', i32), ('g_fixed', i32), ('fin_flags', i32), ('fin', vp)]
 
 
 class RdDst(C.Structure):
@@ -31,7 +34,7 @@ class RdConv(C.Structure):
     _fields_ = [('src', RdSrc * 2), ('nsrc', i32), ('taps', i32), ('w', vp), ('bias', fp), ('CinPad', i32),
                 ('CoutPad', i32), ('N', i32), ('H', i32), ('W', i32), ('Cin', i32), ('Cout', i32), ('G', i32),
                 ('gstart', i32 * (MAXG + 1)), ('emode', i32), ('out', vp), ('stats', fp), ('dst', RdDst * 2),
-                ('c_split', i32), ('cu_limit', i32), ('w_tap_rows', i32), ('pad_', i32)]
+                ('c_split', i32), ('cu_limit', i32), ('w_tap_rows', i32), ('stat_slots', i32)]
 
 
 class RdWgrad(C.Structure):
@@ -44,13 +47,13 @@ class RdBnFwd(C.Structure):
     _fields_ = [('stats', fp), ('conv_bias', fp), ('scale', fp), ('shift', fp), ('mean', fp), ('invstd', fp), ('gamma', fp * MAXG),
                 ('beta', fp * MAXG), ('running_mean', fp * MAXG), ('running_var', fp * MAXG),
                 ('num_batches_tracked', vp * MAXG), ('count', f32 * MAXG), ('C', i32), ('G', i32), ('eps', f32),
-                ('momentum', f32), ('training', i32), ('pad_', i32)]
+                ('momentum', f32), ('training', i32), ('nslots', i32)]
 
 
 class RdBnBwd(C.Structure):
     _fields_ = [('bstats', fp), ('mean', fp), ('invstd', fp), ('gamma', fp * MAXG), ('dgamma', fp * MAXG),
                 ('dbeta', fp * MAXG), ('P', fp), ('Q', fp), ('R', fp), ('count', f32 * MAXG), ('C', i32), ('G', i32),
-                ('fstats', fp), ('conv_bias', fp), ('dbias', fp)]
+                ('fstats', fp), ('conv_bias', fp), ('dbias', fp), ('nslots', i32), ('pad_', i32)]
 
 
 class RdSegLoss(C.Structure):
@@ -79,7 +82,7 @@ class RdPackEntry(C.Structure):
 
 class RdLaunch(C.Structure):
     """rd_launch_t (include/ramdsir.h): one entry of a native launch list."""
-    _fields_ = [('op', i32), ('lane', i32), ('wait_main', i32), ('nargs', i32), ('a', C.c_uint64 * 17)]
+    _fields_ = [('op', i32), ('lane', i32), ('wait_main', i32), ('nargs', i32), ('a', C.c_uint64 * 18)]
 
 
 # RD_OP_* (include/ramdsir.h) by entry-point name
@@ -113,12 +116,12 @@ _SIGS = {
     'rd_gn_finalize_fwd': (C.c_int, [C.POINTER(RdBnFwd), vp]),
     'rd_gn_finalize_bwd': (C.c_int, [C.POINTER(RdBnBwd), vp]),
     'rd_bn_apply': (C.c_int, [vp, vp, vp, fp, fp, fp, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
-    'rd_up_stats': (C.c_int, [vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
+    'rd_up_stats': (C.c_int, [vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, C.c_int, vp]),
     'rd_bn_stats': (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
-    'rd_pool_fwd': (C.c_int, [vp, fp, fp, f32, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
-    'rd_pool_bwd': (C.c_int, [vp, vp, fp, fp, f32, C.c_int, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp]),
+    'rd_pool_fwd': (C.c_int, [vp, fp, fp, f32, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, vp, C.c_int, vp]),
+    'rd_pool_bwd': (C.c_int, [vp, vp, fp, fp, f32, C.c_int, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32), C.c_int, C.c_int, vp]),
     'rd_up_bwd': (C.c_int, [vp, vp, vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i32),
-                            C.c_int, vp]),
+                            C.c_int, vp, C.c_int, vp]),
     'rd_nchw_to_nhwc': (C.c_int, [fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'rd_nhwc_to_nchw': (C.c_int, [vp, fp, fp, fp, C.c_int, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(i32), C.c_int, vp]),

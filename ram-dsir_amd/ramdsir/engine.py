@@ -305,6 +305,12 @@ class Plan:
         self.store_operands = int(T.options()['store_wgrad_operands'])     # bit 0: the forward operand, bit 1: dz
         self.store_min_c = int(T.options()['store_wgrad_min_c'])           # ... of tensors with at least this many channels only
         self.split_wide_dgrad = bool(T.options()['split_wide_dgrad'])   # _dgrad_halves below
+        # True (the fused training step): no BatchNorm finalize launches between the convs -- the launch that first reads a layer's
+        # coefficients derives them from the statistic slots in its prologue (rd_src_t.fin, csrc/bn_fin.h), and every launch spreads
+        # its sums over RD_STAT_SLOTS_FOLD copies only.  False: explicit rd_bn_finalize_* launches (modules, eval plans, gn / in)
+        self.fold_finalize = False
+        self.fold_wgrad_behind = bool(T.options()['fold_wgrad_behind'])
+        self.fold_fwd_kinds = int(T.options()['fold_fwd_kinds'])
         self._unit = {}
         self.nodes = []
         self.keep = []
@@ -385,8 +391,49 @@ class Plan:
     def slot_channels(self):
         return 8 if self.dtype == torch.bfloat16 else 4
 
+    # ---- folded BatchNorm finalize (rd_src_t.fin)
+    def stat_slots(self):
+        """rd_conv_t.stat_slots / the stat_slots arguments of this plan's launches (0 = all RD_STAT_SLOTS copies)."""
+        return L.STAT_SLOTS_FOLD if self.fold_finalize else 0
+
+    def _folds(self, o, direction='fwd'):
+        """The finalize launches of Act `o` are folded into their consumers: BatchNorm in training mode, coefficients read through
+        scale / shift resp. P / Q / R by launches that take a `fin` (not the materialising rd_bn_apply passes).  fold_finalize: 1 both
+        directions, 3 the forward finalizes only, 4 the backward ones only (2: timing experiment, none at all)."""
+        if o.plan.fold_finalize == (4 if direction == 'fwd' else 3):      # (5 / 6: Plan.build un-folds part of the backward ones)
+            return False
+        return bool(o.plan.fold_finalize and o.plan.training and o.norm is not None and o.norm.kind == 'bn' and o.a_buf is None
+                    and o.plan.materialize_dz_min_c is None and not o.plan.split_wide_dgrad and o.plan.G <= L.FIN_MAX_G)
+
+    def _fin_ptr(self, desc):
+        """rd_src_t.fin of a consumer: the address of the (host) finalize descriptor, which the entry point copies into the kernel
+        arguments at launch time.  The descriptor is kept alive by Plan.keep."""
+        return C.addressof(desc)
+
+    def _take_fwd_fin(self, a, kind=1):
+        """(fin, flags) for a FORWARD launch of this plan that reads Act a's scale / shift.  The first consumer inside the owning plan
+        is the owner and later ones (same stream, behind it) need nothing; a consumer in ANOTHER plan runs on another lane, possibly
+        beside the owner, so it derives the coefficients itself (restoration decoder on the encoder bottleneck)."""
+        if getattr(a, 'fin_fwd', None) is None or self.fold_finalize == 2:      # 2: timing experiment -- no finalize at all (wrong results)
+            return None, 0
+        if not (self.fold_fwd_kinds & kind) and a.plan is self and not a.fin_fwd_taken:
+            # this kind of consumer (1 small-channel conv, 2 wide conv, 4 max-pool: tuning.py fold_fwd_kinds) keeps the explicit launch, in front of it
+            a.fin_fwd_taken = True
+            self.fwd.append(a.fin_fwd_op)
+            return None, 0
+        if a.plan is not self:
+            if a.plan.stat_slots() != self.stat_slots():
+                raise ValueError('plans that share a BatchNorm site must agree on fold_finalize')
+            return a.fin_fwd, 0
+        if a.fin_fwd_taken:
+            return None, 0
+        a.fin_fwd_taken = True
+        return a.fin_fwd, L.FIN_OWNER
+
     # ---- descriptor helpers
-    def _src(self, a, mode, n_off, g_fixed):
+    def _src(self, a, mode, n_off, g_fixed, fold=0):
+        """fold != 0: this is a forward launch's source -- attach the folded BatchNorm finalize of `a` if it is still pending (the value
+        is the consumer's kind for tuning.py fold_fwd_kinds: 1 small-channel conv, 2 wide conv)."""
         s = L.RdSrc()
         slope = self.slope
         if a.a_buf is not None and mode in (L.SRC_AFFACT, L.SRC_UP, L.SRC_POOL):
@@ -409,11 +456,16 @@ class Plan:
                 s.ptr = a.buf.data_ptr()
             if mode != L.SRC_RAW:
                 s.scale, s.shift = a.scale.data_ptr(), a.shift.data_ptr()
+                if fold:
+                    fin, flags = self._take_fwd_fin(a, fold)
+                    if fin is not None:
+                        s.fin, s.fin_flags = fin, flags
         s.mode, s.C, s.slope, s.n_off, s.g_fixed = mode, a.Cs, slope, n_off, g_fixed
         return s
 
-    def _dz_src(self, node):
-        """Source descriptor of the gradient w.r.t. this conv's output."""
+    def _dz_src(self, node, owner=None):
+        """Source descriptor of the gradient w.r.t. this conv's output.  owner (True / False; None: no fin): the launch carries the
+        folded BatchNorm-backward finalize of the site, as its owner (the gradient launch) or not (the weight gradient beside it)."""
         o = node.out
         s = L.RdSrc()
         s.C, s.slope, s.n_off, s.g_fixed = (o.gCs if o.norm is None else o.C), 0.0, 0, -1
@@ -424,6 +476,8 @@ class Plan:
         else:
             s.ptr, s.ptr2, s.mode = o.grad_buf().data_ptr(), o.buf.data_ptr(), L.SRC_BNBWD
             s.scale, s.shift, s.q = o.P.data_ptr(), o.R.data_ptr(), o.Q.data_ptr()
+            if owner is not None and getattr(o, 'fin_bwd', None) is not None and self.fold_finalize != 2:
+                s.fin, s.fin_flags = o.fin_bwd, (L.FIN_OWNER if owner else 0)
         return s
 
     def build(self, wpack):
@@ -431,6 +485,7 @@ class Plan:
         lib = L.lib()
         self.finalize_stats()
         dt = self.dt
+        nsl = self.stat_slots()
         ws_need = 0
         self.fwd_split = {}
         for node in self.nodes:
@@ -441,15 +496,19 @@ class Plan:
             if isinstance(node, PoolNode):
                 a = node.src
                 has_bn = a.norm is not None
+                fin, fin_flags = self._take_fwd_fin(a, 4) if has_bn else (None, 0)
                 self.fwd.append((lib.rd_pool_fwd, (a.buf.data_ptr(), a.scale.data_ptr() if has_bn else None, a.shift.data_ptr() if has_bn else None,
-                                                   self.slope if (has_bn and a.act) else 1.0, o.buf.data_ptr(), N, H, W, o.C, self.G, self.gs_arr, dt),
+                                                   self.slope if (has_bn and a.act) else 1.0, o.buf.data_ptr(), N, H, W, o.C, self.G, self.gs_arr, dt,
+                                                   fin, fin_flags),
                                  dict(kernel='pool', what='fwd', layer='%s.%s' % (node.mname, node.name))))
                 continue
             # ---------------- forward conv
             p = L.RdConv()
             p.cu_limit = int(self.conv_cus)
+            p.stat_slots = nsl
+            small = node.Cin <= 32 and node.Cout <= 32
             for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
-                p.src[i] = self._src(a, mode, n_off, g_fixed)
+                p.src[i] = self._src(a, mode, n_off, g_fixed, fold=1 if small else 2)
             p.nsrc, p.taps = len(node.inputs), node.taps
             p.w = wpack.ptr(node.mname, node.name, False)
             p.bias = self.bank.p(node.mname, node.name + '.bias').data_ptr()
@@ -471,7 +530,7 @@ class Plan:
             if o.norm is not None:
                 if o.up:
                     self.fwd.append((lib.rd_up_stats, (o.buf.data_ptr(), o.plan.stat_ptr(o.stats), o.y_buf.data_ptr() if o.y_buf is not None else None,
-                                                        N, H, W, o.C, self.G, self.gs_arr, dt)))
+                                                        N, H, W, o.C, self.G, self.gs_arr, dt, nsl)))
                 b = L.RdBnFwd()
                 b.stats = o.plan.stat_ptr(o.stats)
                 # the conv epilogues sum the result WITHOUT its bias; rd_up_stats sums y = up2(t) itself
@@ -490,9 +549,14 @@ class Plan:
                     b.count[g] = float((self.gstart[g + 1] - self.gstart[g]) * hw)
                 # gn / in always normalise with the statistics of the input itself (nn.GroupNorm / nn.InstanceNorm2d in eval mode too)
                 b.C, b.G, b.eps, b.momentum, b.training = o.C, self.G, EPS, MOMENTUM, 1 if (self.training or kind != 'bn') else 0
+                b.nslots = nsl
                 self.keep.append(b)
                 o.bn_desc = b
-                self.fwd.append((lib.rd_gn_finalize_fwd if kind == 'gn' else lib.rd_bn_finalize_fwd, (C.byref(b),)))
+                if self._folds(o):
+                    o.fin_fwd, o.fin_fwd_taken = self._fin_ptr(b), False          # taken by the first launch that reads scale / shift
+                    o.fin_fwd_op = (lib.rd_bn_finalize_fwd, (C.byref(b),))
+                else:
+                    self.fwd.append((lib.rd_gn_finalize_fwd if kind == 'gn' else lib.rd_bn_finalize_fwd, (C.byref(b),)))
                 if o.a_buf is not None:
                     src = o.y_buf if o.up else o.buf
                     Hh, Ww = (2 * H, 2 * W) if o.up else (H, W)
@@ -515,7 +579,7 @@ class Plan:
                     self.bwd.append((lib.rd_pool_bwd, (o.grad_buf().data_ptr(), a.buf.data_ptr(), a.scale.data_ptr() if has_bn else None,
                                                        a.shift.data_ptr() if has_bn else None, self.slope if (has_bn and a.act) else 1.0,
                                                        1 if (has_bn and a.act) else 0, a.grad_buf().data_ptr(), 1 if a.g_written else 0,
-                                                       a.plan.stat_ptr(a.bstats) if has_bn else None, N, H, W, o.C, self.G, self.gs_arr, dt),
+                                                       a.plan.stat_ptr(a.bstats) if has_bn else None, N, H, W, o.C, self.G, self.gs_arr, dt, nsl),
                                      dict(kernel='pool', what='bwd', layer='%s.%s' % (node.mname, node.name))))
                     a.g_written = True
                 continue
@@ -535,8 +599,13 @@ class Plan:
                     q.fstats = o.plan.stat_ptr(o.stats)
                     q.conv_bias = None if o.up else self.bank.p(node.mname, node.name + '.bias').data_ptr()
                     q.dbias = self.bank.g(node.mname, node.name + '.bias').data_ptr()
+                q.nslots = nsl
                 self.keep.append(q)
-                self.bwd.append((lib.rd_gn_finalize_bwd if o.norm.kind == 'gn' else lib.rd_bn_finalize_bwd, (C.byref(q),)))
+                fin_op, fin_pos = (lib.rd_bn_finalize_bwd, (C.byref(q),)), len(self.bwd)
+                if self._folds(o, 'bwd') and not (o.up and o.plan.fold_finalize == 6):
+                    o.fin_bwd = self._fin_ptr(q)            # carried by rd_up_bwd, or by the gradient launch (owner) and the weight gradient
+                else:
+                    self.bwd.append((lib.rd_gn_finalize_bwd if o.norm.kind == 'gn' else lib.rd_bn_finalize_bwd, (C.byref(q),)))
                 # dz stored once: every >= 64-channel layer, and (round 4) a 32-channel layer whose gradient launch is 64-wide (more
                 # than 32 input channels: dec.convu1.conv1, rec.convu2.conv1) -- a BatchNorm-backward source keeps that launch on the
                 # two-operand conv_pf_kernel (110 us, the slowest gradient launch of the step); with a stored dz it runs on the
@@ -548,8 +617,10 @@ class Plan:
                                                        o.Q.data_ptr(), o.R.data_ptr(), 1.0, N, H, W, o.C, self.G, self.gs_arr, dt)))
                 if o.up:
                     o.dt_buf = self.alloc_act((N, H, W, o.C))
+                    fb = getattr(o, 'fin_bwd', None) if self.fold_finalize != 2 else None
                     self.bwd.append((lib.rd_up_bwd, (o.grad_buf().data_ptr(), o.buf.data_ptr(), o.dt_buf.data_ptr(), o.P.data_ptr(),
-                                                     o.Q.data_ptr(), o.R.data_ptr(), N, H, W, o.C, self.G, self.gs_arr, dt)))
+                                                     o.Q.data_ptr(), o.R.data_ptr(), N, H, W, o.C, self.G, self.gs_arr, dt,
+                                                     fb, L.FIN_OWNER if fb is not None else 0)))
             # wgrad descriptor (launched below: fused with the dgrad where the pair qualifies)
             wg = L.RdWgrad()
             for i, (a, mode, n_off, g_fixed) in enumerate(node.inputs):
@@ -557,7 +628,7 @@ class Plan:
                 if getattr(node, 'a_store', None) and node.a_store[i] is not None:      # stored by the forward launch (rd_src_t.out)
                     wg.a[i].ptr, wg.a[i].mode, wg.a[i].scale, wg.a[i].shift = node.a_store[i].data_ptr(), L.SRC_RAW, None, None
             wg.na, wg.taps = len(node.inputs), node.taps
-            wg.dz = self._dz_src(node)
+            wg.dz = self._dz_src(node, owner=False)          # (promoted to owner below when the conv has no gradient launch)
             wg.N, wg.H, wg.W, wg.Cin, wg.Cout = N, H, W, node.Cin, node.Cout
             wg.G, wg.gstart = self.G, self.gs_arr
             wg.dW = self.bank.g(node.mname, node.name + '.weight').data_ptr()
@@ -600,9 +671,10 @@ class Plan:
             if not all(d.kind == L.DST_NONE for d in dsts):
                 p = L.RdConv()
                 p.cu_limit = int(self.conv_cus)
+                p.stat_slots = nsl
                 if not p.cu_limit and self.dgrad_cus and (node.Cin > 32 or node.Cout > 32):
                     p.cu_limit = int(self.dgrad_cus)
-                p.src[0] = self._dz_src(node)
+                p.src[0] = self._dz_src(node, owner=True)
                 p.nsrc, p.taps = 1, node.taps
                 p.w = wpack.ptr(node.mname, node.name, True)
                 p.bias = None
@@ -618,8 +690,18 @@ class Plan:
                     p.dst[1].kind = L.DST_NONE
                     p.c_split = node.Cin
                 self.keep.append(p)
+            if p is None and wg.dz.fin:
+                wg.dz.fin_flags = L.FIN_OWNER                # the first conv on the image: its weight gradient is the only reader of P / Q / R
             dmeta = self._conv_meta(node, N, H, W, node.Cout, node.Cin, 'dgrad') if p is not None else None
             node.fused = bool(p is not None and self.fused_bwd and lib.rd_conv_bwd_fused_ok(C.byref(p), C.byref(wg), dt))
+            if self.fold_finalize in (5, 6) and not node.fused and not o.up and getattr(o, 'fin_bwd', None) is not None:
+                # fold_finalize 5 / 6: the backward finalize is folded only into launches that do gradient AND weight gradient at once
+                # (and, 5, into rd_up_bwd); a layer with two stand-alone launches keeps the explicit one in front of both
+                o.fin_bwd = None
+                wg.dz.fin, wg.dz.fin_flags = None, 0
+                if p is not None:
+                    p.src[0].fin, p.src[0].fin_flags = None, 0
+                self.bwd.insert(fin_pos, fin_op)
             dgrad_first = False
             if node.fused:
                 # small-channel 3x3 conv: dgrad + weight gradient in ONE launch on the dgrad chain (csrc/conv_fused.hip: both are
@@ -635,11 +717,20 @@ class Plan:
                 # the gradient launch stores the dz its loader forms (rd_src_t.out) and the weight gradient, enqueued BEHIND it, reads that
                 dgrad_first = bool(p is not None and (self.store_operands & 2) and self.dtype == torch.bfloat16 and p.src[0].mode == L.SRC_BNBWD and node.Cout >= self.store_min_c
                                    and not self.split_wide_dgrad and lib.rd_conv_honours_src_out(C.byref(p), dt))
-                if dgrad_first:
+                # a folded BatchNorm-backward finalize (fold_wgrad_order 1): the gradient launch derives P / Q / R as the owner and the weight
+                # gradient, enqueued BEHIND it, reads them like any later launch -- instead of repeating the prologue on its own lane
+                fold_first = bool(p is not None and not dgrad_first and p.src[0].fin and self.fold_wgrad_behind and node is not self.nodes[0])   # (the
+                # plan's LAST gradient launch stays last: TrainStep moves the restoration decoder's to the main lane, behind the join)
+                if fold_first:
+                    wg.dz.fin, wg.dz.fin_flags = None, 0
+                    self.bwd.append((lib.rd_conv, (C.byref(p), dt), dmeta))
+                    dgrad_first = True
+                elif dgrad_first:
                     o.dz_store = self.alloc_act((N, H, W, o.C))
                     p.src[0].out = o.dz_store.data_ptr()
                     wg.dz.ptr, wg.dz.ptr2, wg.dz.mode = o.dz_store.data_ptr(), None, L.SRC_RAW
                     wg.dz.scale = wg.dz.shift = wg.dz.q = None
+                    wg.dz.fin, wg.dz.fin_flags = None, 0
                     self.bwd.append((lib.rd_conv, (C.byref(p), dt), dmeta))
                 ws_need = max(ws_need, lib.rd_wgrad_workspace(C.byref(wg), dt))
                 node.side_meta = [dict(kernel='wgrad', side=True, side_idx=0, layer='%s.%s' % (node.mname, node.name), bytes=wg_bytes, flops=wg_flops)]
@@ -812,7 +903,7 @@ class LaunchList:
                     name = 'side%d' % meta.get('side_idx', 0)
                     e.lane, e.wait_main = idx[name if name in idx else 'side0'], 1
             types = fn.argtypes[:-1]                         # without the trailing stream
-            assert len(types) == len(args) <= 17, (fn.__name__, len(types), len(args))
+            assert len(types) == len(args) <= 18, (fn.__name__, len(types), len(args))
             e.nargs = len(args)
             for i, (v, t) in enumerate(zip(args, types)):
                 e.a[i] = L.pack_arg(v, t)

@@ -39,6 +39,9 @@ class TrainStep:
         self.seg.pad_narrow = self.seg.materialize_up = True
         self.seg.materialize_pool = bool(opt['pool_mat'])
         self.seg.fused_bwd = bool(opt['fused_bwd'])
+        self.seg.fold_finalize = int(opt['fold_finalize'])
+        self.seg.fold_wgrad_behind = bool(opt['fold_wgrad_behind'])
+        self.seg.fold_fwd_kinds = int(opt['fold_fwd_kinds'])
         self.seg.store_operands = int(opt['store_wgrad_operands'])
         self.seg.store_min_c = int(opt['store_wgrad_min_c'])
         # lane budgets are tuned for the bf16 kernels (in fp32 the weight gradients are several times heavier and the side lane
@@ -60,6 +63,9 @@ class TrainStep:
         self.rec.pad_narrow = self.rec.materialize_up = True
         self.rec.materialize_pool = self.seg.materialize_pool
         self.rec.fused_bwd = self.seg.fused_bwd
+        self.rec.fold_finalize = self.seg.fold_finalize
+        self.rec.fold_wgrad_behind = self.seg.fold_wgrad_behind
+        self.rec.fold_fwd_kinds = self.seg.fold_fwd_kinds
         self.rec.store_operands = self.seg.store_operands
         self.rec.store_min_c = self.seg.store_min_c
         lane = bool(budget and opt['rec_lane'])

@@ -46,10 +46,20 @@ DEFAULTS = dict(
                           # them.  0 (all): 4.48 ms/step, 224: 4.46, 192: 4.44, 160: 4.43, 128: 4.51 (scripts/attic/sweep_ws2.sh)
     launch_threads=False, # rd_run_list_threads: the side / rec lanes' launches are enqueued by worker threads of the library, in parallel
                           # with the main lane's (host enqueue 0.85 -> ~0.4 ms per step; the GPU executes the same graph)
+    fold_finalize=6,      # BatchNorm finalize launches folded into the prologue of the launch that first reads the coefficients (rd_src_t.fin,
+                          # csrc/bn_fin.h; statistic sums over 8 slot copies instead of 64).  0: explicit launches; 1: all 76 of the step;
+                          # 3: the forward ones; 4: the backward ones; 6 (default): the forward ones + the backward ones of layers whose
+                          # gradient and weight gradient are ONE launch; 5: 6 + rd_up_bwd; 2: timing experiment, no finalize at all.
+                          # Same box, alternating (scripts/options_ab.py): explicit 4.267, 6: 4.147 ms/step; 1: 4.230 against 4.213 and
+                          # 3: 4.161 -- a stand-alone weight gradient beside its gradient launch repeats the prologue on its own lane,
+                          # and the many-workgroup rd_up_bwd pays it per workgroup; without ANY finalize the step takes 4.03
+    fold_fwd_kinds=7,     # which forward consumers take a folded finalize: 1 small-channel convs, 2 wide convs, 4 the max-pool
+    fold_wgrad_behind=False,   # with fold_finalize: a stand-alone weight gradient is enqueued BEHIND its layer's gradient launch (which owns the
+                          # folded BatchNorm-backward finalize) instead of in front of it with a prologue of its own
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
 )
 _ENV = dict(split_wide_dgrad='RD_SPLIT_WIDE_DGRAD', mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', mat_dz_wide='RD_MAT_DZ_WIDE', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
-            ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', store_wgrad_operands='RD_STORE_WGRAD_OPS', launch_threads='RD_LAUNCH_THREADS', dgrad_cus='RD_DGRAD_CUS', rec_lane='RD_REC_LANE', rec_wgrad_late='RD_REC_WGRAD_LATE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW')
+            ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', store_wgrad_operands='RD_STORE_WGRAD_OPS', launch_threads='RD_LAUNCH_THREADS', dgrad_cus='RD_DGRAD_CUS', rec_lane='RD_REC_LANE', rec_wgrad_late='RD_REC_WGRAD_LATE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW', fold_finalize='RD_FOLD_FINALIZE', fold_wgrad_behind='RD_FOLD_WGRAD_BEHIND', fold_fwd_kinds='RD_FOLD_FWD_KINDS')
 
 
 def options(over=None):

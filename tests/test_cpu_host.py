@@ -55,7 +55,7 @@ def test_launch_list_packing_and_lanes():
     import struct
     from ramdsir import _lib as L, engine as E
     lib = L.lib()
-    assert ctypes.sizeof(L.RdLaunch) == 16 + 8 * 17
+    assert ctypes.sizeof(L.RdLaunch) == 16 + 8 * 18
     assert L.pack_arg(1.5, L.f32) == struct.unpack('<I', struct.pack('<f', 1.5))[0]
     assert L.pack_arg(-1, ctypes.c_int) == 0xFFFFFFFFFFFFFFFF and L.pack_arg(None, L.vp) == 0 and L.pack_arg(4096, L.vp) == 4096
     p, gs = L.RdConv(), L.gstart_array([0, 2, 4])
@@ -63,14 +63,14 @@ def test_launch_list_packing_and_lanes():
     assert L.pack_arg(gs, ctypes.POINTER(L.i32)) == ctypes.addressof(gs)
     ops = [(lib.rd_conv, (ctypes.byref(p), 1), dict(kernel='x')),
            E.sync_op('fork', 'rec'),
-           (lib.rd_pool_fwd, (0x1000, None, None, 0.25, 0x2000, 4, 5, 6, 16, 2, gs, 1), dict(lane='rec')),
+           (lib.rd_pool_fwd, (0x1000, None, None, 0.25, 0x2000, 4, 5, 6, 16, 2, gs, 1, None, 0), dict(lane='rec')),
            (lib.rd_wgrad, (ctypes.byref(L.RdWgrad()), 1), dict(side=True, side_idx=0)),
            E.sync_op('join', 'rec'),
            (lib.rd_adam_step, (ctypes.byref(L.RdAdam()),))]
     ll = E.LaunchList(ops, ('side0', 'rec'))
     got = [(e.op, e.lane, e.wait_main, e.nargs) for e in ll.arr[:ll.n]]
     oc = L.OP_CODES
-    assert got == [(oc['rd_conv'], 0, 0, 2), (L.OP_FORK, 2, 0, 0), (oc['rd_pool_fwd'], 2, 0, 12), (oc['rd_wgrad'], 1, 1, 2),
+    assert got == [(oc['rd_conv'], 0, 0, 2), (L.OP_FORK, 2, 0, 0), (oc['rd_pool_fwd'], 2, 0, 14), (oc['rd_wgrad'], 1, 1, 2),
                    (L.OP_JOIN, 2, 0, 0), (oc['rd_adam_step'], 0, 0, 1)]
     e = ll.arr[2]
     assert e.a[0] == 0x1000 and e.a[1] == 0 and e.a[3] == L.pack_arg(0.25, L.f32) and e.a[10] == ctypes.addressof(gs) and e.a[11] == 1

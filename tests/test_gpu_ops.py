@@ -714,7 +714,7 @@ def test_pool_materialised_forward_and_backward(dtype, with_bn):
     gs = L.gstart_array(gstart)
     out = torch.full((N, Ho, Wo, Cc), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
     L.check(L.lib().rd_pool_fwd(L.ptr(zd), L.ptr(scd), L.ptr(shd), slope if with_bn else 1.0, L.ptr(out), N, Ho, Wo, Cc, 2, gs,
-                                U.DT[dtype][0], None), 'pool_fwd')
+                                U.DT[dtype][0], None, 0, None), 'pool_fwd')
     torch.cuda.synchronize()
     zz = z.clone().requires_grad_(True)
     pre = (zz * U.group_rows(sc, gstart, N) + U.group_rows(sh, gstart, N)) if with_bn else zz
@@ -730,7 +730,8 @@ def test_pool_materialised_forward_and_backward(dtype, with_bn):
         gbuf = U.nhwc(old, dtype)
         bst = torch.zeros(2, L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=U.dev())
         L.check(L.lib().rd_pool_bwd(L.ptr(U.nhwc(gp, dtype)), L.ptr(zd), L.ptr(scd), L.ptr(shd), slope if with_bn else 1.0, 1 if with_bn else 0,
-                                    L.ptr(gbuf), accumulate, L.ptr(bst) if with_bn else None, N, Ho, Wo, Cc, 2, gs, U.DT[dtype][0], None), 'pool_bwd')
+                                    L.ptr(gbuf), accumulate, L.ptr(bst) if with_bn else None, N, Ho, Wo, Cc, 2, gs, U.DT[dtype][0],
+                                    accumulate * L.STAT_SLOTS_FOLD, None), 'pool_bwd')
         torch.cuda.synchronize()
         U.assert_close(U.from_nhwc(gbuf), gref + (old if accumulate else 0), dtype, 'pool_bwd acc=%d' % accumulate)
         if with_bn:
@@ -749,7 +750,7 @@ def test_upsample_stats_and_backward(dtype):
     td = U.nhwc(t.detach(), dtype)
     stats = torch.zeros(2, L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=U.dev())
     gs = L.gstart_array(gstart)
-    L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats), None, N, h, w, Cc, 2, gs, U.DT[dtype][0], None), 'upstats')
+    L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats), None, N, h, w, Cc, 2, gs, U.DT[dtype][0], 0, None), 'upstats')
     torch.cuda.synchronize()
     ref = torch.stack([torch.stack([y[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), y[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
                        for g in range(2)]).detach()
@@ -757,8 +758,9 @@ def test_upsample_stats_and_backward(dtype):
     # materialising variant: y is stored, and the statistics are those of the stored (rounded) values
     stats2 = torch.zeros_like(stats)
     yd = torch.full((N, 2 * h, 2 * w, Cc), float('nan'), dtype=U.DT[dtype][1], device=U.dev())
-    L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats2), L.ptr(yd), N, h, w, Cc, 2, gs, U.DT[dtype][0], None), 'upstats+y')
+    L.check(L.lib().rd_up_stats(L.ptr(td), L.ptr(stats2), L.ptr(yd), N, h, w, Cc, 2, gs, U.DT[dtype][0], L.STAT_SLOTS_FOLD, None), 'upstats+y')
     torch.cuda.synchronize()
+    assert float(stats2[:, L.STAT_SLOTS_FOLD:].abs().max()) == 0.0            # only the first RD_STAT_SLOTS_FOLD copies were used
     U.assert_close(U.from_nhwc(yd), y.detach(), dtype, 'up y')
     ys = U.from_nhwc(yd)
     ref2 = torch.stack([torch.stack([ys[gstart[g]:gstart[g + 1]].sum((0, 2, 3)), ys[gstart[g]:gstart[g + 1]].pow(2).sum((0, 2, 3))], -1)
@@ -773,7 +775,7 @@ def test_upsample_stats_and_backward(dtype):
     g2d = U.nhwc(g2, dtype)
     Pd, Qd, Rd = U.fdev(P), U.fdev(Q), U.fdev(R)
     L.check(L.lib().rd_up_bwd(L.ptr(g2d), L.ptr(td), L.ptr(dt), L.ptr(Pd), L.ptr(Qd), L.ptr(Rd), N, h, w, Cc, 2, gs,
-                              U.DT[dtype][0], None), 'upbwd')
+                              U.DT[dtype][0], None, 0, None), 'upbwd')
     torch.cuda.synchronize()
     U.assert_close(U.from_nhwc(dt), t.grad, dtype, 'up_bwd')
 

@@ -364,6 +364,65 @@ def test_stored_weight_gradient_operands_give_identical_bits():
     assert float(outs[0][0].abs().max()) > 0
 
 
+@pytest.mark.parametrize('dtype,dataset,bs,S', [(torch.float32, 'fundus', [2, 3, 3], 64), (torch.bfloat16, 'fundus', [2, 3, 3], 256),
+                                                (torch.bfloat16, 'prostate', [2, 2, 2, 2, 2], 192)])
+def test_folded_batchnorm_finalize_gives_the_bits_of_the_explicit_launches(dtype, dataset, bs, S):
+    """TrainStep(options=dict(fold_finalize=...)): the default step has NO rd_bn_finalize_* launch -- the first launch that reads a
+    BatchNorm's coefficients derives them from the statistic slots in its prologue (rd_src_t.fin, csrc/bn_fin.h), and the sums are
+    spread over 8 slot copies instead of 64.  Same formulas, exact fp64 slot sums: gradients, parameters, losses AND every BatchNorm
+    buffer (running_mean / running_var in group order for the two passes of the shared BatchNorms, num_batches_tracked; DSBN per
+    domain) after three steps are bit-identical to the step with the explicit launches (nn.BatchNorm2d semantics: unet.py:17-28,
+    dsbn.py:10-11)."""
+    torch.manual_seed(0)
+    B = sum(bs)
+    outs = []
+    for fold in (0, 1, 6):          # 0: explicit launches, 1: every finalize folded, 6: the default (tuning.py fold_finalize: the forward ones, and
+        #                             the backward ones of the layers whose gradient and weight gradient are ONE launch)
+        bank, mods = S_.make_bank(DEV, 3, 16, 2, len(bs))
+        g = torch.Generator().manual_seed(1)
+        for (m, k), (off, shape) in bank.index.items():
+            v = bank.p(m, k)
+            if len(shape) == 4:
+                v.copy_((torch.randn(shape, generator=g) * (2.0 / (shape[0] * shape[2] * shape[3])) ** 0.5).to(DEV))
+            elif '.bn' in k and k.endswith('weight'):
+                v.copy_((1.0 + 0.1 * torch.randn(shape, generator=g)).to(DEV))
+            elif '.bn' in k and k.endswith('bias'):
+                v.copy_((0.1 * torch.randn(shape, generator=g)).to(DEV))
+        ts = S_.TrainStep(bank, mods, dtype, bs, S, S, dataset=dataset, consistency='kd', lr=1e-3, total_iters=100, ram=True,
+                          options=dict(fold_finalize=fold))
+        names = [op[0].__name__ for op in ts._ops if op[0] is not None]
+        n_fin = sum(1 for nm in names if nm.startswith('rd_bn_finalize'))
+        assert {0: n_fin > 70, 1: n_fin == 0, 6: 0 < n_fin <= 38}[fold], n_fin         # 38 + 38 sites (fp32 has no one-launch backward: 6 keeps all 38 backward launches)
+        ts.wpack.refresh()
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        if dataset == 'fundus':
+            src = torch.rand(B, S, S, 3, device=DEV, generator=gen) * 255
+            trg = torch.rand(B, S, S, 3, device=DEV, generator=gen) * 255
+            tgt = (torch.rand(B, 2, S, S, device=DEV, generator=gen) > 0.5).float()
+        else:
+            src = torch.rand(B, S, S, 3, device=DEV, generator=gen) * 2 - 1
+            trg = torch.rand(B, S, S, 3, device=DEV, generator=gen) * 2 - 1
+            tgt = (torch.rand(B, S, S, device=DEV, generator=gen) > 0.7).long()
+        lam = torch.tensor([0.1 * (1 + i % 9) for i in range(B)], device=DEV)
+        ts.load_raw(src, trg, lam)
+        ts.load_target(tgt)
+        for _ in range(3):
+            ts.step()
+        torch.cuda.synchronize()
+        outs.append((bank.grads.clone(), bank.params.clone(), ts.losses.clone(), ts.rec_mse.clone(),
+                     {k: v.clone() for k, v in bank.buffers.items()}))
+        del ts
+    for other in outs[1:]:
+        for a, b in zip(outs[0][:4], other[:4]):
+            assert torch.equal(a, b)
+        for k, v in outs[0][4].items():
+            assert torch.equal(v, other[4][k]), k
+    nbt = [v for (m, k), v in outs[1][4].items() if k.endswith('num_batches_tracked')]
+    assert {int(v) for (m, k), v in outs[1][4].items() if k.endswith('num_batches_tracked') and m != 'rec'} == {6}    # two passes x three steps
+    assert {int(v) for (m, k), v in outs[1][4].items() if k.endswith('num_batches_tracked') and m == 'rec'} == {3}
+    assert float(outs[0][0].abs().max()) > 0 and torch.isfinite(outs[0][0]).all()
+
+
 @pytest.mark.parametrize('dataset', ['fundus', 'prostate'])
 def test_pipelined_ram_steps_equal_classical_steps(dataset):
     """TrainStep.load_raw_next(): the NEXT batch is uploaded into the other input slot and mixed (RAM) into that slot's copy of the
