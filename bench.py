@@ -55,12 +55,37 @@ HBM_COPY_GBS = 5300.0                    # what a plain torch copy (read + write
 MFMA_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF (no sparsity)
 
 
-def synth_inputs(B, S, rank, device):
-    """U[0,255] uint8 source and partner images (what a decoded PNG is), lambda from random.Random(1337),
-    masks = two concentric random discs (cup inside disc)."""
+# The workloads BASELINE.json lists: dataset (loss kind, RAM input range), per-domain batch split, side, classes.
+#   C2   configs[1], the metric's configuration: Fundus target 0, 3 source domains x [2,3,3] at 400 x 400 (train.py:35-37 scaled to 8)
+#   C3   configs[2]: Prostate leave-one-out, 5 source domains x 2 slices at 384 x 384, softmax / CE / dice_multi (train.py:39-45,363-465)
+#   C5   configs[4]: synthetic 512 x 512 stream, 4 source domains x 2 (the per-GPU step of the 8-GPU roofline run)
+#   F256 the reference's own training shape: Fundus 16 = [3,6,7] at 256 x 256 (train.py:35,541)
+CONFIGS = {
+    'C2': dict(dataset='fundus', bs=[2, 3, 3], size=400, num_classes=2, consistency='kd', lr=2e-3,
+               workload='Fundus target0 --ram --rec --consistency kd, batch 8=[2,3,3] per GPU, %dx%dx3'),
+    # lr 1e-3 is the reference's Prostate default (train.py:619).  --consistency_type mse, not kd: on white-noise images the softmax of
+    # the freshly initialised network reaches EXACT zeros within two steps (logit differences > 100), and the reference's own KD formula
+    # (train.py:85-88: KLDivLoss of p.log()) is inf / NaN there -- in the oracle as in the HIP loss kernel; the launches are the same
+    'C3': dict(dataset='prostate', bs=[2, 2, 2, 2, 2], size=384, num_classes=2, consistency='mse', lr=1e-3,
+               workload='Prostate leave-one-out --ram --rec --consistency --consistency_type mse, batch 10=[2,2,2,2,2] per GPU (5 source domains), %dx%dx3 (2.5-D slices)'),
+    'C5': dict(dataset='fundus', bs=[2, 2, 2, 2], size=512, num_classes=2, consistency='kd', lr=2e-3,
+               workload='Synthetic 4-domain stream --ram --rec --consistency kd, batch 8=[2,2,2,2] per GPU, %dx%dx3'),
+    'F256': dict(dataset='fundus', bs=[3, 6, 7], size=256, num_classes=2, consistency='kd', lr=2e-3,
+                 workload='Fundus, the reference\'s own training shape (train.py:35,541) --ram --rec --consistency kd, batch 16=[3,6,7] per GPU, %dx%dx3'),
+}
+
+
+def synth_inputs(B, S, rank, device, dataset='fundus'):
+    """SURVEY.md 8(d).  fundus: U[0,255] uint8 source and partner images (what a decoded PNG is), masks = two concentric random discs
+    (cup inside disc) as the 2-channel multilabel float mask; prostate: float32 U[-1,1] slices (what the .npy files hold,
+    prostate.py:177-188), int64 label map = one random disc.  lambda from random.Random(1337) in both."""
     rng = np.random.RandomState(1337 + rank)
-    src = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.uint8)
-    trg = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.uint8)
+    if dataset == 'fundus':
+        src = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.uint8)
+        trg = np.round(rng.uniform(0, 255, (B, S, S, 3))).astype(np.uint8)
+    else:
+        src = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
+        trg = rng.uniform(-1, 1, (B, S, S, 3)).astype(np.float32)
     pr = random.Random(1337 + rank)
     lam = np.array([pr.randint(1, 10) / 10 for _ in range(B)], np.float32)
     yy, xx = np.mgrid[0:S, 0:S]
@@ -72,6 +97,8 @@ def synth_inputs(B, S, rank, device):
         d2 = (yy - cy) ** 2 + (xx - cx) ** 2
         mask[i, 1] = d2 <= r_disc ** 2
         mask[i, 0] = d2 <= r_cup ** 2
+    if dataset != 'fundus':
+        mask = mask[:, 1].astype(np.int64)
     t = lambda a: torch.from_numpy(a).to(device)
     return t(src), t(trg), t(lam), t(mask), (src, trg, lam, mask)
 
@@ -152,7 +179,7 @@ def pmc_aggregate(pmc_rows, B, dtype, size):
     return out
 
 
-def collect_live_pmc(B, dtype, size, timeout=240):
+def collect_live_pmc(B, dtype, size, config='C2', timeout=240):
     """HBM traffic measured BY THIS RUN: the same command (3 steps, no baselines) as a child process under `rocprofv3 -i scripts/pmc_hbm.txt
     --kernel-trace` (FETCH_SIZE and WRITE_SIZE in separate passes, kernel trace only: the guide's recipe), its counter files
     aggregated by pmc_aggregate().  Returns True when the figures of the line come from it; on any failure (no rocprofv3, a
@@ -169,8 +196,8 @@ def collect_live_pmc(B, dtype, size, timeout=240):
     outdir = tempfile.mkdtemp(prefix='rd_pmc_', dir='/tmp')
     try:
         cmd = [exe, '-i', os.path.join(ROOT, 'scripts', 'pmc_hbm.txt'), '--kernel-trace', '-M', '--output-format', 'csv', '-d', outdir, '-o', 'p',
-               '--', sys.executable, os.path.abspath(__file__), '--steps', '3', '--warmup', '1', '--size', str(size), '--dtype', dtype,
-               '--no-cpu-baseline', '--no-fp32-leg', '--no-ablation', '--no-live-pmc']
+               '--', sys.executable, os.path.abspath(__file__), '--steps', '3', '--warmup', '1', '--config', config, '--size', str(size), '--dtype', dtype,
+               '--no-cpu-baseline', '--no-fp32-leg', '--no-ablation', '--no-live-pmc', '--no-saturation']
         env = dict(os.environ, TMPDIR='/tmp', RD_BENCH_CHILD='1')
         for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'RD_FORCE_DDP'):
             env.pop(k, None)
@@ -381,7 +408,7 @@ def step_cost_by_ablation(ts, fams, steps=20):
     return {fam: round(base - med(t[fam]), 3) for fam in fams}, round(min(bases), 3), round(max(bases), 3)
 
 
-def cpu_baseline(host_inputs, bs):
+def cpu_baseline(host_inputs, bs, dataset='fundus', num_classes=2, consistency='kd', lr=2e-3):
     """The oracle (torch CPU restatement of train.py:225-296 + numpy RAM of fundus.py:13-61) timed on this box's host
     cores on the same workload (8 images at 400x400 per step): 1 warm-up step + 3 timed steps, the numpy
     RAM per image on ONE core as a DataLoader worker runs it.  `value` = images/s of step + RAM / 8 workers (the
@@ -395,33 +422,36 @@ def cpu_baseline(host_inputs, bs):
     torch.set_num_threads(cores)
     B = src.shape[0]
     t0 = time.time()
-    pairs = [OR.ram_fundus(src[i].astype(np.float32), trg[i].astype(np.float32), float(lam[i]), dtype=np.float32) for i in range(B)]
+    ram_fn = OR.ram_fundus if dataset == 'fundus' else OR.ram_prostate
+    pairs = [ram_fn(src[i].astype(np.float32), trg[i].astype(np.float32), float(lam[i]), dtype=np.float32) for i in range(B)]
     t_ram = time.time() - t0                   # B images, one core
     img = torch.from_numpy(np.stack([p[0] for p in pairs]))
     frq = torch.from_numpy(np.stack([p[1] for p in pairs]))
-    enc, dec, rec = OU.encoder_state(seed=1), OU.decoder_state(seed=2), OU.rec_decoder_state(num_classes=3, num_domains=len(bs), seed=3)
+    enc, dec, rec = OU.encoder_state(seed=1), OU.decoder_state(num_classes=num_classes, seed=2), OU.rec_decoder_state(num_classes=3, num_domains=len(bs), seed=3)
     opt = dict(enc=OS.adam_state({k: enc[k] for k in OU.param_keys(enc)}), dec=OS.adam_state({k: dec[k] for k in OU.param_keys(dec)}),
                rec=OS.adam_state({k: rec[k] for k in OU.param_keys(rec)}))
-    cfg = OS.StepConfig(dataset='fundus', batch_sizes=bs, consistency='kd')
+    cfg = OS.StepConfig(dataset=dataset, batch_sizes=bs, consistency=consistency, num_classes=num_classes, lr=lr)
     times = []
     for it in range(4):                        # 1 warm-up + 3 timed
         t0 = time.time()
         OS.train_step(enc, dec, rec, opt, img, frq, torch.from_numpy(mask), cfg, it)
         times.append(time.time() - t0)
     t_step = float(np.median(times[1:]))
-    return dict(value=round(B / (t_step + t_ram / 8), 3), unit='images/s', cores=cores, kind='port',
+    S_ = src.shape[1]
+    return dict(value=round(B / (t_step + t_ram / 8), 3), unit='images/s', cores=cores, host_cores=os.cpu_count(), kind='port',
                 step_only=round(B / t_step, 3), step_plus_ram_serial=round(B / (t_step + t_ram), 3),
-                sample='1 warm-up + 3 timed steps of the same workload (8 images 400x400 each): torch-CPU step median %.2f s on %d threads '
-                       '(warm-up %.2f s); numpy RAM %.2f s per batch of 8 on 1 core; value = step + RAM/8 workers' % (t_step, cores, times[0], t_ram))
+                sample='1 warm-up + 3 timed steps of the same workload (%d images %dx%d each): torch-CPU step median %.2f s on %d threads of the '
+                       'host\'s %d (warm-up %.2f s); numpy RAM %.2f s per batch of %d on 1 core; value = step + RAM/8 workers'
+                       % (B, S_, S_, t_step, cores, os.cpu_count() or 0, times[0], t_ram, B))
 
 
-def fp32_leg(bank_init, bs, Sz, dev, src, trg, lam, mask, steps=6, warmup=2):
+def fp32_leg(bank_init, bs, Sz, dev, src, trg, lam, mask, steps=6, warmup=2, dataset='fundus', num_classes=2, consistency='kd', lr=2e-3):
     """The same step in fp32 storage -- the reference's own precision and the parity path of the tests."""
     from ramdsir import step as S
-    bank, mods = S.make_bank(dev, 3, 16, 2, len(bs))
+    bank, mods = S.make_bank(dev, 3, 16, num_classes, len(bs))
     bank.params.copy_(bank_init)
-    ts = S.TrainStep(bank, mods, torch.float32, bs, Sz, Sz, dataset='fundus', consistency='kd', lambda_rec=0.1, lr=2e-3,
-                     total_iters=21200, ram='u8')
+    ts = S.TrainStep(bank, mods, torch.float32, bs, Sz, Sz, dataset=dataset, consistency=consistency, lambda_rec=0.1, lr=lr,
+                     total_iters=21200, num_classes=num_classes, ram='u8' if dataset == 'fundus' else True)
     ts.wpack.refresh()
     ts.load_raw(src, trg, lam)
     ts.load_target(mask)
@@ -493,7 +523,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--size', type=int, default=400)
+    ap.add_argument('--config', default='C2', choices=sorted(CONFIGS), help='which of BASELINE.json\'s workloads (C2 = the metric\'s configuration; C3 Prostate 5 x 2 at 384; C5 512 with 4 domains; F256 the reference\'s native Fundus shape)')
+    ap.add_argument('--size', type=int, default=0, help='override the side of the configuration (0: its own)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--graph', action='store_true', help='replay one captured hipGraph per step instead of the 3-stream eager launch (slower on ROCm 7: DESIGN.md section 3)')
     ap.add_argument('--no-graph', action='store_true', help='(default; kept for older command lines)')
@@ -501,6 +532,7 @@ def main():
     ap.add_argument('--no-fp32-leg', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='classical step: RAM at the head of every step instead of in the previous step\'s tail')
     ap.add_argument('--no-ablation', action='store_true', help='skip the in-run ablation that picks the headline roofline family')
+    ap.add_argument('--no-saturation', action='store_true', help='skip the 4-process run on this GPU that reports gpu_saturated_images_per_s')
     ap.add_argument('--no-live-pmc', action='store_true', help='take the HBM traffic figures from the committed profiles/dominant_kernel_pmc.json instead of measuring them in a rocprofv3 child run')
     args = ap.parse_args()
 
@@ -519,17 +551,19 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
     from ramdsir import step as S, ddp as D
 
-    bs, Sz = [2, 3, 3], args.size
+    cfg = CONFIGS[args.config]
+    bs, Sz, dataset, K = list(cfg['bs']), args.size or cfg['size'], cfg['dataset'], cfg['num_classes']
     B = sum(bs)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    bank, mods = S.make_bank(dev, 3, 16, 2, len(bs))
+    bank, mods = S.make_bank(dev, 3, 16, K, len(bs))
     init_weights(bank)
     params0 = bank.params.clone()
     # a captured graph replays ONE chain: nothing runs beside the weight gradients, so they keep the whole GPU (tuning.py)
-    ts = S.TrainStep(bank, mods, dtype, bs, Sz, Sz, dataset='fundus', consistency='kd', lambda_rec=0.1, lr=2e-3,
-                     total_iters=21200, ram='u8', options=dict(side_cus=0, rec_cus=0) if args.graph else None)
+    ts = S.TrainStep(bank, mods, dtype, bs, Sz, Sz, dataset=dataset, consistency=cfg['consistency'], lambda_rec=0.1, lr=cfg['lr'],
+                     total_iters=21200, num_classes=K, ram='u8' if dataset == 'fundus' else True,
+                     options=dict(side_cus=0, rec_cus=0) if args.graph else None)
     ts.wpack.refresh()
-    src, trg, lam, mask, host_inputs = synth_inputs(B, Sz, rank, dev)
+    src, trg, lam, mask, host_inputs = synth_inputs(B, Sz, rank, dev, dataset)
     ts.load_raw(src, trg, lam)
     ts.load_target(mask)
     torch.cuda.synchronize()
@@ -599,7 +633,7 @@ def main():
             'metric': 'images/sec (seg+rec+RAM step)', 'value': round(world * B * args.steps / elapsed, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'Fundus target0 --ram --rec --consistency kd, batch 8=[2,3,3] per GPU, %dx%dx3' % (Sz, Sz),
+            'config': {'workload': cfg['workload'] % (Sz, Sz), 'name': args.config, 'batch_split': bs, 'dataset': dataset, 'consistency': cfg['consistency'], 'lr': cfg['lr'],
                        'global_batch': world * B, 'parallelism': 'dp%d' % world,
                        'process_group': ('%s world %d' % (dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else 'none (single process)', 'hipgraph': bool(args.graph), 'streams': 1 if (args.graph or not ts.fork) else 1 + len(ts.lanes()),
                        'lanes_verified': bool(ts.lanes_verified), 'gradient_exchange': exchange,
@@ -610,8 +644,9 @@ def main():
         # HBM traffic measured by this run (a rocprofv3 child of the same command, after the timed region); single process only: under
         # torchrun the committed summary is used
         if world == 1 and runner is None and not args.graph and not args.no_live_pmc:
-            collect_live_pmc(B, args.dtype, Sz)
-            collect_live_sq(args.dtype, Sz)
+            collect_live_pmc(B, args.dtype, Sz, args.config)
+            if args.config == 'C2':
+                collect_live_sq(args.dtype, Sz)
         out['roofline_step'] = whole_step_roofline(B, Sz, out['ms_per_step'], args.dtype)
         if args.dtype == 'bf16':
             roofs = {}
@@ -639,9 +674,21 @@ def main():
             for fam, r in roofs.items():
                 out['roofline' if fam == dominant else 'roofline_' + fam] = r
         if world == 1 and args.dtype == 'bf16' and not args.no_fp32_leg:
-            out['extra'] = {'fp32': fp32_leg(params0, bs, Sz, dev, src, trg, lam, mask)}
+            out['extra'] = {'fp32': fp32_leg(params0, bs, Sz, dev, src, trg, lam, mask, dataset=dataset, num_classes=K, consistency=cfg['consistency'], lr=cfg['lr'])}
+        if world == 1 and runner is None and args.config == 'C2' and Sz == 400 and args.dtype == 'bf16' and not args.no_saturation and not _under_profiler() \
+                and os.environ.get('RD_BENCH_CHILD') != '1':
+            # how much of the gap to the roofs is dependency bubbles and how much is kernels: the same step from 4 processes at once on this GPU
+            try:
+                sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+                import host_contention as HC
+                sat = HC.saturated_rate()
+                out['gpu_saturated_images_per_s'] = sat['images_per_s'] if sat else None
+                out['gpu_saturated'] = sat
+            except Exception as e:                                    # the figure is diagnostic: never lose the line over it
+                out['gpu_saturated_images_per_s'] = None
+                out['gpu_saturated'] = {'error': repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(host_inputs, bs)
+            out['cpu_baseline'] = cpu_baseline(host_inputs, bs, dataset, K, cfg['consistency'], cfg['lr'])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

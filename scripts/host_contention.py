@@ -7,7 +7,7 @@ import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def worker(steps):
+def worker(steps, start_at=0.0):
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'ram-dsir_amd')]
     import torch
     from ramdsir import step as S
@@ -27,22 +27,30 @@ def worker(steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter(); ts.step(); one.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
-    # (b) throughput: `steps` steps back to back
+    # (b) throughput: `steps` steps back to back, all workers from the same wall-clock instant when one is given
+    while time.time() < start_at:
+        time.sleep(0.001)
+    w0 = time.time()
     t0 = time.perf_counter()
     for _ in range(steps):
         ts.step()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print('HCRESULT ' + json.dumps(dict(enqueue_ms_idle=round(1e3 * sorted(one)[len(one) // 2], 3), enqueue_ms_loop=round(1e3 * (t1 - t0) / steps, 3),
+    print('HCRESULT ' + json.dumps(dict(wall_start=w0, wall_end=time.time(), late=bool(start_at and w0 - start_at > 0.05),enqueue_ms_idle=round(1e3 * sorted(one)[len(one) // 2], 3), enqueue_ms_loop=round(1e3 * (t1 - t0) / steps, 3),
                                         ms_per_step=round(1e3 * (t2 - t0) / steps, 3), images_per_s=round(8 * steps / (t2 - t0), 1),
                                         lanes_verified=bool(ts.lanes_verified))), flush=True)
 
 
-def run(k, steps):
+def run(k, steps, lead_s=0.0):
+    """lead_s > 0: the workers start their timed loops together, lead_s seconds from now (enough for every interpreter to import torch,
+    build the step and warm up); the saturated rate is then all images / (last end - common start)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--worker', str(steps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
-             for _ in range(k)]
+    for name in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'RD_FORCE_DDP'):
+        env.pop(name, None)
+    start_at = time.time() + lead_s if lead_s > 0 else 0.0
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--worker', str(steps), repr(start_at)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, env=env) for _ in range(k)]
     res = []
     for p in procs:
         o, _ = p.communicate(timeout=900)
@@ -54,9 +62,24 @@ def run(k, steps):
     return res
 
 
+def saturated_rate(k=4, steps=150, lead_s=30.0):
+    """images/s of k processes running the bench step on ONE GPU from a common start: what the kernels deliver when the dependency
+    bubbles of one process's step are filled by other processes' kernels (bench.py reports it beside the single-process value)."""
+    res = run(k, steps, lead_s)
+    if any(r['late'] for r in res):
+        return None
+    t0, t1 = min(r['wall_start'] for r in res), max(r['wall_end'] for r in res)
+    return dict(processes=k, steps_each=steps, images_per_s=round(8 * steps * k / (t1 - t0), 1),
+                per_process_ms_per_step=[r['ms_per_step'] for r in res])
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 2 and sys.argv[1] == '--worker':
-        worker(int(sys.argv[2]))
+        worker(int(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == '--sat':            # common-start saturated rates: host_contention.py --sat 1,2,4,8 [steps]
+        for k in [int(x) for x in sys.argv[2].split(',')]:
+            print(saturated_rate(k, int(sys.argv[3]) if len(sys.argv) > 3 else 150), flush=True)
         sys.exit(0)
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30

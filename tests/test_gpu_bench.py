@@ -32,3 +32,21 @@ def test_bench_line_on_the_forced_data_parallel_path():
     assert cfg['ram_pipelined'] is True and abs(cfg['final_loss']) < 10
     # the exchange path costs little on one rank: within 15 % of the plain step of the same run's roofline block
     assert d['roofline']['bound'] in ('hbm', 'mfma') and d['roofline_step']['algorithmic_bytes_per_step'] > 8e9
+
+
+@pytest.mark.parametrize('name,dataset,split,side', [('C3', 'prostate', [2, 2, 2, 2, 2], 384), ('C5', 'fundus', [2, 2, 2, 2], 512),
+                                                     ('F256', 'fundus', [3, 6, 7], 256)])
+def test_bench_lines_of_the_other_baseline_configs(name, dataset, split, side):
+    """bench.py --config: the workloads BASELINE.json lists beside the metric's own (C3 Prostate 5 x 2 at 384 with softmax / CE / dice_multi,
+    train.py:39-45,363-465; C5 512 x 512 with 4 domains; F256 the reference's native Fundus shape, train.py:35,541) give a line with the
+    same fields: throughput of the whole step at that shape, its roofline position, the workload named in config."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', name, '--steps', '4', '--warmup', '2', '--no-cpu-baseline',
+                        '--no-fp32-leg', '--no-ablation', '--no-live-pmc', '--no-saturation'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
+    cfg = d['config']
+    assert cfg['name'] == name and cfg['dataset'] == dataset and cfg['batch_split'] == split and ('%dx%d' % (side, side)) in cfg['workload']
+    assert cfg['global_batch'] == sum(split) and d['value'] > 0 and d['dtype'] == 'bf16' and abs(cfg['final_loss']) < 20
+    rs = d['roofline_step']
+    assert abs(rs['bytes_per_image'] / (1027560000 * (side / 400.0) ** 2) - 1) < 0.01         # SURVEY.md 8d scaling with the side
+    assert d['roofline']['bound'] in ('hbm', 'mfma') and 0 < d['roofline']['frac'] < 1
