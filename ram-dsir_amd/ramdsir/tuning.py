@@ -52,7 +52,9 @@ DEFAULTS = dict(
                           # gradient and weight gradient are ONE launch; 5: 6 + rd_up_bwd; 2: timing experiment, no finalize at all.
                           # Same box, alternating (scripts/options_ab.py): explicit 4.267, 6: 4.147 ms/step; 1: 4.230 against 4.213 and
                           # 3: 4.161 -- a stand-alone weight gradient beside its gradient launch repeats the prologue on its own lane,
-                          # and the many-workgroup rd_up_bwd pays it per workgroup; without ANY finalize the step takes 4.03
+                          # and the many-workgroup rd_up_bwd pays it per workgroup; without ANY finalize the step takes 4.03.  Also measured:
+                          # the explicit backward launch moved to the weight-gradient lane with the gradient launch deriving P / Q / R itself
+                          # (4.542 against 4.423 for 6 and 4.531 explicit, a slower box)
     fold_fwd_kinds=7,     # which forward consumers take a folded finalize: 1 small-channel convs, 2 wide convs, 4 the max-pool
     fold_wgrad_behind=False,   # with fold_finalize: a stand-alone weight gradient is enqueued BEHIND its layer's gradient launch (which owns the
                           # folded BatchNorm-backward finalize) instead of in front of it with a prologue of its own
