@@ -638,6 +638,7 @@ def main():
                        'process_group': ('%s world %d' % (dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else 'none (single process)', 'hipgraph': bool(args.graph), 'streams': 1 if (args.graph or not ts.fork) else 1 + len(ts.lanes()),
                        'lanes_verified': bool(ts.lanes_verified), 'gradient_exchange': exchange,
                        'lane_layout': layouts, 'ddp_comm': runner.comm_choice if runner is not None else None,
+                       'launch_threads': runner.launch_choice if runner is not None else {'launch_threads': bool(ts.launch_threads), 'how': 'single process'},
                        'ram_pipelined': not (args.graph or args.no_pipeline), 'launch': 'rd_run_list (one native call per step)' if not args.graph else 'hipGraph replay',
                        'final_loss': round(losses['loss'], 4)},
         }

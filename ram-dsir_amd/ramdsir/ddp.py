@@ -66,6 +66,9 @@ class DataParallelStep:
         self.graphs = None
         if choice < 0:
             self.pick_comm()
+        self.launch_choice = {'launch_threads': bool(ts.launch_threads), 'how': 'option'}
+        if int(ts.opt['launch_threads']) < 0:
+            self.pick_launch_threads()
 
     def _comm_stream(self, own):
         if own:
@@ -104,6 +107,41 @@ class DataParallelStep:
         own = times[1] < times[0]
         self.comm = self._comm_stream(own)
         self.comm_choice = {'own_comm_stream': bool(own), 'how': 'measured', 'ms_per_step_lane': round(times[0], 3), 'ms_per_step_own': round(times[1], 3)}
+        ts._restore(saved)
+        ts._slot, ts._x_ready, ts._next_loaded = state
+        ts.src, ts.trg, ts.lam = ts.raw_slots[ts._slot] if ts.ram is not None else (None, None, None)
+        torch.cuda.synchronize()
+
+    def pick_launch_threads(self, steps=6):
+        """One host thread or one per lane for the enqueue (rd_run_list_threads)?  Eight ranks share one host, and a rank's enqueue is more
+        than half of its step time, so the answer depends on how many cores the ranks leave each other: measured on the real process group,
+        like the communication stream above -- `steps` eager steps each way, the slowest rank decides, state restored."""
+        import time
+        ts = self.ts
+        if not ts.fork:
+            self.launch_choice = {'launch_threads': False, 'how': 'one stream: nothing to parallelise'}
+            return
+        saved, state = ts._snapshot(), (ts._slot, ts._x_ready, ts._next_loaded)
+        times = []
+        for threads in (False, True):
+            ts.launch_threads = threads
+            ts._restore(saved)
+            self.step()
+            torch.cuda.synchronize()
+            if dist.is_initialized():
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / steps * 1e3)
+        t = torch.tensor(times, dtype=torch.float64, device=ts.bank.device)
+        if dist.is_initialized() and self.buckets.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times = [float(v) for v in t]
+        ts.launch_threads = bool(times[1] < 0.98 * times[0])          # worker threads only for a measurable gain
+        self.launch_choice = {'launch_threads': ts.launch_threads, 'how': 'measured', 'ms_per_step_one_thread': round(times[0], 3),
+                              'ms_per_step_lane_threads': round(times[1], 3)}
         ts._restore(saved)
         ts._slot, ts._x_ready, ts._next_loaded = state
         ts.src, ts.trg, ts.lam = ts.raw_slots[ts._slot] if ts.ram is not None else (None, None, None)

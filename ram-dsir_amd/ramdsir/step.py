@@ -48,7 +48,7 @@ class TrainStep:
         # itself becomes the critical path when it is narrowed: 315 -> 268 images/s)
         budget = bool(opt['fork']) and dtype == torch.bfloat16
         self.seg.side_cus = T.cu_budget(opt['side_cus'], dev) if budget else 0
-        self.seg.dgrad_cus = int(opt['dgrad_cus']) if budget else 0
+        self.seg.dgrad_cus = T.cu_budget(opt['dgrad_cus'], dev) if budget else 0
         self.seg.materialize_min_c = opt['mat_min_c'] if opt['mat_min_c'] > 0 else None
         self.seg.materialize_dz_min_c = opt['mat_dz_min_c'] if opt['mat_dz_min_c'] > 0 else None
         self.seg.materialize_dz_wide = bool(opt['mat_dz_wide'])
@@ -155,7 +155,7 @@ class TrainStep:
         self.lanes_verified = bool(opt['fork']) and all(streams.verified.get(id(st), False) for st in picked)
         self.fork = bool(opt['fork'])
         self.rec_lane = bool(opt['rec_lane'])
-        self.launch_threads = bool(opt['launch_threads']) and self.fork
+        self.launch_threads = int(opt['launch_threads']) > 0 and self.fork      # (-1: DataParallelStep measures it; one process: one thread)
         self._slot1_keep = []
         self._ops = self._build_ops()
 

@@ -44,7 +44,8 @@ DEFAULTS = dict(
     dgrad_cus=160,        # compute-unit budget of the seg plan's >= 64-channel gradient launches (they run on the persistent whole-CU
                           # kernel conv_ws_kernel<2> since round 4): leaves 96 CUs to the weight-gradient / restoration lanes beside
                           # them.  0 (all): 4.48 ms/step, 224: 4.46, 192: 4.44, 160: 4.43, 128: 4.51 (scripts/attic/sweep_ws2.sh)
-    launch_threads=False, # rd_run_list_threads: the side / rec lanes' launches are enqueued by worker threads of the library, in parallel
+    launch_threads=-1,    # (-1: measured at start-up by the data-parallel wrapper, DataParallelStep.pick_launch_threads; a single process keeps one
+                          # thread) rd_run_list_threads: the side / rec lanes' launches are enqueued by worker threads of the library, in parallel
                           # with the main lane's (host enqueue 0.85 -> ~0.4 ms per step; the GPU executes the same graph)
     fold_finalize=6,      # BatchNorm finalize launches folded into the prologue of the launch that first reads the coefficients (rd_src_t.fin,
                           # csrc/bn_fin.h; statistic sums over 8 slot copies instead of 64).  0: explicit launches; 1: all 76 of the step;
@@ -80,8 +81,13 @@ def options(over=None):
 
 
 def cu_budget(value, device):
-    """side_cus / rec_cus -> compute units: -1 = half of the device's compute units (the measured optimum on the 256-CU MI355X)."""
-    if value >= 0:
+    """side_cus / rec_cus / dgrad_cus -> compute units of THIS device.  The positive defaults are the measured optima on the 256-CU
+    MI355X and are scaled with the device's compute-unit count (hipDeviceProp multiProcessorCount; a multiple of 8 = whole XCD rows),
+    -1 = half of the device, 0 = no budget.  device None: the value as given (host-side tests)."""
+    if value == 0 or device is None:
         return int(value)
     import torch
-    return torch.cuda.get_device_properties(device).multi_processor_count // 2
+    n = torch.cuda.get_device_properties(device).multi_processor_count
+    if value < 0:
+        return n // 2
+    return int(value) if n == 256 else max(8, int(round(value * n / 256.0 / 8.0)) * 8)

@@ -118,29 +118,48 @@ _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path[:0] = [%r, %r]
 from ramdsir.ddp import GradBuckets
-rank = int(sys.argv[1])
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2], RANK=str(rank), WORLD_SIZE='2')
-dist.init_process_group('gloo', rank=rank, world_size=2)
+rank, world = int(sys.argv[1]), int(sys.argv[3])
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group('gloo', rank=rank, world_size=world)
 g = torch.arange(10, dtype=torch.float32) * (rank + 1)
 b = GradBuckets(g, [0, 1, 4, 10])
 assert len(b) == 3
 ws = [b.reduce(2, async_op=True), b.reduce(1, async_op=True), b.reduce(0, async_op=False)]
 for w in ws:
     if w is not None: w.wait()
-exp = torch.arange(10, dtype=torch.float32) * 1.5
+exp = torch.arange(10, dtype=torch.float32) * (world + 1) / 2.0          # mean over the ranks of (rank + 1)
 assert torch.allclose(g, exp), (g, exp)
+# the loss scalars train.py logs: one all-reduce, the mean over the ranks (every rank calls it)
+l = torch.full((8,), float(rank))
+dist.all_reduce(l)
+assert torch.allclose(l / world, torch.full((8,), (world - 1) / 2.0))
+# DistributedSampler shards of one domain's file list (train.py:216-225): disjoint, equal length, reshuffled per epoch
+from torch.utils.data.distributed import DistributedSampler
+ds = list(range(103))
+sp = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=1337, drop_last=True)
+sp.set_epoch(0)
+mine = torch.tensor(list(sp))
+allr = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(allr, mine)
+flat = torch.cat(allr).tolist()
+assert len(mine) == 103 // world and len(set(flat)) == len(flat), (len(mine), len(flat))
+sp.set_epoch(1)
+assert list(sp) != mine.tolist()
 dist.destroy_process_group()
 print('ok')
 '''
 
 
-def test_gradient_buckets_average_over_two_gloo_ranks(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_gradient_buckets_average_over_gloo_ranks(tmp_path, world):
+    """ramdsir.ddp.GradBuckets (three buckets, asynchronous + synchronous reduce), the loss-scalar mean and the DistributedSampler
+    shards at world 2 and at the node's real rank count 8 (SURVEY.md 8e), gloo on CPU."""
     script = tmp_path / 'w.py'
     script.write_text(_WORKER % (ROOT, os.path.join(ROOT, 'ram-dsir_amd')))
-    port = str(29500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-             for r in range(2)]
-    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    port = str(29500 + (os.getpid() + 17 * world) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, str(world)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and 'ok' in o, o
 

@@ -27,6 +27,8 @@ def test_bench_line_on_the_forced_data_parallel_path():
     assert [e['bucket'] for e in ex] == [2, 1, 0] and sum(e['bytes'] for e in ex) == 4 * 3800021
     assert all(e['allreduce_us'] > 0 for e in ex)
     assert cfg['ddp_comm']['own_comm_stream'] is False              # one rank: nothing to measure, the weight-gradient lane
+    lt = cfg['launch_threads']                                      # one host thread or one per lane: measured at start-up (ddp.py)
+    assert lt['how'] == 'measured' and lt['ms_per_step_one_thread'] > 0 and lt['ms_per_step_lane_threads'] > 0
     lay = cfg['lane_layout']
     assert len(lay) == 1 and set(lay[0]) >= {'main', 'side0', 'rec', 'budgets'} and lay[0]['budgets']['side_cus'] == 96
     assert cfg['ram_pipelined'] is True and abs(cfg['final_loss']) < 10

@@ -24,17 +24,18 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('graph', [0, 1])
-def test_two_ranks_on_one_gpu_average_gradients_and_stay_in_sync(graph):
+@pytest.mark.parametrize('graph,world', [(0, 2), (1, 2), (0, 8)])
+def test_ranks_on_one_gpu_average_gradients_and_stay_in_sync(graph, world):
+    """world 2 (eager and captured) and the node's real rank count, world 8 (eager): eight processes on cuda:0, each with its own batch."""
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ddp_worker.py'), '--rank', str(r), '--world', '2',
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ddp_worker.py'), '--rank', str(r), '--world', str(world),
                                '--port', str(port), '--graph', str(graph)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
-             for r in range(2)]
+             for r in range(world)]
     outs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=600)
+            o, _ = p.communicate(timeout=120 + 30 * world)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -56,7 +57,7 @@ def test_two_ranks_on_one_gpu_average_gradients_and_stay_in_sync(graph):
         assert r['iters'] == 2 and r['moved'] > 0, r
         assert r['bn_tracked'] == 4, r                    # 2 steps x 2 passes, rank-local
     assert res[0]['loss_local'] != res[1]['loss_local']   # different batches ...
-    assert res[0]['loss_mean'] == res[1]['loss_mean']     # ... one logged value
+    assert all(r['loss_mean'] == res[0]['loss_mean'] for r in res)     # ... one logged value
 
 
 def _run_workers(world, graph, backend, timeout=600):
