@@ -79,10 +79,17 @@ def initial_states():
     return (OU.encoder_state(seed=21), OU.decoder_state(num_classes=2, seed=22), OU.rec_decoder_state(num_classes=3, num_domains=3, seed=23))
 
 
-def train_oracle(stream, lr=2e-3):
+def train_oracle(stream, lr=2e-3, perturb_seed=None):
+    """perturb_seed: the initial conv weights and BatchNorm parameters multiplied by (1 + 1e-6 N(0, 1)) -- a one-ulp-sized perturbation
+    of the same start: what the spread of ONE recipe over 300 Adam steps is (the ReLU decisions amplify it, DESIGN.md numerics)."""
     from oracle import ram as OR, step as OS, unet as OU
     torch.set_num_threads(min(torch.get_num_threads(), 16))      # 64x64 convs: more threads than that only add overhead
     enc, dec, rec = (OU.clone_state(s) for s in initial_states())
+    if perturb_seed is not None:
+        g = torch.Generator().manual_seed(int(perturb_seed))
+        for sd in (enc, dec, rec):
+            for k in OU.param_keys(sd):
+                sd[k].mul_(1.0 + 1e-6 * torch.randn(sd[k].shape, generator=g))
     opt = {m: OS.adam_state({k: sd[k] for k in OU.param_keys(sd)}) for m, sd in (('enc', enc), ('dec', dec), ('rec', rec))}
     cfg = OS.StepConfig(dataset='fundus', batch_sizes=BATCH, consistency='kd', lr=lr, total_iters=len(stream))
     hist = []

@@ -1,0 +1,77 @@
+"""-m gpu: a same-hardware BITWISE golden of the fused HIP step -- the loss terms of 10 fp32 + 10 bf16 steps at 128 x 128 (batch 8 =
+[2,3,3], fixed weights and inputs) as float32 bit patterns, committed in tests/golden/hip_bitwise.json.  The step is bitwise
+reproducible (test_gpu_step.py::test_step_is_bitwise_reproducible), so on the same device type and library version ANY difference
+is a change of the arithmetic: a kernel edit that moves one ulp anywhere shows up here, where the oracle comparisons
+(test_gpu_fullsize.py, test_oracle_step.py) only hold the step to the reference's cross-host noise bands.
+
+Regenerate after an INTENDED change of the arithmetic or of the default schedule (tuning.py: lane budgets and tile shapes change the
+grouping of the fp32 partial sums and therefore the bits):
+    RD_REGEN_BITWISE=1 python -m pytest tests/test_gpu_bitwise_golden.py -m gpu      (on the GPU box; writes gpurun_out/hip_bitwise.json,
+    to be copied to tests/golden/hip_bitwise.json)
+Reference for what is computed: code/train.py:225-296 (the loss terms of train_fundus)."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden', 'hip_bitwise.json')
+DEV = 'cuda:0'
+STEPS, SIDE, BS = 10, 128, [2, 3, 3]
+
+
+def _bits(x):
+    return '%08x' % struct.unpack('<I', struct.pack('<f', float(x)))[0]
+
+
+def _run(dtype):
+    from ramdsir import step as S
+    import bench as Bn
+    torch.manual_seed(0)
+    bank, mods = S.make_bank(DEV, 3, 16, 2, len(BS))
+    Bn.init_weights(bank)
+    ts = S.TrainStep(bank, mods, dtype, BS, SIDE, SIDE, dataset='fundus', consistency='kd', lr=2e-3, total_iters=1000, ram='u8')
+    ts.wpack.refresh()
+    src, trg, lam, mask, _ = Bn.synth_inputs(sum(BS), SIDE, 0, DEV)
+    ts.load_raw(src, trg, lam)
+    ts.load_target(mask)
+    rows = []
+    for _ in range(STEPS):
+        ts.step()
+        torch.cuda.synchronize()
+        rows.append([_bits(v) for v in ts.losses[:6].tolist()] + [_bits(v) for v in ts.rec_mse.tolist()])
+    digest = _bits(float(bank.params.double().sum()))                     # every parameter after the last step, folded into one number
+    return rows, digest
+
+
+def test_loss_bits_of_ten_steps_match_the_committed_golden():
+    import sys
+    sys.path.insert(0, ROOT)
+    prop = torch.cuda.get_device_properties(0)
+    got = {'device': prop.name, 'compute_units': prop.multi_processor_count, 'steps': STEPS, 'side': SIDE, 'batch_split': BS,
+           'terms': ['seg1', 'dice1', 'seg2', 'dice2', 'consistency', 'seg_total', 'rec_d0', 'rec_d1', 'rec_d2']}
+    for name, dtype in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+        rows, digest = _run(dtype)
+        assert all(np.isfinite(struct.unpack('<f', bytes.fromhex(h)[::-1])[0]) for r in rows for h in r)
+        got[name] = {'loss_bits': rows, 'param_sum_bits': digest}
+    if os.environ.get('RD_REGEN_BITWISE') == '1' or not os.path.exists(GOLDEN):
+        out = os.path.join(ROOT, 'gpurun_out', 'hip_bitwise.json')
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        json.dump(got, open(out, 'w'), indent=1)
+        if not os.path.exists(GOLDEN):
+            pytest.skip('no committed golden yet: wrote %s' % out)
+        return
+    ref = json.load(open(GOLDEN))
+    if (ref['device'], ref['compute_units']) != (got['device'], got['compute_units']):
+        pytest.skip('golden recorded on %s with %d compute units, this is %s with %d: the lane budgets group the partial sums differently'
+                    % (ref['device'], ref['compute_units'], got['device'], got['compute_units']))
+    for name in ('f32', 'bf16'):
+        for it, (a, b) in enumerate(zip(got[name]['loss_bits'], ref[name]['loss_bits'])):
+            assert a == b, '%s step %d: terms %s differ from the golden (%s vs %s)' % (
+                name, it, [t for t, x, y in zip(got['terms'], a, b) if x != y], a, b)
+        assert got[name]['param_sum_bits'] == ref[name]['param_sum_bits'], name
