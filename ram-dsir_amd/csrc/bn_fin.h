@@ -197,6 +197,23 @@ __device__ __forceinline__ void bwd_coef(float gam, float is, float mu, const Bw
     R = -P * r.s1 / cnt - Q * mu;
 }
 
+// P, Q, R of ONE (group, channel) pair: for kernels that need only their own channels and keep them in a table of their own (the
+// weight gradients: a workgroup covers 64 of the layer's channels); no stores, no ownership
+__device__ __forceinline__ void bwd_pair(const FinArg& fa, int g, int c, float& P, float& Q, float& R) {
+    const rd_bn_bwd_t& q = fa.d.b;
+    const int C = q.C, ns = q.nslots > 0 ? q.nslots : RD_STAT_SLOTS;
+    double s1d, sgzd;
+    slot_sums(q.bstats, g, c, C, ns, s1d, sgzd);
+    const float* gp = q.gamma[0];
+    float cnt = q.count[0];
+#pragma unroll
+    for (int j = 1; j < FIN_MAX_G; ++j)
+        if (g == j) { gp = q.gamma[j]; cnt = q.count[j]; }
+    const float mu = q.mean[g * C + c], is = q.invstd[g * C + c], gam = gp[c];
+    const BwdStat r = bwd_stat(s1d, sgzd, mu, is);
+    bwd_coef(gam, is, mu, r, cnt, P, Q, R);
+}
+
 // backward: dz = P g + Q z + R coefficients for every (group, channel); owner: dgamma += sum g zhat, dbeta += sum g, in group order
 // lds: NULL, or 3 * G * C floats: [0] P, [1] R, [2] Q -- the order of rd_src_t's scale, shift, q for an RD_SRC_BNBWD source
 __device__ __forceinline__ void bwd(const FinArg& fa, float* lds = nullptr, bool all_write = true) {

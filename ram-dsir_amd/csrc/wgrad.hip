@@ -434,7 +434,11 @@ __device__ int wg_trace_key;
 #endif
 template <int NQZ, int XP>
 __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles, const rdfin::FinArg fa) {
-    rdfin::prologue(fa);                               // BatchNorm-backward finalize folded into this launch (bn_fin.h)
+    // BatchNorm-backward finalize folded into this launch (bn_fin.h).  Beside a gradient launch that owns it (the usual case) this
+    // kernel derives P / Q / R of ITS 64 gradient channels straight into its coefficient table below -- no stores, no read-back; as
+    // the owner (no gradient launch: not a geometry of this kernel in the network) it takes the global path
+    const bool fin_tab = fa.which >= 0 && !(fa.flags & RD_FIN_OWNER);
+    if (!fin_tab) rdfin::prologue(fa);
     typedef bf16_t T;
     constexpr int S = 8, TAPS = 9;
     constexpr int THW = 4;
@@ -477,6 +481,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(const rd_wgrad_t p, in
             const bool raw = sd.mode == RD_SRC_RAW || !live, bwd = sd.mode == RD_SRC_BNBWD && live;
             const int gs = sd.g_fixed >= 0 ? sd.g_fixed : g;
             float* row = s_coef + (size_t)((g * 2 + which) * 3) * 64 + c;
+            if (which && fin_tab && bwd) {
+                float P, Q, R;
+                rdfin::bwd_pair(fa, gs, cc, P, Q, R);
+                row[0] = P;
+                row[64] = R;
+                row[128] = Q;
+                continue;
+            }
             row[0] = raw ? 1.f : sd.scale[gs * sd.C + cc];
             row[64] = raw ? 0.f : sd.shift[gs * sd.C + cc];
             row[128] = bwd ? sd.q[gs * sd.C + cc] : 0.f;
