@@ -77,7 +77,9 @@ def parse_args(argv=None):
     p.add_argument('--activation', type=str, default='relu')
     p.add_argument('--gpu', type=str, default='0')
     # additions
-    p.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f32'], help='activation storage type of the fused step')
+    p.add_argument('--dtype', type=str, default=None, choices=['bf16', 'f32'],
+                   help='activation storage type; default: bf16 for the fused step (--norm bn), f32 for the module-level loop of --norm gn / in '
+                        '(its modules are process-wide objects that validation shares: fp32 is their parity-grade mode)')
     p.add_argument('--log_every', type=int, default=20)
     p.add_argument('--num_workers', type=int, default=8)
     p.add_argument('--max_iters', type=int, default=None, help='stop early (smoke runs)')
@@ -252,7 +254,7 @@ def main(args):
         print('norm=%s: module-level training loop (torch autograd between the HIP modules)' % args.norm)
     trainer = Trainer(encoder, seg_decoder, rec_decoder, bsl[:len(domain_idx_list)], H, W, dataset=args.dataset,
                            consistency=cons, lambda_rec=args.lambda_rec, lr=args.lr, total_iters=total_iters,
-                           dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+                           dtype=torch.bfloat16 if (args.dtype or ('bf16' if args.norm == 'bn' else 'f32')) == 'bf16' else torch.float32)
 
     writer = SummaryWriter(os.path.join(args.save_path, 'log')) if rank == 0 else None      # train.py:538
     previous_best, iter_num = 0.0, 0

@@ -102,13 +102,21 @@ def train_oracle(stream, lr=2e-3, perturb_seed=None):
     return (enc, dec), hist
 
 
-def train_hip(stream, dtype, lr=2e-3, device='cuda:0'):
+def train_hip(stream, dtype, lr=2e-3, device='cuda:0', perturb_seed=None, options=None):
+    """perturb_seed: as in train_oracle (the same perturbed start for the same seed)."""
     from ramdsir import step as S_
     from ramdsir import engine as E
+    from oracle import unet as OU
     bank, mods = S_.make_bank(device, 3, 16, 2, 3)
-    for m, sd in zip(('enc', 'dec', 'rec'), initial_states()):
+    states = [OU.clone_state(sd) for sd in initial_states()]
+    if perturb_seed is not None:
+        g = torch.Generator().manual_seed(int(perturb_seed))
+        for sd in states:
+            for k in OU.param_keys(sd):
+                sd[k].mul_(1.0 + 1e-6 * torch.randn(sd[k].shape, generator=g))
+    for m, sd in zip(('enc', 'dec', 'rec'), states):
         S_.load_state(bank, m, sd)
-    ts = S_.TrainStep(bank, mods, dtype, BATCH, S, S, dataset='fundus', consistency='kd', lr=lr, total_iters=len(stream), ram='u8')
+    ts = S_.TrainStep(bank, mods, dtype, BATCH, S, S, dataset='fundus', consistency='kd', lr=lr, total_iters=len(stream), ram='u8', options=options)
     ts.wpack.refresh()
     hist = []
     for src, trg, lam, msk in stream:

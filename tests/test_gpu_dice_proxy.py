@@ -2,16 +2,18 @@
 300 iterations at 64x64, batch 8 = [2,3,3] over three source domains, same initial weights and batch stream for every
 run; held-out domain 0 evaluated as code/train.py:91-132 does.
 
-What was measured (profiles/r03_dice_proxy.json from scripts/dice_proxy_run.py, plus two runs of this test on other boxes;
-avg = (cup + disc) * 100 / 2) BEFORE the step became bitwise reproducible (fp64 accumulation of the BatchNorm sums inside a workgroup,
-csrc/conv_device.h flush_bstats) -- i.e. the spread below is what ulp-level differences in the statistics do to 300 Adam steps:
-  fp32 oracle 90.0 / 89.4 / 89.4 by host (three runs from initial weights perturbed by 1e-6 on one host: 89.8 / 90.2 / 90.1);
-  HIP fp32 89.1 89.6 90.5 | 90.7 89.8 89.2 | 91.4 90.1 91.1: mean 90.2, sd 0.8;
-  bf16: the oracle under the bf16 rounding model (oracle.unet.rounding) 91.2 / 89.9 / 89.9; HIP bf16 92.0 92.9 93.0 | 94.3 92.5 93.2
-  | 92.8 88.5 94.6: mean 92.6, sd 1.7 -- ABOVE the fp32 reference by 2.5 points, and above the rounding-model oracle too, so the
-  rounding points alone do not explain it (bf16 noise acts as a regulariser on this small task; the spread is twice fp32's).
-Now two HIP runs of a dtype are the SAME run (asserted below: identical trained weights), so a single run is a draw from those
-distributions: it is held to 3.5 points of the fp32 oracle (fp32), and one-sidedly to "not more than 3.5 below" (bf16)."""
+What was measured.  Round 3 (profiles/r03_dice_proxy.json; before the step became bitwise reproducible, so repeated HIP runs were
+different draws): fp32 oracle 90.0 / 89.4 / 89.4 by host; HIP fp32 mean 90.2, sd 0.8 (9 runs); oracle under the bf16 rounding model
+(oracle.unet.rounding) 91.2 / 89.9 / 89.9; HIP bf16 mean 92.6, sd 1.7 (9 runs) -- 2.5 points above the rounding model, unexplained then.
+Round 5 (the step is deterministic now, so the spread is probed the way the reference's own is: initial parameters x (1 + 1e-6 N(0,1)),
+the SAME perturbation seeds for every trainer; scripts/dice_proxy_oracle_spread.py on the CPU, scripts/dice_proxy_hip_spread.py on the
+GPU; profiles/r05_dice_proxy_oracle_spread.json, profiles/r05_dice_proxy_hip_spread.json):
+  oracle, bf16 rounding model   mean 90.6, sd 0.7 (8 runs)        HIP bf16   mean 91.5, sd 1.2 (8 runs; the unperturbed run: 92.79)
+  oracle, fp32                  (see the json)                    HIP fp32   mean 90.3, sd 0.9 (8 runs; the unperturbed run: 90.21)
+The bf16 "gap" is 0.9 +- 0.5 points between the two DISTRIBUTIONS (2 sigma) -- the 2.5 of round 3 compared nine noisy HIP draws, whose
+unperturbed member happens to be a high one, with two or three oracle runs.  What remains is a wider spread of the bf16 HIP step (1.2
+against 0.7), not a shift that the rounding points fail to explain.  The gates: one HIP run of a dtype against the oracle of the same
+arithmetic, TWO-SIDED, 3.5 points = 2.5 sigma of the difference of two draws (sqrt(1.2^2 + 0.7^2) = 1.4)."""
 import numpy as np
 import pytest
 import torch
@@ -54,8 +56,9 @@ def test_runs_learn_the_task_and_agree_on_held_out_dice(runs):
         for sa, sb in zip(runs[k][0][0], runs[k][1][0]):     # (encoder, decoder) state dicts of run 0 / run 1
             for key in sa:
                 assert torch.equal(sa[key], sb[key]), (k, key)
-    assert max(abs(v - ref) for v in avg['hip_f32']) <= 3.5, avg     # fp32 kernels vs the fp32 reference arithmetic (sd of a draw: 0.8)
-    assert min(avg['hip_bf16']) >= ref - 3.5, avg            # the bench dtype is not worse than the reference's fp32 (sd of a draw: 1.7)
+    assert max(abs(v - ref) for v in avg['hip_f32']) <= 3.5, avg     # fp32 kernels vs the fp32 reference arithmetic (sd of a draw: 0.9)
+    assert max(abs(v - ref_b) for v in avg['hip_bf16']) <= 3.5, avg  # bf16 kernels vs the oracle with the same rounding points, TWO-SIDED
+    assert min(avg['hip_bf16']) >= ref - 3.5, avg            # ... and the bench dtype is not worse than the reference's fp32
     assert ref_b >= ref - 2.5, avg                           # nor is the oracle with the same rounding points
 
 
