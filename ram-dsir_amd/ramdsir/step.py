@@ -36,7 +36,8 @@ class TrainStep:
         # ---- graphs
         self.opt = opt = T.options(options)
         self.seg = E.Plan(bank, dtype, 2 * B, [0, B, 2 * B], slope=slope)
-        self.seg.pad_narrow = self.seg.materialize_up = True
+        self.seg.pad_narrow = True
+        self.seg.materialize_up = bool(opt['up_mat'])
         self.seg.materialize_pool = bool(opt['pool_mat'])
         self.seg.fused_bwd = bool(opt['fused_bwd'])
         self.seg.fold_finalize = int(opt['fold_finalize'])
@@ -60,7 +61,8 @@ class TrainStep:
         for b in batch_sizes:
             gs.append(gs[-1] + b)
         self.rec = E.Plan(bank, dtype, B, gs, slope=slope)
-        self.rec.pad_narrow = self.rec.materialize_up = True
+        self.rec.pad_narrow = True
+        self.rec.materialize_up = self.seg.materialize_up
         self.rec.materialize_pool = self.seg.materialize_pool
         self.rec.fused_bwd = self.seg.fused_bwd
         self.rec.fold_finalize = self.seg.fold_finalize

@@ -11,6 +11,8 @@ DEFAULTS = dict(
                           # weight gradient both read the two operands and the extra pass (14 launches, 0.25 ms of main-lane time) is gone:
                           # 4.36 -> 4.23 ms/step together with side_cus 128 -> 96 (docs/experiments.md, round-4 rows)
     mat_dz_wide=True,     # with mat_dz_min_c > 0: ... and for a 32-channel layer whose gradient launch is 64-wide (engine.Plan.build)
+    up_mat=True,          # store y = up2(t) once (rd_up_stats) instead of interpolating t in the loaders of the 3x3 conv behind it (round 5: 4.19 vs
+                          # 5.0+ ms/step, docs/experiments.md)
     pool_mat=True,        # store the 2x2 max-pool in front of ConvD levels 2-5 once (rd_pool_fwd / rd_pool_bwd)
     fused_bwd=True,       # <= 32-channel 3x3 convs (bf16): dgrad + weight gradient in one launch (csrc/conv_fused.hip)
     split_wide_dgrad=False,  # a one-chunk gradient launch with 33..64 output channels as two launches of the small-channel kernel
@@ -61,7 +63,7 @@ DEFAULTS = dict(
                           # folded BatchNorm-backward finalize) instead of in front of it with a prologue of its own
     conv_nb1_below=300,   # mirrors csrc/conv_big.hip: 64-wide launches below this many workgroups run 32-wide tiles (meta only)
 )
-_ENV = dict(split_wide_dgrad='RD_SPLIT_WIDE_DGRAD', mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', mat_dz_wide='RD_MAT_DZ_WIDE', pool_mat='RD_POOL_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
+_ENV = dict(split_wide_dgrad='RD_SPLIT_WIDE_DGRAD', mat_min_c='RD_MAT_MINC', mat_dz_min_c='RD_MAT_DZ_MINC', mat_dz_wide='RD_MAT_DZ_WIDE', pool_mat='RD_POOL_MAT', up_mat='RD_UP_MAT', side_streams='RD_SIDE_STREAMS', side_cus='RD_SIDE_CUS', rec_cus='RD_REC_CUS',
             ddp_own_comm_stream='RD_DDP_OWN_COMM', fused_bwd='RD_FUSED_BWD_HOST', fork='RD_FORK', store_wgrad_operands='RD_STORE_WGRAD_OPS', launch_threads='RD_LAUNCH_THREADS', dgrad_cus='RD_DGRAD_CUS', rec_lane='RD_REC_LANE', rec_wgrad_late='RD_REC_WGRAD_LATE', graph_fork='RD_GRAPH_FORK', conv_nb1_below='RD_CONV_NB1_BELOW', fold_finalize='RD_FOLD_FINALIZE', fold_wgrad_behind='RD_FOLD_WGRAD_BEHIND', fold_fwd_kinds='RD_FOLD_FWD_KINDS')
 
 
