@@ -43,9 +43,14 @@ __device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // wrong when set): 1 no MFMAs / fragment reads, 2 no stores, 4 no transform / LDS writes, 16 no epilogue
 // NSL: live 16-byte channel slots of the input: 1, 2 or 4.  OUTV: 16-byte output vectors per lane: 2 (Cout 32), 1 (Cout 16), 3 (Cout <= 4:
 // the network's output layers, four unconditional scalar stores per lane), 0 (any other Cout, element-wise conditional stores)
-template <int NSL, int OUTV, int XP>
+// RD_SW_XP_ALL (compile-time, -DRD_SW_XP_ALL=bits: timing builds of EVERY instantiation, scripts/ab_layers_lib.sh; results wrong when set)
+#ifndef RD_SW_XP_ALL
+#define RD_SW_XP_ALL 0
+#endif
+template <int NSL, int OUTV, int XP_>
 __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t p, int tiles_per_wg, const rdfin::FinArg fa) {
     typedef bf16_t T;
+    constexpr int XP = XP_ | RD_SW_XP_ALL;
     constexpr int S = 8, NV = 2;
     constexpr int NKS = NSL <= 2 ? 1 : 2;                // k-steps of 16 channels
     constexpr int NSH = NSL == 1 ? 0 : (NSL == 2 ? 1 : 2);
@@ -232,6 +237,21 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         if constexpr (!(XP & 1)) {
+            if constexpr (NKS == 1) {
+                // <= 16 input channels: all nine fragments requested before the first MFMA (36 registers this instantiation has): one LDS
+                // round trip per tile instead of one per kernel row
+                uint4 f[3][3];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) f[kh][kw] = *reinterpret_cast<const uint4*>(s_in + foff[kh][kw]);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[kh * 3 + kw][0]),
+                                                                      __builtin_bit_cast(bf16x8, f[kh][kw]), acc, 0, 0, 0);
+            } else {
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 uint4 f[3][NKS];
@@ -245,6 +265,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
                     for (int ks = 0; ks < NKS; ++ks)
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[kh * 3 + kw][ks]),
                                                                       __builtin_bit_cast(bf16x8, f[kw][ks]), acc, 0, 0, 0);
+            }
             }
         }
         if constexpr ((XP & 16) != 0) return;
