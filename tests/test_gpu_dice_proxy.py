@@ -8,9 +8,9 @@ different draws): fp32 oracle 90.0 / 89.4 / 89.4 by host; HIP fp32 mean 90.2, sd
 Round 5 (the step is deterministic now, so the spread is probed the way the reference's own is: initial parameters x (1 + 1e-6 N(0,1)),
 the SAME perturbation seeds for every trainer; scripts/dice_proxy_oracle_spread.py on the CPU, scripts/dice_proxy_hip_spread.py on the
 GPU; profiles/r05_dice_proxy_oracle_spread.json, profiles/r05_dice_proxy_hip_spread.json):
-  oracle, bf16 rounding model   mean 90.6, sd 0.7 (8 runs)        HIP bf16   mean 91.5, sd 1.2 (8 runs; the unperturbed run: 92.79)
-  oracle, fp32                  (see the json)                    HIP fp32   mean 90.3, sd 0.9 (8 runs; the unperturbed run: 90.21)
-The bf16 "gap" is 0.9 +- 0.5 points between the two DISTRIBUTIONS (2 sigma) -- the 2.5 of round 3 compared nine noisy HIP draws, whose
+  oracle, bf16 rounding model   mean 90.7, sd 0.7 (8 runs)        HIP bf16   mean 91.5, sd 1.2 (8 runs; the unperturbed run: 92.79)
+  oracle, fp32                  mean 90.1, sd 0.6 (8 runs)        HIP fp32   mean 90.3, sd 0.9 (8 runs; the unperturbed run: 90.21)
+The bf16 "gap" is 0.8 +- 0.5 points between the two DISTRIBUTIONS (1.7 sigma; fp32: 0.2 +- 0.4) -- the 2.5 of round 3 compared nine noisy HIP draws, whose
 unperturbed member happens to be a high one, with two or three oracle runs.  What remains is a wider spread of the bf16 HIP step (1.2
 against 0.7), not a shift that the rounding points fail to explain.  The gates: one HIP run of a dtype against the oracle of the same
 arithmetic, TWO-SIDED, 3.5 points = 2.5 sigma of the difference of two draws (sqrt(1.2^2 + 0.7^2) = 1.4)."""
