@@ -32,7 +32,8 @@ import torch
 #   conv64     3x3 convs on 64-wide output-channel tiles (conv_ws_kernel + conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> + conv_pp_kernel), MFMA-bound
 #   wgrad      the stand-alone weight gradients (>= 64-channel layers, 1x1 convs, the first conv): MFMA kernel + split reduce
 #   conv_small forward (and the few unfused gradient) launches of the <= 32-channel convs (conv_small_fwd_kernel / conv_small_kernel), HBM-bound
-#   ram        Random Amplitude Mixup: rd_ram_mix = row FFT + column FFT / window mix / inverse column FFT + inverse row FFT (3 kernels), HBM-bound
+#   ram        Random Amplitude Mixup: rd_ram_mix = kept row bins (matrix-core DFT for uint8 images, else row FFT) + column FFT / window mix /
+#              inverse column FFT + inverse row FFT with the output epilogue (3 kernels), HBM-bound
 # The HEADLINE `roofline` is not a constant: bench.py times the step with each of the three families that hold the most kernel time
 # left out (scripts/ablate_step.py's measurement, inside this run) and headlines the one whose absence shortens the step most
 # (`dominant_by_step_cost`); `dominant_by_kernel_time` is reported beside it.  The other families follow as roofline_<name>.
@@ -45,8 +46,8 @@ FAMILIES = {
                   count=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel')),
     'conv_small': dict(match=lambda m: str(m.get('kernel', '')).startswith('conv_small_kernel'),
                        symbols=('conv_small_fwd_kernel', 'conv_small_kernel'), count=None),
-    'ram': dict(match=lambda m: m.get('kernel') == 'ram', symbols=('ram_row_fwd_kernel', 'ram_col_mix_kernel', 'ram_row_inv_kernel'),
-                count=('ram_row_fwd_kernel',)),
+    'ram': dict(match=lambda m: m.get('kernel') == 'ram', symbols=('ram_row_dft_kernel', 'ram_row_fwd_kernel', 'ram_col_mix_kernel', 'ram_row_inv_kernel'),
+                count=('ram_col_mix_kernel',)),
 }
 PMC_JSON = os.path.join(ROOT, 'profiles', 'dominant_kernel_pmc.json')
 SQ_JSON = os.path.join(ROOT, 'profiles', 'r04_mfma_busy.json')
@@ -240,6 +241,7 @@ def kernel_roofline(ts, fam, eager=True):
         evs.append((e0, e1))
         acc['nbytes'] += meta['bytes']
         acc['flops'] += meta['flops']
+        acc['built'] = acc.get('built', 0) + meta.get('bytes_as_built', 0)
 
     lanes = ts.lanes() if eager else {}
     ts.run_segment(ts.seg_a + ts.seg_b, main, lanes, wrap)
@@ -272,6 +274,14 @@ def kernel_roofline(ts, fam, eager=True):
                achieved_gbs=round(gbs, 1), achieved_tflops=round(tfs, 1))
     if traffic:
         out['traffic_over_algorithmic'] = round(traffic / (nbytes / n), 3)
+    if acc.get('built'):
+        # the same launches priced on the bytes of the path AS BUILT (uint8 pixels in, fp32 spectra of the kept bins between the passes,
+        # one 16-byte slot per pixel and output tensor out) beside SURVEY.md 8(d)'s fp32-in / fp32-out convention above
+        built = acc['built'] / n
+        out.update(avg_bytes_as_built=int(built), achieved_gbs_as_built=round(built * n / (total_ms * 1e-3) / 1e9, 1),
+                   frac_as_built=round(built * n / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        if traffic:
+            out['traffic_over_as_built'] = round(traffic / built, 3)
     return out
 
 

@@ -395,9 +395,17 @@ typedef struct {
     float div;
     int32_t pad_;
     const float* trg_amp;
+    const void* dft_tables;     /* rd_ram_dft_tables() output for this (H, W, b), or NULL: see below */
 } rd_ram_t;
 int64_t rd_ram_workspace(int B, int H, int W, int b);
 int rd_ram_mix(const rd_ram_t* p, int dtype, void* stream);
+/* The mix only needs the bins |kx|, |ky| <= b of each spectrum (41 of 201 row bins at 400 x 400): with coefficient tables for the
+ * geometry -- rd_ram_dft_tables_bytes() bytes of device memory filled ONCE by rd_ram_dft_tables (fp64 sincos, three bf16 terms per
+ * coefficient) and passed as rd_ram_t.dft_tables -- rd_ram_mix computes exactly those bins as matrix products on the matrix cores
+ * (csrc/ram_dft.hip) instead of whole FFTs on the vector units.  dft_tables == NULL, or a geometry the matrix path does not take
+ * (rd_ram_dft_tables_bytes returns 0: W not a multiple of 16): the FFT kernels. */
+int64_t rd_ram_dft_tables_bytes(int H, int W, int b);
+int rd_ram_dft_tables(void* tables, int H, int W, int b, void* stream);
 
 /* The reference's free functions on their own (API parity; the training step uses rd_ram_mix):
  *   rd_ram_amp     extract_amp_spectrum (fundus.py:13-19): amp[C][H][W] = |fft2(img[C][H][W])|, fp32

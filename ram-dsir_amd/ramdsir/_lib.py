@@ -72,7 +72,7 @@ class RdRam(C.Structure):
     _fields_ = [('src', fp), ('trg', fp), ('lam', fp), ('out_img', vp), ('out_freq', vp), ('workspace', vp),
                 ('tw_w', fp), ('tw_h', fp), ('B', i32), ('H', i32), ('W', i32), ('C', i32), ('b', i32),
                 ('clip_lo', f32), ('clip_hi', f32), ('scale', f32), ('offset', f32), ('out_cstride', i32), ('src_u8', i32),
-                ('div', f32), ('pad_', i32), ('trg_amp', fp)]
+                ('div', f32), ('pad_', i32), ('trg_amp', fp), ('dft_tables', vp)]
 
 
 class RdPackEntry(C.Structure):
@@ -97,6 +97,8 @@ OP_CODES = {name: 10 + i for i, name in enumerate((
 _SIGS = {
     'rd_ram_workspace': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'rd_ram_mix': (C.c_int, [C.POINTER(RdRam), C.c_int, vp]),
+    'rd_ram_dft_tables_bytes': (i64, [C.c_int, C.c_int, C.c_int]),
+    'rd_ram_dft_tables': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     'rd_ram_amp_workspace': (i64, [C.c_int, C.c_int, C.c_int]),
     'rd_ram_amp': (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp, fp, fp, vp]),
     'rd_ram_mutate': (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]),

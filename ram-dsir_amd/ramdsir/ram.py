@@ -22,6 +22,25 @@ def _twiddle(n, device):
     return torch.from_numpy(t).to(device)
 
 
+_TABLES = {}
+
+
+def dft_tables(H, W, b, device):
+    """Coefficient tables of the matrix-core path for one geometry (rd_ram_dft_tables, built once per process and device), or None
+    when the geometry runs the FFT kernels."""
+    key = (H, W, b, str(device))
+    if key not in _TABLES:
+        lib = L.lib()
+        n = int(lib.rd_ram_dft_tables_bytes(H, W, b))
+        t = None
+        if n > 0:
+            t = torch.empty(n, dtype=torch.uint8, device=device)
+            L.check(lib.rd_ram_dft_tables(t.data_ptr(), H, W, b, torch.cuda.current_stream(device).cuda_stream), 'rd_ram_dft_tables')
+            torch.cuda.current_stream(device).synchronize()
+        _TABLES[key] = t
+    return _TABLES[key]
+
+
 class RamMixer:
     """Plan for one (B, H, W) geometry.  `fundus`: inputs on the 0..255 scale, clip [0,255], /127.5-1
     (fundus.py:215-225); `prostate`: inputs in [-1,1], clip [-1,1] (prostate.py:188)."""
@@ -34,8 +53,10 @@ class RamMixer:
         lib = L.lib()
         self.ws = E.workspace(lib.rd_ram_workspace(B, H, W, self.b) // 4, device)
         self.tw_w, self.tw_h = _twiddle(W, device), _twiddle(H, device)
+        self.tables = dft_tables(H, W, self.b, device)
         p = L.RdRam()
         p.workspace, p.tw_w, p.tw_h = self.ws.data_ptr(), self.tw_w.data_ptr(), self.tw_h.data_ptr()
+        p.dft_tables = self.tables.data_ptr() if self.tables is not None else None
         p.B, p.H, p.W, p.C, p.b = B, H, W, 3, self.b
         if dataset == 'fundus':
             # x / 127.5 - 1 as a DIVISION: bit for bit numpy's `img /= 127.5; img -= 1.0` (fundus.py:217-218)
@@ -47,7 +68,8 @@ class RamMixer:
     def share_workspace(self, other):
         """Use another mixer's workspace and twiddle tables (same geometry; the two are never in flight together)."""
         assert (self.B, self.H, self.W, self.b) == (other.B, other.H, other.W, other.b)
-        self.ws, self.tw_w, self.tw_h = other.ws, other.tw_w, other.tw_h
+        self.ws, self.tw_w, self.tw_h, self.tables = other.ws, other.tw_w, other.tw_h, other.tables
+        self.p.dft_tables = self.tables.data_ptr() if self.tables is not None else None
         self.p.workspace, self.p.tw_w, self.p.tw_h = self.ws.data_ptr(), self.tw_w.data_ptr(), self.tw_h.data_ptr()
 
     def bind(self, src, trg, lam, out_img, out_freq, trg_amp=None):
@@ -69,8 +91,17 @@ class RamMixer:
         # meta for bench.py's family table: algorithmic bytes by SURVEY.md 8(d)'s convention = source + partner + output once as
         # fp32, 12 * C * H * W per image (the uint8 pipeline reads less and the bf16 output writes less; the convention is kept so
         # that the figure is comparable with the reference's numpy path, code/dataset/fundus.py:13-61); ~62 MFLOP per 400 x 400 image
+        # bytes_as_built: what the three kernels have to move -- source + partner pixels once for the row pass (1 or 4 bytes per value) and
+        # the source again for the output pass, the kept row bins [2B][3][H][KP] complex64 written and read, the column results
+        # [B][3][H][KP] written and read, and the two output tensors at their pixel stride
+        px = self.H * self.W * self.B
+        ebytes = 1 if self.p.src_u8 else 4
+        kp = (self.b + 1 + 3) // 4 * 4
+        spec = 3 * self.H * kp * 8 * self.B
+        out_b = 2 * px * max(int(self.p.out_cstride), 3) * (2 if self.dtype == torch.bfloat16 else 4)
         return (L.lib().rd_ram_mix, (C.byref(self.p), self.dt),
                 dict(kernel='ram', what='mix', layer='ram', bytes=12 * 3 * self.H * self.W * self.B,
+                     bytes_as_built=3 * px * 3 * ebytes + 2 * (2 * spec) + 2 * spec + out_b,
                      flops=int(62e6 * self.H * self.W / 160000.0) * self.B))
 
     def run(self, stream=None):

@@ -1,11 +1,12 @@
 #!/bin/bash
-# ON THE GPU BOX: rd_ram_mix alone under the debug library's geometry switches.
+# ON THE GPU BOX: rd_ram_mix alone under the debug library's switches.  RD_RAM_WAVE bits 0 / 1 / 2 = the wave-level kernel for the row
+# forward / column mix / row inverse pass (csrc/ram_wavefft.h); 0 = the Stockham kernels for all three.
 cd $GRAFT_REPO_ROOT
 export RAMDSIR_DEBUG_LIB=1
-for spec in "default:X=1" "fwd1:RD_RAM_ROWS_FWD=1" "kt2:RD_RAM_KT=2" "kt1:RD_RAM_KT=1" "inv1:RD_RAM_ROWS_INV=1" "inv4:RD_RAM_ROWS_INV=4" "fwd1kt2:RD_RAM_ROWS_FWD=1,RD_RAM_KT=2" "fwd1kt2inv4:RD_RAM_ROWS_FWD=1,RD_RAM_KT=2,RD_RAM_ROWS_INV=4"; do
+for spec in "wave-all:RD_RAM_WAVE=7" "stockham:RD_RAM_WAVE=0" "wave-A:RD_RAM_WAVE=1" "wave-B:RD_RAM_WAVE=2" "wave-C:RD_RAM_WAVE=4"; do
   name=${spec%%:*}; vars=${spec#*:}
   ( IFS=','; for kv in $vars; do export "$kv"; done; echo -n "$name: "; python scripts/ram_bench.py u8 400 2>&1 | tail -1 )
 done
-python scripts/ram_bench.py f32 400 | tail -1
-python scripts/ram_bench.py u8 256 | tail -1
-python scripts/ram_bench.py u8 512 | tail -1
+for a in "f32 400" "u8 256" "u8 384" "u8 512"; do
+  for w in 7 0; do echo -n "RD_RAM_WAVE=$w: "; RD_RAM_WAVE=$w python scripts/ram_bench.py $a | tail -1; done
+done

@@ -54,12 +54,15 @@ def test_ram_benchmark_sizes_vs_oracle(S):
         np.testing.assert_allclose(frq[i], of, rtol=0, atol=2e-3 / 127.5)
         np.testing.assert_array_equal(img[i], oi)
     np.testing.assert_allclose(frq[2], img[2], atol=1e-6)        # lambda = 1 is the identity (then clip)
-    # uint8 inputs (decoded PNG pixels, 1 byte per value): the same integers -> the same result bit for bit
+    # uint8 inputs (decoded PNG pixels, 1 byte per value): the same integers.  img bit for bit; the mixed image within the fp32 rounding of
+    # the two row passes (uint8 rows run the matrix-core DFT of csrc/ram_dft.hip, fp32 rows the FFT)
     s8 = torch.from_numpy(np.stack(src).astype(np.uint8)).to(DEV)
     t8 = torch.from_numpy(np.stack(trg).astype(np.uint8)).to(DEV)
     img8, frq8 = R.source_to_target_freq_batch(s8, t8, torch.tensor(lam, dtype=torch.float32, device=DEV), 'fundus', torch.float32)
     np.testing.assert_array_equal(img8.cpu().numpy(), img)
-    np.testing.assert_array_equal(frq8.cpu().numpy(), frq)
+    np.testing.assert_allclose(frq8.cpu().numpy(), frq, rtol=0, atol=2e-4 / 127.5)
+    for i in range(B):
+        np.testing.assert_allclose(frq8[i].cpu().numpy(), OR.ram_fundus(src[i], trg[i], lam[i])[1], rtol=0, atol=2e-3 / 127.5)
 
 
 def test_ram_prostate_call_site_and_bf16_output():
@@ -75,6 +78,38 @@ def test_ram_prostate_call_site_and_bf16_output():
         assert frq[i].min() >= -1 and frq[i].max() <= 1
     imgb, frqb = _run(src, trg, lam, 'prostate', torch.bfloat16)
     np.testing.assert_allclose(frqb, frq, rtol=0, atol=2 ** -8)    # bf16 storage of values in [-1,1]
+
+
+def test_matrix_core_row_pass_agrees_with_the_fft_row_pass():
+    """uint8 images with coefficient tables run the row pass on the matrix cores (csrc/ram_dft.hip); without tables, and for fp32
+    pixels, the FFT kernels: the same result within the fp32 rounding of either (2e-4 on the 0..255 scale), at every bench side, with
+    rows that do not fill the last 32-row block and a batch of mixed ratios."""
+    from ramdsir import _lib as L
+    lib = L.lib()
+    for S, H in ((400, 400), (256, 256), (384, 384), (512, 512), (400, 72), (320, 200)):
+        rng = np.random.RandomState(S + H)
+        B = 3
+        src = torch.from_numpy(rng.randint(0, 256, (B, H, S, 3)).astype(np.uint8)).to(DEV)
+        trg = torch.from_numpy(rng.randint(0, 256, (B, H, S, 3)).astype(np.uint8)).to(DEV)
+        src[1, :, :, 2] = 0                                  # an all-zero channel: |F_src| == 0, the reference's angle() == 0 branch
+        lam = torch.tensor([0.1, 0.5, 0.9], dtype=torch.float32, device=DEV)
+        outs = []
+        for tables in (True, False):
+            m = R.RamMixer(B, H, S, torch.float32, DEV, 'fundus')
+            assert m.tables is not None and int(lib.rd_ram_dft_tables_bytes(H, S, m.b)) == m.tables.numel()
+            if not tables:
+                m.p.dft_tables = None
+            oi = torch.empty(B, H, S, 3, device=DEV)
+            of = torch.empty(B, H, S, 3, device=DEV)
+            m.bind(src, trg, lam, oi, of)
+            m.run()
+            torch.cuda.synchronize()
+            outs.append((oi.cpu().numpy(), of.cpu().numpy()))
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
+        np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-4 / 127.5, err_msg=str((S, H)))
+        assert np.abs(outs[0][1] - outs[0][0]).max() > 0.05          # the mix did something
+    assert int(lib.rd_ram_dft_tables_bytes(400, 250, 25)) == 0       # a width the matrix pass does not take: the FFT kernels
+    assert R.dft_tables(400, 250, 25, DEV) is None
 
 
 def test_ram_rejects_unsupported_sizes():
