@@ -11,7 +11,7 @@ Sz = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 bank, mods = S.make_bank('cuda:0', 3, 16, 2, 3)
 Bn.init_weights(bank)
-ts = S.TrainStep(bank, mods, dtype, [2, 3, 3], Sz, Sz, ram=True)
+ts = S.TrainStep(bank, mods, dtype, [2, 3, 3], Sz, Sz, ram='u8')           # uint8 pixels, as bench.py's Fundus workload
 ts.wpack.refresh()
 src, trg, lam, mask, _ = Bn.synth_inputs(8, Sz, 0, 'cuda:0')
 ts.load_raw(src, trg, lam); ts.load_target(mask)
