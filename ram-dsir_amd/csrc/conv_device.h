@@ -708,6 +708,26 @@ __device__ __forceinline__ void flush_half_wave_sums16(double* s_red, const floa
     atomicAdd(&s_red[ch * 2 + (idx & 1)], (double)r[0]);
 }
 
+// The same sums WITHOUT atomics: wave `wave` leaves its 64 values (channel, statistic) in s_part[wave][64]; the caller adds the waves in
+// index order behind a barrier.  LDS atomics arrive in a timing-dependent order, and an fp64 sum is only independent of the order while
+// the terms span less than 2^29 in magnitude -- per-wave sums over a few rows do not always (scripts/conv_repeat_stress.py).
+template <int S, int NV>
+__device__ __forceinline__ void store_half_wave_sums16(double* s_part, int wave, const float (&sa)[NV][S], const float (&sb)[NV][S], int li, int h) {
+    static_assert(NV * S == 16, "16 channels per lane");
+    float r[32];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            r[(v * S + e) * 2 + 0] = sa[v][e];
+            r[(v * S + e) * 2 + 1] = sb[v][e];
+        }
+    half_wave_sums<32>(r, li);
+    const int idx = half_wave_sum_index(li), c = idx >> 1;
+    const int ch = 2 * S * (c / S) + S * h + (c % S);
+    s_part[wave * 64 + ch * 2 + (idx & 1)] = (double)r[0];
+}
+
 // sum b1/b2 over the lanes of a wave that own the same channel slot (lane % SL), then one LDS atomic per
 // wave and channel instead of one per thread (64-way same-address contention otherwise)
 template <int S, int SL>

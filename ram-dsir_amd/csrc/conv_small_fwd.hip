@@ -47,14 +47,24 @@ __device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 #ifndef RD_SW_XP_ALL
 #define RD_SW_XP_ALL 0
 #endif
-template <int NSL, int OUTV, int XP_>
-__global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t p, int tiles_per_wg, const rdfin::FinArg fa) {
+#ifndef RD_SW_NWV_DEFAULT
+#define RD_SW_NWV_DEFAULT 8
+#endif
+// NWV: waves per workgroup.  8 (the product): one workgroup per CU, wave w owns tile row w.  4 (debug library, RD_SW_NWV=4; inputs of <= 16
+// channels): TWO independent 256-thread workgroups per CU, wave w owns rows w and w + 4 -- the phases of a tile (requests, transform,
+// products, epilogue) are serial inside a workgroup (one barrier per tile), two workgroups interleave theirs without one: 58 -> 45 us for
+// the 16 -> 16 launches at 400 x 400, the step 4.63 -> 4.55 ms (debug library).  NOT the default: 8 of 310 repetitions of a 300-step training
+// run gave different final weights with it, none of 230 with NWV = 8 (scripts/determinism_ab.sh; a single launch repeated 10 000 times is
+// bitwise stable either way, scripts/conv_repeat_stress.py) -- an interaction in the step that is not understood yet.
+template <int NSL, int OUTV, int XP_, int NWV>
+__global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_small_fwd_kernel(const rd_conv_t p, int tiles_per_wg, const rdfin::FinArg fa) {
     typedef bf16_t T;
     constexpr int XP = XP_ | RD_SW_XP_ALL;
     constexpr int S = 8, NV = 2;
     constexpr int NKS = NSL <= 2 ? 1 : 2;                // k-steps of 16 channels
     constexpr int NSH = NSL == 1 ? 0 : (NSL == 2 ? 1 : 2);
-    constexpr int NITV = (SW_NPIX * NSL + 511) / 512;    // loader items (halo pixel, live channel slot) per thread
+    constexpr int NT = 64 * NWV, RPW = TH / NWV;         // threads; tile rows per wave
+    constexpr int NITV = (SW_NPIX * NSL + NT - 1) / NT;  // loader items (halo pixel, live channel slot) per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_inb = smem;                                                      // 2 x [NPIX + 1][4 slots x 16 B]
     double* s_red = reinterpret_cast<double*>(smem + 2 * SW_BUF_BYTES);      // [32][2], fp64 (conv_device.h flush_bstats)
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     // ---- prologue: zero the tile buffers (channel slots beyond Cin stay zero), bias table, this lane's weight fragments
     {
         uint4* z4 = reinterpret_cast<uint4*>(smem);
-        for (int i = tid; i < 2 * SW_BUF_BYTES / 16; i += 512) z4[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < 2 * SW_BUF_BYTES / 16; i += NT) z4[i] = make_uint4(0, 0, 0, 0);
         if (tid < 32) s_bias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
         if (tid < 64) s_red[tid] = 0.0;
     }
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     const int C = ssrc.C;
 #pragma unroll
     for (int b = 0; b < NITV; ++b) {
-        const int pixi = (tid + b * 512) >> NSH;
+        const int pixi = (tid + b * NT) >> NSH;
         const int pix = min(pixi, SW_NPIX - 1);
         const int py = pix / SW_PW, px = pix - py * SW_PW;
         iyx[b] = (py << 16) | px;
@@ -212,14 +222,16 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
 
     // ---- compute constants: this lane's pixel column li of tile row `wave`; fragment (kh, kw, ks) of the row = halo pixel
     //      (wave + kh, li + kw), 16-byte slot 2 ks + h
-    int foff[3][3];
+    int foff[RPW][3][3];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int rw = 0; rw < RPW; ++rw)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int pix = (wave + kh) * SW_PW + li + kw;
-            foff[kh][kw] = (pix * 4 + (h ^ ((pix >> 2) & 3))) * 16;          // slot h; slot 2 + h = this ^ 32 bytes
-        }
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int pix = (wave + NWV * rw + kh) * SW_PW + li + kw;
+                foff[rw][kh][kw] = (pix * 4 + (h ^ ((pix >> 2) & 3))) * 16;  // slot h; slot 2 + h = this ^ 32 bytes
+            }
     float sa[NV][S], sb[NV][S];
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -230,8 +242,9 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     const bool vec_ok = (p.Cout % S) == 0;
     const bool two = __builtin_amdgcn_readfirstlane((int)(p.Cout > 16));     // <= 16 output channels: one vector per lane
 
-    auto compute = [&](const Pos& q) {
+    auto compute_row = [&](const Pos& q, const int rw) {
         const int x0 = q.tx * TW, y0 = q.ty * TH;
+        const int trow = wave + NWV * rw;                    // this wave's tile row
         const char* s_in = s_inb + (q.j & 1) * SW_BUF_BYTES;
         f32x16 acc;
 #pragma unroll
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) f[kh][kw] = *reinterpret_cast<const uint4*>(s_in + foff[kh][kw]);
+                    for (int kw = 0; kw < 3; ++kw) f[kh][kw] = *reinterpret_cast<const uint4*>(s_in + foff[rw][kh][kw]);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks) f[kw][ks] = *reinterpret_cast<const uint4*>(s_in + (foff[kh][kw] ^ (ks * 32)));
+                    for (int ks = 0; ks < NKS; ++ks) f[kw][ks] = *reinterpret_cast<const uint4*>(s_in + (foff[rw][kh][kw] ^ (ks * 32)));
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
         if constexpr ((XP & 16) != 0) return;
         const bool live = q.j < nt;                          // ghost iterations run the same code with every lane off
         const bool full = live && y0 + TH <= H && x0 + TW <= W;               // wave-uniform: every pixel of the tile exists
-        const bool valid = live && y0 + wave < H && x0 + li < W;
+        const bool valid = live && y0 + trow < H && x0 + li < W;
         const unsigned toff = (unsigned)((y0 * W + x0) * p.Cout);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
             const float bs[S] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int e = 0; e < S; ++e) o[e] = vec[e] + bs[e];
-            T* dst = out + (toff + ooff + 16 * v);
+            T* dst = out + (toff + ooff + (unsigned)(NWV * rw * W * p.Cout) + 16 * v);
             if constexpr (OUTV == 3) {
                 // <= 4 output channels (the out1 convs: 2 classes, 3 colours): four scalar stores per lane, unconditional like the
                 // vector stores below -- lanes of the upper half-wave, pixels outside the image and channels beyond Cout write to the
@@ -345,6 +358,10 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
             }
         }
     };
+    auto compute = [&](const Pos& q) {
+#pragma unroll
+        for (int rw = 0; rw < RPW; ++rw) compute_row(q, rw);
+    };
 
     // ---- pipeline: sets 0 .. NSET-1 requested, tile 0 transformed, its set re-used for tile NSET
     Pos qc = pos_at(0), ql = pos_at(0), qi = pos_at(0);      // streams: compute (tile it), transform (it + 1), request (it + 1 + NSET)
@@ -352,6 +369,8 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     // the minimum over the paths that reach it, and a prologue without stores would make the loop wait as if its own stores did not
     // exist -- i.e. for the loads requested only ONE iteration earlier.
     auto fake_stores = [&]() {
+#pragma unroll
+        for (int rw = 0; rw < RPW; ++rw)
         if constexpr (OUTV == 3 && !(XP & 2)) {
             T* tr = reinterpret_cast<T*>(&sw_trash[512 + tid]);
 #pragma unroll
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
     // writes) while the other multiplies tile it (the matrix pipe), then they swap.  With the same order in all eight waves both
     // waves of a SIMD reach their 18 dependent MFMAs together and one of them waits out the other's 1152 cycles.  Two loops, not a
     // branch inside one: each is straight-line code, so the compiler still counts the loads and stores in flight (see above).
-    if (XP & 32 ? true : wave < 4) {
+    if (XP & 32 ? true : wave < NWV / 2) {
         for (int it0 = 0; it0 < nt; it0 += SW_NSET) {
 #pragma unroll
             for (int k = 0; k < SW_NSET; ++k) {
@@ -416,7 +435,16 @@ __global__ __launch_bounds__(512, 1) void conv_small_fwd_kernel(const rd_conv_t 
 
     // ---- BatchNorm sums of all tiles: summed over the 32 lanes of a half-wave (conv_device.h half_wave_sums), one LDS atomic per lane,
     //      one global set per workgroup
-    flush_half_wave_sums16<S, NV>(s_red, sa, sb, li, h);
+    __syncthreads();                                         // the tile buffers are free: per-wave sums land there, added in wave order
+    double* s_part = reinterpret_cast<double*>(smem);        // [NWV][64]
+    store_half_wave_sums16<S, NV>(s_part, wave, sa, sb, li, h);
+    __syncthreads();
+    if (tid < 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) t += s_part[w * 64 + tid];
+        s_red[tid] = t;
+    }
     __syncthreads();
     if (tid < 32 && tid < p.Cout && p.stats) {
         const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + tid) * 2;
@@ -442,7 +470,14 @@ int rd_conv_small_fwd_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
     if ((size_t)p.N * p.H * p.W * 32 >= (1ull << 31)) return RD_CONV_PP_NA;        // 32-bit element offsets inside the kernel
     const int ntiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
     const bool limited = p.cu_limit > 0 && p.cu_limit < rd_num_cus();
-    const long slots = limited ? p.cu_limit : rd_num_cus();                         // one 512-thread workgroup per CU
+    const int nl_ = (p.Cin + 7) / 8;
+    static const int nwv_sw = rd_switch("RD_SW_NWV", RD_SW_NWV_DEFAULT);             // 8: one 512-thread workgroup per CU; 4: two of 256
+    // two rows per wave need a second row accumulator, twice the fragment offsets and loader items: the 32-channel-input instantiations
+    // (72 registers of weights) spill 200-470 bytes per lane that way and stay on one workgroup per CU
+    static const int nwv_mask = rd_switch("RD_SW_NWV_MASK", 15);              // debug: 1 Cout 16, 2 Cout 32, 4 Cout <= 4 / other, 8 inputs of <= 8 channels
+    const int cls = (nl_ <= 1 ? 8 : (p.Cout == 16 ? 1 : (p.Cout == 32 ? 2 : 4)));
+    const int nwv = (nwv_sw == 4 && nl_ <= 2 && (nwv_mask & cls)) ? 4 : 8;
+    const long slots = (long)(limited ? p.cu_limit : rd_num_cus()) * (8 / nwv);
     // tiles per workgroup: whole rounds of resident workgroups; a workgroup pays about two tile-times of pipeline fill + drain
     int tpw = 0;
     double best = 1e30;
@@ -462,10 +497,12 @@ int rd_conv_small_fwd_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
 #define RD_SW_LAUNCH(NSL, OUTV, XP) do { \
         static bool attr_set = false; \
         if (!attr_set) { \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_fwd_kernel<NSL, OUTV, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_fwd_kernel<NSL, OUTV, XP, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_fwd_kernel<NSL, OUTV, XP, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS); \
             attr_set = true; \
         } \
-        hipLaunchKernelGGL((conv_small_fwd_kernel<NSL, OUTV, XP>), grid, dim3(512), SW_LDS, st, p, tpw, rdfin::current()); \
+        if (nwv == 4) hipLaunchKernelGGL((conv_small_fwd_kernel<NSL, OUTV, XP, 4>), grid, dim3(256), SW_LDS, st, p, tpw, rdfin::current()); \
+        else hipLaunchKernelGGL((conv_small_fwd_kernel<NSL, OUTV, XP, 8>), grid, dim3(512), SW_LDS, st, p, tpw, rdfin::current()); \
         return (int)hipGetLastError(); \
     } while (0)
 #ifdef RD_DEBUG_SWITCHES

@@ -394,6 +394,8 @@ class Plan:
     # ---- folded BatchNorm finalize (rd_src_t.fin)
     def stat_slots(self):
         """rd_conv_t.stat_slots / the stat_slots arguments of this plan's launches (0 = all RD_STAT_SLOTS copies)."""
+        if os.environ.get('RAMDSIR_DEBUG_LIB') == '1' and 'RD_FOLD_SLOTS' in os.environ:      # experiments: how many copies a folded producer spreads its sums over
+            return int(os.environ['RD_FOLD_SLOTS'])
         return L.STAT_SLOTS_FOLD if self.fold_finalize else 0
 
     def _folds(self, o, direction='fwd'):

@@ -12,8 +12,14 @@ GPU; profiles/r05_dice_proxy_oracle_spread.json, profiles/r05_dice_proxy_hip_spr
   oracle, fp32                  mean 90.1, sd 0.6 (8 runs)        HIP fp32   mean 90.3, sd 0.9 (8 runs; the unperturbed run: 90.21)
 The bf16 "gap" is 0.8 +- 0.5 points between the two DISTRIBUTIONS (1.7 sigma; fp32: 0.2 +- 0.4) -- the 2.5 of round 3 compared nine noisy HIP draws, whose
 unperturbed member happens to be a high one, with two or three oracle runs.  What remains is a wider spread of the bf16 HIP step (1.2
-against 0.7), not a shift that the rounding points fail to explain.  The gates: one HIP run of a dtype against the oracle of the same
-arithmetic, TWO-SIDED, 3.5 points = 2.5 sigma of the difference of two draws (sqrt(1.2^2 + 0.7^2) = 1.4)."""
+against 0.7), not a shift that the rounding points fail to explain.
+The gates, two-sided.  fp32: one HIP run against the one oracle run, 3.5 points (3 sigma of the difference of two draws, sqrt(0.9^2 +
+0.6^2) = 1.1, + the 0.2 between the means).  bf16: every kernel edit that moves an ulp re-draws the HIP run, and ONE draw against ONE
+oracle draw at 3.5 points = (3.5 - 0.8) / 1.4 = 1.9 sigma failed one edit in forty by construction (it did: 93.45 against 89.94, 3.51).
+So the bf16 gate is on the DISTRIBUTION: the mean of three HIP draws (the unperturbed start and perturbation seeds 0 and 1 of the
+profile above) against the committed mean of the eight oracle draws under the rounding model (profiles/r05_dice_proxy_oracle_spread.json:
+90.7), within 0.8 + 3 sqrt(1.2^2 / 3 + 0.7^2 / 8) = 3.0 points; a single draw only has to stay within 5 of the single oracle-model run
+(0.8 + 3 x 1.4)."""
 import numpy as np
 import pytest
 import torch
@@ -35,6 +41,7 @@ def runs():
         out['oracle_bf16_model'] = [DP.train_oracle(stream)]
     out['hip_f32'] = [DP.train_hip(stream, torch.float32) for _ in range(REPS)]
     out['hip_bf16'] = [DP.train_hip(stream, torch.bfloat16) for _ in range(REPS)]
+    out['hip_bf16_draws'] = [DP.train_hip(stream, torch.bfloat16, perturb_seed=sd) for sd in (0, 1)]
     return out
 
 
@@ -57,8 +64,17 @@ def test_runs_learn_the_task_and_agree_on_held_out_dice(runs):
             for key in sa:
                 assert torch.equal(sa[key], sb[key]), (k, key)
     assert max(abs(v - ref) for v in avg['hip_f32']) <= 3.5, avg     # fp32 kernels vs the fp32 reference arithmetic (sd of a draw: 0.9)
-    assert max(abs(v - ref_b) for v in avg['hip_bf16']) <= 3.5, avg  # bf16 kernels vs the oracle with the same rounding points, TWO-SIDED
-    assert min(avg['hip_bf16']) >= ref - 3.5, avg            # ... and the bench dtype is not worse than the reference's fp32
+    # bf16 kernels vs the oracle with the same rounding points, TWO-SIDED, on the distribution (docstring): three draws against the
+    # committed mean of the oracle's eight
+    import json
+    import os
+    spread = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r05_dice_proxy_oracle_spread.json')))
+    model_mean = float(spread['oracle_bf16_rounding_model']['mean'])
+    draws = [avg['hip_bf16'][0]] + [_avg(st, test) for st, _ in runs['hip_bf16_draws']]
+    print('HIP bf16 draws:', [round(v, 2) for v in draws], 'mean %.2f against the oracle-model distribution mean %.2f' % (np.mean(draws), model_mean))
+    assert abs(np.mean(draws) - model_mean) <= 3.0, (draws, model_mean)
+    assert max(abs(v - ref_b) for v in draws) <= 5.0, (draws, avg)
+    assert np.mean(draws) >= ref - 3.0, (draws, avg)         # ... and the bench dtype is not worse than the reference's fp32
     assert ref_b >= ref - 2.5, avg                           # nor is the oracle with the same rounding points
 
 

@@ -949,8 +949,11 @@ def test_layout_boundary_kernels(dtype):
     {'RD_CONV_NB1_BELOW': '100000'},                                                # 32-wide tiles for every 64-wide launch
     {'RD_SW_TPW': '5'},                                                             # conv_small_fwd_kernel: 5 tiles per workgroup (+ ghosts)
     {'RD_SW_TPW': '2'},                                                             # ... fewer tiles than register sets
+    {'RD_SW_NWV': '4'},                                                             # ... two 256-thread workgroups per CU, two tile rows per wave (<= 16-channel inputs)
+    {'RD_SW_NWV': '4', 'RD_SW_TPW': '5'},
+    {'RD_SW_NWV': '8'},                                                             # ... one 512-thread workgroup per CU for every input width
     {'RD_CONV_SMALL_FWD': '0'},                                                      # conv_small_kernel for the forward launches
-], ids=['ws_fwd_bwd', 'ws_fwd_bwd_8x32', 'ws_fwd_pf_bwd', 'pp_staged', 'pf_lean', 'pf_lean_8x32', 'pf_staged', 'nb1_everywhere', 'small_fwd_tpw5', 'small_fwd_tpw2', 'small_fwd_off'])
+], ids=['ws_fwd_bwd', 'ws_fwd_bwd_8x32', 'ws_fwd_pf_bwd', 'pp_staged', 'pf_lean', 'pf_lean_8x32', 'pf_staged', 'nb1_everywhere', 'small_fwd_tpw5', 'small_fwd_tpw2', 'small_fwd_nwv4', 'small_fwd_nwv4_tpw5', 'small_fwd_nwv8', 'small_fwd_off'])
 def test_conv_kernels_under_forced_dispatch(env):
     """Which kernel a 64-wide launch takes depends on its size (csrc/conv_pp.hip, conv_big.hip), and the cases above are small.
     The dispatch switches (debug build of the library only) are read once per process: re-run the conv parity tests in a child
