@@ -35,7 +35,11 @@ constexpr int SW_FIN = 2 * SW_BUF_BYTES + 64 * 8 + 32 * 4;                   // 
 constexpr int SW_LDS = SW_FIN + rdfin::FIN_LDS_FLOATS * 4;
 constexpr int SW_NSET = 3;                                                 // 2: the same step (4.85 ms), 5 for the <=16-channel inputs: 4.91
 
-__device__ uint4 sw_trash[1024];                         // where the stores of lanes without an output pixel go
+__device__ uint4 sw_trash[1024];
+#ifdef RD_DEBUG_SWITCHES
+__device__ int sw_jitter_flag;
+__device__ __forceinline__ bool sw_jitter_on() { return *reinterpret_cast<volatile int*>(&sw_jitter_flag) != 0; }
+#endif                         // where the stores of lanes without an output pixel go
 
 __device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -446,6 +450,15 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_small_fwd_kernel(const
         s_red[tid] = t;
     }
     __syncthreads();
+#ifdef RD_DEBUG_SWITCHES
+    // debug library, RD_SW_JITTER=1: a pseudo-random wait in front of the slot atomics, so that the ORDER in which the workgroups of a launch
+    // arrive at a slot differs from run to run (scripts/determinism_probe.py: does any result depend on that order?)
+    if (tiles_per_wg < 0 || sw_jitter_on()) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        const unsigned long long w = (t0 * 2654435761ull >> 7) & 4095;
+        while (__builtin_readcyclecounter() - t0 < w) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
     if (tid < 32 && tid < p.Cout && p.stats) {
         const size_t so = (((size_t)g * RD_STAT_SLOTS + slot) * p.Cout + tid) * 2;
         atomicAdd(&p.stats[so + 0], s_red[tid * 2 + 0]);
@@ -521,6 +534,16 @@ int rd_conv_small_fwd_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
         case 23: RD_SW_LAUNCH(4, 2, 23);
         case 32: RD_SW_LAUNCH(4, 2, 32);
         default: break;
+        }
+    }
+#endif
+#ifdef RD_DEBUG_SWITCHES
+    {
+        static bool jit_set = false;
+        if (!jit_set) {
+            const int j = rd_switch("RD_SW_JITTER", 0);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(sw_jitter_flag), &j, sizeof(int));
+            jit_set = true;
         }
     }
 #endif
