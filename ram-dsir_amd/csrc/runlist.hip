@@ -2,6 +2,7 @@
 // with the lane forks / joins as HIP events.  Host code only.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stdlib.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -56,6 +57,10 @@ inline float as_f(uint64_t v) {
     return f;
 }
 
+#ifdef RD_DEBUG_SWITCHES
+static int rd_switch_rl(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#endif
+
 #define P(i) ((void*)(uintptr_t)o.a[i])
 #define CP(T, i) ((const T*)(uintptr_t)o.a[i])
 #define I(i) ((int)(int64_t)o.a[i])
@@ -63,7 +68,38 @@ inline float as_f(uint64_t v) {
 #define F(i) (as_f(o.a[i]))
 #define NARGS(k) do { if (o.nargs != (k)) return -1; } while (0)
 
+#ifdef RD_DEBUG_SWITCHES
+// Debug library, RD_POISON_LDS=1: in front of EVERY launch of a list a kernel fills the LDS of every CU (and the registers of the waves
+// it runs) with a NaN pattern -- 0x7fc07fc0 is a NaN as fp32 and as two bf16, and 1e307-sized as half an fp64.  LDS and registers are
+// not cleared between kernels: a launch that reads either before writing it normally sees what the previous kernel of the same process
+// left there (repeatable when the process is alone on the GPU, arbitrary when it is not); with the poison it sees NaNs, and the losses show it.
+__global__ __launch_bounds__(1024) void rd_poison_lds_kernel(int words) {
+    extern __shared__ unsigned poison_smem[];
+    for (int i = threadIdx.x; i < words; i += blockDim.x) poison_smem[i] = 0x7fc07fc0u;
+    __syncthreads();
+    if (poison_smem[(threadIdx.x * 7) % words] == 1u) poison_smem[0] = 2u;         // keep the stores alive
+}
+void poison_lds(void* st) {
+    static int on = -1, cus = 0;
+    if (on < 0) {
+        on = rd_switch_rl("RD_POISON_LDS");
+        hipDeviceProp_t pr;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipGetDeviceProperties(&pr, dev);
+        cus = pr.multiProcessorCount;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rd_poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (on != 1) return;
+    // one 160 KB workgroup per CU (x2 so that every CU gets one even if some run two 80 KB... the second wave of workgroups overwrites again)
+    hipLaunchKernelGGL(rd_poison_lds_kernel, dim3(2 * cus), dim3(1024), 160 * 1024, (hipStream_t)st, 160 * 1024 / 4);
+}
+#endif
+
 int call(const rd_launch_t& o, void* st) {
+#ifdef RD_DEBUG_SWITCHES
+    poison_lds(st);
+#endif
     switch (o.op) {
     case RD_OP_CONV: NARGS(2); return rd_conv(CP(rd_conv_t, 0), I(1), st);
     case RD_OP_WGRAD: NARGS(2); return rd_wgrad(CP(rd_wgrad_t, 0), I(1), st);
