@@ -11,13 +11,21 @@ import bench as Bn
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 Sz = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 bs = [2, 3, 3]
+DETAIL = os.environ.get('STRESS_DETAIL') == '1'
+HEAD_ONLY = os.environ.get('STRESS_HEAD') == '1'
 torch.manual_seed(0)
 bank, mods = S.make_bank('cuda:0', 3, 16, 2, 3)
 Bn.init_weights(bank)
-ts = S.TrainStep(bank, mods, torch.bfloat16, bs, Sz, Sz, dataset='fundus', consistency='kd', lr=2e-3, total_iters=1000, ram='u8')
+NORAM = os.environ.get('STRESS_NORAM') == '1'               # no RAM kernels in the step: x is loaded once
+ts = S.TrainStep(bank, mods, torch.bfloat16, bs, Sz, Sz, dataset='fundus', consistency='kd', lr=2e-3, total_iters=1000, ram=None if NORAM else 'u8')
 ts.wpack.refresh()
 src, trg, lam, mask, _ = Bn.synth_inputs(sum(bs), Sz, 0, 'cuda:0')
-ts.load_raw(src, trg, lam); ts.load_target(mask)
+if NORAM:
+    g_ = torch.Generator().manual_seed(1)
+    ts.load_images((torch.rand(sum(bs), 3, Sz, Sz, generator=g_) * 2 - 1).cuda(), (torch.rand(sum(bs), 3, Sz, Sz, generator=g_) * 2 - 1).cuda())
+else:
+    ts.load_raw(src, trg, lam)
+ts.load_target(mask)
 for _ in range(3):
     ts.step()
 torch.cuda.synchronize()
@@ -27,11 +35,21 @@ saved = ts._snapshot()
 def run():
     ts._restore(saved)
     torch.cuda.synchronize()
-    ts.step()
+    if HEAD_ONLY:                                            # the reset and the forward / decoder-backward segment only: no encoder backward, no Adam
+        ts.launch(ts.head_names(), join=True)
+    else:
+        ts.step()
     torch.cuda.synchronize()
-    return dict(params=bank.params.clone(), grads=bank.grads.clone(), losses=ts.losses.clone(), rec=ts.rec_mse.clone(),
-                seg_stats=ts.seg.stat_arena.clone(), rec_stats=ts.rec.stat_arena.clone(),
-                buffers=torch.cat([v.flatten().double() for v in bank.buffers.values()]))
+    out = dict(params=bank.params.clone(), grads=bank.grads.clone(), losses=ts.losses.clone(), rec=ts.rec_mse.clone(),
+               seg_stats=ts.seg.stat_arena.clone(), rec_stats=ts.rec.stat_arena.clone(),
+               buffers=torch.cat([v.flatten().double() for v in bank.buffers.values()]))
+    if DETAIL:                                               # every activation / gradient / coefficient tensor of the two plans, in allocation order
+        for name, plan in (('seg', ts.seg), ('rec', ts.rec)):
+            for i, t in enumerate(plan.keep):
+                if not torch.is_tensor(t):
+                    continue
+                out['%s.keep[%d] %s %s' % (name, i, tuple(t.shape), str(t.dtype).replace('torch.', ''))] = t.clone()
+    return out
 
 
 ref = run()
@@ -43,9 +61,14 @@ for r in range(reps):
         bad += 1
         if bad <= 5:
             msg = []
-            for k in diff:
+            for k in diff[:40]:
                 a, b = cur[k].flatten().double(), ref[k].flatten().double()
+                a, b = torch.nan_to_num(a, nan=1e30), torch.nan_to_num(b, nan=1e30)
                 idx = (a != b).nonzero().flatten()
                 msg.append('%s: %d of %d values, first at %d (%.9g vs %.9g)' % (k, idx.numel(), a.numel(), int(idx[0]), float(a[idx[0]]), float(b[idx[0]])))
-            print('repetition %d differs: %s' % (r, '; '.join(msg)), flush=True)
+                if k.startswith('seg.keep[1]') and cur[k].dim() == 4:
+                    N_, H_, W_, C_ = cur[k].shape
+                    pix = sorted(set((int(i) // (H_ * W_ * C_), (int(i) // (W_ * C_)) % H_, (int(i) // C_) % W_) for i in idx.tolist()))
+                    msg.append('    wrong pixels (n, y, x) of %s: %s' % (k.split()[0], pix[:60]))
+            print('repetition %d differs (%d tensors):\n  %s' % (r, len(diff), '\n  '.join(msg)), flush=True)
 print('%d repetitions of one %dx%d step: %d differ from the first' % (reps, Sz, Sz, bad))
