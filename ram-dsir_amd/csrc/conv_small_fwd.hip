@@ -52,14 +52,14 @@ __device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 #define RD_SW_XP_ALL 0
 #endif
 #ifndef RD_SW_NWV_DEFAULT
-#define RD_SW_NWV_DEFAULT 8
+#define RD_SW_NWV_DEFAULT 4
 #endif
-// NWV: waves per workgroup.  8 (the product): one workgroup per CU, wave w owns tile row w.  4 (debug library, RD_SW_NWV=4; inputs of <= 16
-// channels): TWO independent 256-thread workgroups per CU, wave w owns rows w and w + 4 -- the phases of a tile (requests, transform,
-// products, epilogue) are serial inside a workgroup (one barrier per tile), two workgroups interleave theirs without one: 58 -> 45 us for
-// the 16 -> 16 launches at 400 x 400, the step 4.63 -> 4.55 ms (debug library).  NOT the default: 8 of 310 repetitions of a 300-step training
-// run gave different final weights with it, none of 230 with NWV = 8 (scripts/determinism_ab.sh; a single launch repeated 10 000 times is
-// bitwise stable either way, scripts/conv_repeat_stress.py) -- an interaction in the step that is not understood yet.
+// NWV: waves per workgroup.  8: one 512-thread workgroup per CU, wave w owns tile row w (inputs of 32 channels: two rows per wave do not fit
+// their 72 registers of weights).  4 (inputs of <= 16 channels, the default there): TWO independent 256-thread workgroups per CU, wave w owns
+// rows w and w + 4 -- the phases of a tile (requests, transform, products, epilogue) are serial inside a workgroup (one barrier per tile),
+// two workgroups interleave theirs without one: 58 -> 45 us for the 16 -> 16 launches at 400 x 400, the step 4.19 -> 4.12 ms.
+// (When first measured this shape cost the step its run-to-run repeatability on some boxes; the reason was not the shape but the
+// v_permlane32_swap of the epilogue, see there.)
 template <int NSL, int OUTV, int XP_, int NWV>
 __global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_small_fwd_kernel(const rd_conv_t p, int tiles_per_wg, const rdfin::FinArg fa) {
     typedef bf16_t T;
@@ -300,9 +300,13 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_small_fwd_kernel(const
             for (int j = 0; j < 4; ++j) {
                 const unsigned ua = __float_as_uint(acc[8 * v + j]);
                 const unsigned ub = __float_as_uint(acc[8 * v + 4 + j]);
-                const auto rs = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
-                vec[j] = __uint_as_float(rs[0]);
-                vec[4 + j] = __uint_as_float(rs[1]);
+                // The regroup between the two half-waves by two 32-lane shuffles, NOT by v_permlane32_swap: with that instruction here, 1-2 % of
+                // the steps of a process that SHARES the GPU with other processes came out with whole 16-lane groups of a tile row unswapped
+                // (for 16 output channels: the zero rows of the accumulator, i.e. exactly the bias) -- never alone on the GPU, never with the
+                // shuffles (profiles/r05_determinism.txt (6)-(8), scripts/load_stress_ab.sh); wait states in front of it did not help.
+                const unsigned oa = __shfl_xor(ua, 32, 64), ob = __shfl_xor(ub, 32, 64);
+                vec[j] = __uint_as_float(h == 0 ? ua : ob);
+                vec[4 + j] = __uint_as_float(h == 0 ? oa : ub);
             }
             const float4 b0 = *reinterpret_cast<const float4*>(s_bias + cb), b1 = *reinterpret_cast<const float4*>(s_bias + cb + 4);
             const float bs[S] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
