@@ -223,9 +223,9 @@ def test_step_is_bitwise_reproducible(dtype, dataset, bs, S):
     """The same parameters, optimizer state and inputs give the same BITS, run after run, on three streams: every reduction whose
     order depends on timing (waves arriving at a workgroup's BatchNorm sums, workgroups arriving at the statistic slots) accumulates
     fp32 terms in fp64, where the sum is exact and therefore order-independent WHILE the terms span less than 2^29 (csrc/conv_device.h
-    flush_bstats); the weight-gradient splits are summed in a fixed order.  Condition (round 5, profiles/r05_determinism.txt): this test runs
-    alone on the GPU, where the arrival orders are stable as well; three such processes at once do not reproduce each other's bits (DESIGN.md,
-    numerics).  Reference: train.py:608-614 (--deterministic gives cuDNN-deterministic runs there).
+    flush_bstats); the weight-gradient splits are summed in a fixed order.  Round 5 (profiles/r05_determinism.txt): with other processes on the
+    same GPU the step did NOT repeat -- one instruction (v_permlane32_swap in conv_small_fwd_kernel) left lane groups unswapped; fixed, and
+    scripts/load_train_ab.sh is the test for that case.  Reference: train.py:608-614 (--deterministic gives cuDNN-deterministic runs there).
     Before this held (round 2) two identical fp32 runs differed by up to 8e-3 in a gradient tensor, bf16 runs by 13 %."""
     torch.manual_seed(0)
     B = sum(bs)
