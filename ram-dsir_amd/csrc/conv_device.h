@@ -637,6 +637,19 @@ __device__ __forceinline__ void grad_plain_finish(const GradPlainReq& q, const r
     *reinterpret_cast<uint4*>(reinterpret_cast<T*>(d.g) + q.idx) = Slot<T>::pack(gw);
 }
 
+// The regroup of an accumulator between the two half-waves: r0 = (a of lanes 0-31 | b of lanes 0-31 in lanes 32-63), r1 = (a of lanes 32-63
+// in lanes 0-31 | b of lanes 32-63) -- what v_permlane32_swap a, b computes in one instruction.  NOT with that instruction: in
+// conv_small_fwd_kernel it left 16-lane groups unswapped in 1-2 % of the steps of a process that shares the GPU with other processes
+// (profiles/r05_determinism.txt); two 32-lane shuffles never did.  h = lane / 32.
+struct HalfSwap { unsigned r0, r1; };
+__device__ __forceinline__ HalfSwap rd_half_swap(unsigned a, unsigned b, int h) {
+    const unsigned oa = __shfl_xor(a, 32, 64), ob = __shfl_xor(b, 32, 64);
+    HalfSwap r;
+    r.r0 = h == 0 ? a : ob;
+    r.r1 = h == 0 ? oa : b;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------ half-wave sums of many values
 // The BatchNorm sums of a workgroup: every lane holds NTOT (32 or 64) partial sums -- one pixel column, all channels -- and each has
 // to be summed over the 32 lanes of its half-wave.  A butterfly per VALUE (five __shfl_xor steps each, the form all kernels had) is

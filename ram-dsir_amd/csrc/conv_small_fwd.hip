@@ -304,9 +304,9 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_small_fwd_kernel(const
                 // the steps of a process that SHARES the GPU with other processes came out with whole 16-lane groups of a tile row unswapped
                 // (for 16 output channels: the zero rows of the accumulator, i.e. exactly the bias) -- never alone on the GPU, never with the
                 // shuffles (profiles/r05_determinism.txt (6)-(8), scripts/load_stress_ab.sh); wait states in front of it did not help.
-                const unsigned oa = __shfl_xor(ua, 32, 64), ob = __shfl_xor(ub, 32, 64);
-                vec[j] = __uint_as_float(h == 0 ? ua : ob);
-                vec[4 + j] = __uint_as_float(h == 0 ? oa : ub);
+                const HalfSwap rs = rd_half_swap(ua, ub, h);
+                vec[j] = __uint_as_float(rs.r0);
+                vec[4 + j] = __uint_as_float(rs.r1);
             }
             const float4 b0 = *reinterpret_cast<const float4*>(s_bias + cb), b1 = *reinterpret_cast<const float4*>(s_bias + cb + 4);
             const float bs[S] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
