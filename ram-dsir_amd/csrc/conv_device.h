@@ -639,14 +639,24 @@ __device__ __forceinline__ void grad_plain_finish(const GradPlainReq& q, const r
 
 // The regroup of an accumulator between the two half-waves: r0 = (a of lanes 0-31 | b of lanes 0-31 in lanes 32-63), r1 = (a of lanes 32-63
 // in lanes 0-31 | b of lanes 32-63) -- what v_permlane32_swap a, b computes in one instruction.  NOT with that instruction: in
-// conv_small_fwd_kernel it left 16-lane groups unswapped in 1-2 % of the steps of a process that shares the GPU with other processes
-// (profiles/r05_determinism.txt); two 32-lane shuffles never did.  h = lane / 32.
+// conv_small_fwd_kernel it left 16-lane groups unswapped in 1-2 % of the steps of a process that shares the GPU with other processes,
+// and with two workgroups per CU also alone on the GPU (profiles/r05_determinism.txt; scripts/probe/swap_probe.hip is the stand-alone
+// reproducer, profiles/r06_swap_probe.txt its result).  Round 6: NO kernel of the product library contains the instruction any more
+// (tests/test_cpu_host.py disassembles the library); every epilogue regroups through this function.  ONE 32-lane exchange does it: the
+// lower half-wave needs its partner's a and has its own b to give, the upper half-wave the other way round.  h = lane / 32.
+// -DRD_USE_PERMLANE32_SWAP builds the old form (the probe and A/B timing only).
 struct HalfSwap { unsigned r0, r1; };
 __device__ __forceinline__ HalfSwap rd_half_swap(unsigned a, unsigned b, int h) {
-    const unsigned oa = __shfl_xor(a, 32, 64), ob = __shfl_xor(b, 32, 64);
     HalfSwap r;
-    r.r0 = h == 0 ? a : ob;
-    r.r1 = h == 0 ? oa : b;
+#ifdef RD_USE_PERMLANE32_SWAP
+    const auto s = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    r.r0 = s[0];
+    r.r1 = s[1];
+#else
+    const unsigned got = __shfl_xor(h == 0 ? b : a, 32, 64);
+    r.r0 = h == 0 ? a : got;
+    r.r1 = h == 0 ? got : b;
+#endif
     return r;
 }
 

@@ -26,7 +26,7 @@ bool rd_conv_ws_stores_sources(const rd_conv_t& p);  // conv_pp.hip: ... on an i
 bool rd_conv_big_stores_sources(const rd_conv_t& p, int dtype);
 
 // Register ("lean") epilogues: accumulators leave as 16-byte NHWC vectors straight from registers (MFMA roles swapped:
-// weights x pixels, v_permlane32_swap regroup) instead of through the LDS-staged epilogue of conv_epilogue.h.
+// weights x pixels, rd_half_swap regroup) instead of through the LDS-staged epilogue of conv_epilogue.h.
 // 0 = not eligible, 1 = forward, 2 = gradient with plain destinations only.  NT = output channels per workgroup.
 inline int rd_conv_lean_mode(const rd_conv_t& p, int NT) {
     if (p.Cout != p.CoutPad || p.Cout % NT) return 0;

@@ -117,7 +117,7 @@ __device__ __forceinline__ void conv_epilogue(const rd_conv_t& p, f32x16 (&acc)[
 
 // ------------------------------------------------------------------------------------ register epilogue (bf16)
 // For accumulators produced with the MFMA roles swapped (A = weights, B = pixels): row (r&3) + 8*(r>>2) + 4*h of block nb
-// is an output channel, the column (lane & 31) a pixel of tile row wave*2 + mb.  v_permlane32_swap regroups a lane's 16
+// is an output channel, the column (lane & 31) a pixel of tile row wave*2 + mb.  rd_half_swap regroups a lane's 16
 // channels of a block into two vectors of 8 contiguous channels (lanes h=0: 16v..16v+7, lanes h=1: 16v+8..16v+15), which
 // are stored / combined with the destination tensors as whole 16-byte NHWC slots.  ~1/3 of the instructions of the
 // LDS-staged conv_epilogue above.  EP 1 = forward (+bias, BatchNorm sums), EP 2 = gradient into plain destinations.
@@ -189,9 +189,9 @@ __device__ __forceinline__ void conv_epilogue_lean(const rd_conv_t& p, f32x16 (&
                 for (int j = 0; j < 4; ++j) {
                     const unsigned a = __float_as_uint(acc[mb][nb][8 * v + j]);
                     const unsigned b = __float_as_uint(acc[mb][nb][8 * v + 4 + j]);
-                    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-                    o[j] = __uint_as_float(r[0]);
-                    o[4 + j] = __uint_as_float(r[1]);
+                    const HalfSwap r = rd_half_swap(a, b, h);
+                    o[j] = __uint_as_float(r.r0);
+                    o[4 + j] = __uint_as_float(r.r1);
                 }
                 if constexpr (EP == 1) {
                     if (!valid) continue;

@@ -361,9 +361,9 @@ __global__ __launch_bounds__(512, 1) void conv_small_bwd_fused_kernel(const rd_c
                         for (int j = 0; j < 4; ++j) {
                             const unsigned ua = __float_as_uint(acc[8 * v + j]);
                             const unsigned ub = __float_as_uint(acc[8 * v + 4 + j]);
-                            const auto rs = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
-                            vec[j] = __uint_as_float(rs[0]);
-                            vec[4 + j] = __uint_as_float(rs[1]);
+                            const HalfSwap rs = rd_half_swap(ua, ub, h);
+                            vec[j] = __uint_as_float(rs.r0);
+                            vec[4 + j] = __uint_as_float(rs.r1);
                         }
                         Slot<T>::unpack(araw[mb][v], xr);
                         const bool on = valid && live[v];

@@ -793,9 +793,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     auto regroup = [&](const f32x16& a, int v, float* o) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[8 * v + j]), __float_as_uint(a[8 * v + 4 + j]), false, false);
-            o[j] = __uint_as_float(r[0]);
-            o[4 + j] = __uint_as_float(r[1]);
+            const HalfSwap r = rd_half_swap(__float_as_uint(a[8 * v + j]), __float_as_uint(a[8 * v + 4 + j]), h);
+            o[j] = __uint_as_float(r.r0);
+            o[4 + j] = __uint_as_float(r.r1);
         }
     };
 

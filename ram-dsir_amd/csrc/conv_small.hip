@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
     if constexpr (sizeof(T) == 2) nks = p.Cin <= 16 ? 1 : 2;
 
     // ---- epilogue: after the (weights x pixels) MFMA a lane owns ONE pixel (column lane&31) and 16 output
-    //      channels; they are regrouped into NV vectors of S contiguous channels (bf16: one v_permlane32_swap
+    //      channels; they are regrouped into NV vectors of S contiguous channels (bf16: one half-wave exchange, rd_half_swap
     //      per pair of registers) so that all global traffic of the epilogue is 16-byte, straight from registers
     int cbv[NV];
 #pragma unroll
@@ -196,9 +196,9 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const rd_conv_t p, i
                     for (int j = 0; j < 4; ++j) {
                         const unsigned a = __float_as_uint(acc[mb][8 * v + j]);
                         const unsigned b = __float_as_uint(acc[mb][8 * v + 4 + j]);
-                        const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-                        vec[v][j] = __uint_as_float(r[0]);
-                        vec[v][4 + j] = __uint_as_float(r[1]);
+                        const HalfSwap r = rd_half_swap(a, b, h);
+                        vec[v][j] = __uint_as_float(r.r0);
+                        vec[v][4 + j] = __uint_as_float(r.r1);
                     }
             } else {
 #pragma unroll

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_small_fwd_kernel(const
             for (int j = 0; j < 4; ++j) {
                 const unsigned ua = __float_as_uint(acc[8 * v + j]);
                 const unsigned ub = __float_as_uint(acc[8 * v + 4 + j]);
-                // The regroup between the two half-waves by two 32-lane shuffles, NOT by v_permlane32_swap: with that instruction here, 1-2 % of
+                // The regroup between the two half-waves by a 32-lane shuffle (rd_half_swap), NOT by v_permlane32_swap: with that instruction here, 1-2 % of
                 // the steps of a process that SHARES the GPU with other processes came out with whole 16-lane groups of a tile row unswapped
                 // (for 16 output channels: the zero rows of the accumulator, i.e. exactly the bias) -- never alone on the GPU, never with the
                 // shuffles (profiles/r05_determinism.txt (6)-(8), scripts/load_stress_ab.sh); wait states in front of it did not help.

@@ -114,6 +114,28 @@ def test_product_path_never_imports_the_oracle():
             assert 'oracle' not in open(os.path.join(pkg, fn)).read(), fn
 
 
+def test_product_library_contains_no_permlane32_swap(tmp_path):
+    """v_permlane32_swap produced wrong pixels under co-resident waves (profiles/r05_determinism.txt, profiles/r06_swap_probe.txt):
+    since round 6 every epilogue regroups through rd_half_swap (csrc/conv_device.h), and the DEVICE CODE of the shipped library --
+    not only the sources -- is checked for the instruction here."""
+    import shutil
+    from ramdsir import _lib
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump not in this image')
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / 'lib.so')
+    subprocess.run([objdump, '--offloading', str(so)], cwd=tmp_path, check=True, capture_output=True)
+    objs = [f for f in os.listdir(tmp_path) if f.endswith('gfx950')]
+    assert objs, 'no gfx950 code objects found in the library'
+    n_inst, n_mfma = 0, 0
+    for f in objs:
+        dis = subprocess.run([objdump, '-d', str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        n_inst += dis.count('v_permlane32_swap')
+        n_mfma += dis.count('v_mfma_f32_32x32x16_bf16')
+    assert n_mfma > 100                                     # the disassembly is the real thing
+    assert n_inst == 0, f'{n_inst} v_permlane32_swap instructions in the product library'
+
+
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path[:0] = [%r, %r]

@@ -653,17 +653,21 @@ def test_data_parallel_step_matches_plain_step_on_one_rank(golden_dir):
             dist.destroy_process_group()
 
 
-def test_step_repeats_bit_for_bit_while_other_processes_share_the_gpu():
-    """Three processes at once, each repeating ONE 64 x 64 step 300 times from the same saved state (scripts/step_repeat_stress.py) and
+@pytest.mark.parametrize('reps,side', [(300, 64), (100, 400)])
+def test_step_repeats_bit_for_bit_while_other_processes_share_the_gpu(reps, side):
+    """Three processes at once, each repeating ONE step `reps` times from the same saved state (scripts/step_repeat_stress.py) and
     comparing parameters, gradients, losses and statistics with its first repetition: 0 differences.  Until round 5 this failed in 1-2 % of
     the repetitions -- conv_small_fwd_kernel's v_permlane32_swap left 16-lane groups unswapped when the GPU was time-sliced between
-    processes: 16 pixels holding the bias (profiles/r05_determinism.txt) -- while every single-process test passed."""
+    processes: 16 pixels holding the bias (profiles/r05_determinism.txt) -- while every single-process test passed.  Round 6: the
+    instruction is gone from every kernel (rd_half_swap), and the case at the BENCH shape (C2: 400 x 400, bf16, [2, 3, 3]) puts every
+    kernel family of the step under the same load: conv_ws_kernel's multi-tile ranges, conv_pf_kernel at two workgroups per CU, the
+    fused backward, the small-channel gradient launches, the 128-wide weight gradients."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, 'scripts', 'step_repeat_stress.py'), '300', '64']
+    cmd = [sys.executable, os.path.join(root, 'scripts', 'step_repeat_stress.py'), str(reps), str(side)]
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for _ in range(3)]
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-1500:]
-        assert '300 repetitions of one 64x64 step: 0 differ from the first' in o, o[-1500:]
+        assert '%d repetitions of one %dx%d step: 0 differ from the first' % (reps, side, side) in o, o[-1500:]
