@@ -133,7 +133,8 @@ typedef struct {
     int32_t w_tap_rows;  /* rows per tap of the packed array `w` points into when that is MORE than CoutPad: a launch over a 32-row
                           * block of a wider pack (w = pack + first_row * CK elements; honoured by the small-channel kernels, which is
                           * where such launches go); 0: CoutPad */
-    int32_t stat_slots;  /* >0: `stats` and dst[].bstats are spread over the first stat_slots copies only (RD_STAT_SLOTS_FOLD); 0: all */
+    int32_t stat_slots;  /* >0: `stats` and dst[].bstats are spread over the first stat_slots copies only (RD_STAT_SLOTS_FOLD); 0: all.
+                            0..RD_STAT_SLOTS (else -2), and never MORE than the nslots of the consumer that finalizes these sums */
 } rd_conv_t;
 
 int rd_conv(const rd_conv_t* p, int dtype, void* stream);
@@ -220,7 +221,8 @@ typedef struct {
     int32_t C, G;
     float eps, momentum;
     int32_t training;     /* 0: eval -- scale/shift from the running statistics, nothing updated */
-    int32_t nslots;       /* rd_src_t.fin only: statistic copies the producers used (0 = all); rd_bn_finalize_fwd sums all of them */
+    int32_t nslots;       /* rd_src_t.fin only: statistic copies the producers used (0 = all); a multiple of 8 up to RD_STAT_SLOTS (else -3),
+                             >= every producer's stat_slots.  rd_bn_finalize_fwd sums all RD_STAT_SLOTS copies */
 } rd_bn_fwd_t;
 int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream);
 
@@ -456,6 +458,14 @@ int rd_join_lanes(void* const* streams, int n_streams, uint32_t mask);
  * GPU executes the same graph.  Not used while the main stream is being captured.  Returns the previous setting.  Process-wide;
  * rd_run_list itself must still be called from one thread at a time. */
 int rd_run_list_threads(int enable);
+
+/* Measurement only (bench.py `box`): what this box's GPU sustains on two fixed micro-kernels, so that a bench line can be compared across
+ * boxes of a pool whose clocks differ by a few per cent.  No reference counterpart (the reference publishes no throughput: BASELINE.md).
+ *   which 0: streaming copy of n bytes (n % 16 == 0) from a to b, 16 B per lane, 8 workgroups of 256 threads per CU;
+ *   which 1: n iterations of four independent v_mfma_f32_32x32x16_bf16 per wave, 8 waves on every CU (a: >= 4 bytes of device scratch, b unused):
+ *            flops = CUs x 8 x n x 4 x 32768.
+ * The caller times the launch with events on `stream`. */
+int rd_box_probe(int which, void* a, void* b, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,8 +14,10 @@
 // running statistics (momentum recursion in group order for groups that share one BatchNorm), num_batches_tracked; dgamma / dbeta.
 //
 // Numerics: the formulas and fp32 / fp64 roles are those of bn_finalize_fwd_kernel / bn_finalize_bwd_kernel (bn.hip) verbatim; the
-// slot sums are fp64 sums of fp32 terms (exact, hence order-independent: DESIGN.md "run-to-run reproducibility"), so a folded
-// finalize is bit-identical to the explicit launch.
+// slot sums are fp64 sums of fp32 terms -- exact, hence order-independent, WHILE the terms of one sum span fewer than 2^29 in
+// magnitude x count (conv_device.h flush_bstats; DESIGN.md "run-to-run reproducibility": true of every tensor of the network, not of
+// adversarial data) -- so a folded finalize is bit-identical to the explicit launch.  With 8 copies instead of 64 (RD_STAT_SLOTS_FOLD)
+// each copy takes 8 x as many atomics; the persistent kernels add once per workgroup, which is what keeps that cheap.
 #pragma once
 #include <string.h>
 #include "common.h"
@@ -99,8 +101,10 @@ __device__ __forceinline__ void fwd(const FinArg& fa, float* lds = nullptr, bool
     const int C = f.C, G = f.G, ns = f.nslots > 0 ? f.nslots : RD_STAT_SLOTS;
     const double* st = f.stats;
     const bool own = (fa.flags & RD_FIN_OWNER) != 0 && last_block();
+    // a flat thread index: with a 2-D / 3-D block threads that share threadIdx.x would otherwise race on the owner's read-modify-writes
     const int nthr = blockDim.x * blockDim.y * blockDim.z;
-    for (int i = threadIdx.x; i < G * C; i += nthr) {
+    const int flat = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    for (int i = flat; i < G * C; i += nthr) {
         int g, c;
         pair_of(i, C, g, c);
         double s1, s2;
@@ -221,8 +225,10 @@ __device__ __forceinline__ void bwd(const FinArg& fa, float* lds = nullptr, bool
     const int C = q.C, G = q.G, ns = q.nslots > 0 ? q.nslots : RD_STAT_SLOTS;
     const double* st = q.bstats;
     const bool own = (fa.flags & RD_FIN_OWNER) != 0 && last_block();
+    // a flat thread index: with a 2-D / 3-D block threads that share threadIdx.x would otherwise race on the owner's read-modify-writes
     const int nthr = blockDim.x * blockDim.y * blockDim.z;
-    for (int i = threadIdx.x; i < G * C; i += nthr) {
+    const int flat = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    for (int i = flat; i < G * C; i += nthr) {
         int g, c;
         pair_of(i, C, g, c);
         double s1d, sgzd;
@@ -353,6 +359,10 @@ inline int make_arg(FinArg& a, const rd_src_t* srcs, int n) {
         else memcpy(&a.d.f, srcs[i].fin, sizeof(rd_bn_fwd_t));
         const int G = a.is_bwd ? a.d.b.G : a.d.f.G, C = a.is_bwd ? a.d.b.C : a.d.f.C;
         if (G < 1 || G > FIN_MAX_G || C < 1 || C != srcs[i].C) return -3;
+        // slot_sums reads the copies in blocks of eight: a count that is not a whole number of blocks would run into the next group's
+        // copies (or past the buffer).  The producer's stat_slots must not exceed this count, or part of its sums is never read (ramdsir.h)
+        const int ns = a.is_bwd ? a.d.b.nslots : a.d.f.nslots;
+        if (ns < 0 || ns > RD_STAT_SLOTS || ns % 8) return -3;
         if (!a.is_bwd && !a.d.f.training) return -3;           // eval mode has no batch statistics to finalize
     }
     return 0;

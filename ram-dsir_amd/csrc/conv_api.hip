@@ -123,6 +123,7 @@ int rd_conv(const rd_conv_t* p, int dtype, void* stream) {
     const int ck = dtype == RD_BF16 ? 32 : 16;
     if (p->CinPad % ck || p->CoutPad % 32 || p->CinPad < p->Cin || p->CoutPad < p->Cout) return -2;
     hipStream_t st = (hipStream_t)stream;
+    if (p->stat_slots < 0 || p->stat_slots > RD_STAT_SLOTS) return -2;               // the kernels add into slot (index mod stat_slots) of [RD_STAT_SLOTS] copies
     if (rdfin::make_arg(rdfin::current(), p->src, p->nsrc)) return -3;                // rd_src_t.fin: copied into the kernel arguments
     if (p->w_tap_rows && !(p->CinPad == ck && p->CoutPad == 32 && p->emode == 1 && p->w_tap_rows >= p->CoutPad)) return -2;   // ramdsir.h
     if (p->CinPad == ck && p->CoutPad == 32) return rd_conv_small_dispatch(*p, dtype, st);   // one K chunk, one N block
@@ -161,6 +162,7 @@ int64_t rd_conv_bwd_fused_workspace(const rd_conv_t* dgrad, const rd_wgrad_t* wg
 
 int rd_conv_bwd_fused(const rd_conv_t* dgrad, const rd_wgrad_t* wgrad, int dtype, void* stream) {
     if (!rd_conv_bwd_fused_ok(dgrad, wgrad, dtype) || !wgrad->partial || !wgrad->dW) return -1;
+    if (dgrad->stat_slots < 0 || dgrad->stat_slots > RD_STAT_SLOTS) return -2;
     if (rdfin::make_arg(rdfin::current(), dgrad->src, dgrad->nsrc)) return -3;          // the gradient descriptor's dz carries it; wgrad->dz.fin is ignored
     return rd_bwd_fused_dispatch(*dgrad, *wgrad, (hipStream_t)stream);
 }

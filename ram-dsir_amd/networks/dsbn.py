@@ -15,7 +15,21 @@ class DomainSpecificBatchNorm2d(nn.Module):
         self.bns = nn.ModuleList(FusedBatchNorm2d(num_features, eps, momentum, affine, track_running_stats)
                                  for _ in range(num_domains))
 
+    def reset_running_stats(self):
+        """Every domain's running_mean / running_var / num_batches_tracked back to 0 / 1 / 0 (dsbn.py:13-15)."""
+        for d in range(len(self.bns)):
+            self.bns[d].reset_running_stats()
+
+    def reset_parameters(self):
+        """Every domain's statistics AND affine parameters back to their initial values (dsbn.py:17-19)."""
+        for d in range(len(self.bns)):
+            self.bns[d].reset_parameters()
+
     def forward(self, x, domain_label):
         if x.dim() != 4:
             raise ValueError('expected 4D input (got {}D input)'.format(x.dim()))
         return self.bns[domain_label[0]](x), domain_label
+
+
+# the reference's module also exports the dimension-agnostic base class (dsbn.py:4); here the 2-D class is the only one, under both names
+_DomainSpecificBatchNorm = DomainSpecificBatchNorm2d

@@ -395,7 +395,10 @@ class Plan:
     def stat_slots(self):
         """rd_conv_t.stat_slots / the stat_slots arguments of this plan's launches (0 = all RD_STAT_SLOTS copies)."""
         if os.environ.get('RAMDSIR_DEBUG_LIB') == '1' and 'RD_FOLD_SLOTS' in os.environ:      # experiments: how many copies a folded producer spreads its sums over
-            return int(os.environ['RD_FOLD_SLOTS'])
+            n = int(os.environ['RD_FOLD_SLOTS'])
+            if n < 0 or n > L.STAT_SLOTS or n % 8:              # the folded prologues read the copies in blocks of eight (csrc/bn_fin.h slot_sums)
+                raise ValueError('RD_FOLD_SLOTS must be 0 or a multiple of 8 up to %d' % L.STAT_SLOTS)
+            return n
         return L.STAT_SLOTS_FOLD if self.fold_finalize else 0
 
     def _folds(self, o, direction='fwd'):
@@ -564,6 +567,14 @@ class Plan:
                     Hh, Ww = (2 * H, 2 * W) if o.up else (H, W)
                     self.fwd.append((lib.rd_bn_apply, (src.data_ptr(), None, o.a_buf.data_ptr(), o.scale.data_ptr(), None, o.shift.data_ptr(),
                                                        self.slope, N, Hh, Ww, o.C, self.G, self.gs_arr, dt)))
+        # a folded forward finalize exists only inside the launch that TAKES it (_take_fwd_fin, as owner).  A BatchNorm site whose readers are
+        # all in other plans (flags 0), materialising passes or consumer kinds without a `fin` would otherwise never write its saved mean /
+        # invstd, running statistics and num_batches_tracked -- and the backward pass would read stale values: the explicit launch, at the end
+        for node in self.nodes:
+            o = node.out
+            if getattr(o, 'fin_fwd', None) is not None and o.plan is self and not o.fin_fwd_taken and self.fold_finalize != 2:
+                o.fin_fwd_taken = True
+                self.fwd.append(o.fin_fwd_op)
         if not self.training:
             return
         # ---------------- backward, reverse order; bwd_split[m] = index where module m's backward starts
@@ -703,6 +714,7 @@ class Plan:
                 wg.dz.fin, wg.dz.fin_flags = None, 0
                 if p is not None:
                     p.src[0].fin, p.src[0].fin_flags = None, 0
+                assert fin_pos >= self.bwd_node_start[(node.mname, node.name)]      # inside this node's range: no recorded index moves
                 self.bwd.insert(fin_pos, fin_op)
             dgrad_first = False
             if node.fused:

@@ -253,3 +253,28 @@ def test_sq_counter_aggregation_of_the_bench_line():
     assert c['dispatches'] == 2 and c['mfma_busy'] == round(256000.0 / (1024 * 1000.0), 4) == 0.25
     assert c['mfma_busy_occupied'] == 0.25 and c['lds_conflict_ratio'] == 0.02          # 256 workgroups occupy the whole device
     assert 'wgrad' not in out
+
+
+def test_dsbn_module_keeps_the_reference_surface():
+    """code/networks/dsbn.py:4-34: the base-class name, reset_running_stats / reset_parameters over every domain, the 4-D check and
+    the checkpoint keys (bns.{d}.*) -- on CPU, no compute call."""
+    from torch import nn
+    from networks import dsbn
+    m = dsbn.DomainSpecificBatchNorm2d(6, num_domains=3)
+    assert issubclass(dsbn.DomainSpecificBatchNorm2d, dsbn._DomainSpecificBatchNorm)
+    assert sorted(m.state_dict()) == sorted('bns.%d.%s' % (d, k) for d in range(3)
+                                            for k in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'))
+    assert all(isinstance(b, nn.BatchNorm2d) for b in m.bns)
+    for b in m.bns:
+        b.running_mean.fill_(3.0); b.running_var.fill_(5.0); b.num_batches_tracked.fill_(7)
+        with torch.no_grad():
+            b.weight.fill_(2.0); b.bias.fill_(1.0)
+    m.reset_running_stats()
+    for b in m.bns:
+        assert float(b.running_mean.abs().max()) == 0 and float(b.running_var.min()) == 1 and int(b.num_batches_tracked) == 0
+        assert float(b.weight.min()) == 2.0                    # parameters untouched
+    m.reset_parameters()
+    for b in m.bns:
+        assert float(b.weight.min()) == 1.0 and float(b.bias.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 6, 4), torch.zeros(2, dtype=torch.long))

@@ -52,3 +52,24 @@ def test_bench_lines_of_the_other_baseline_configs(name, dataset, split, side):
     rs = d['roofline_step']
     assert abs(rs['bytes_per_image'] / (1027560000 * (side / 400.0) ** 2) - 1) < 0.01         # SURVEY.md 8d scaling with the side
     assert d['roofline']['bound'] in ('hbm', 'mfma') and 0 < d['roofline']['frac'] < 1
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` with WORLD_SIZE unset starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+    (bench.launch_ranks: never an exec, before the parent touches the GPU) and relays rank 0's line and the exit code.  --launch-ranks
+    forces the same path for N = 1 (this box has one GPU); with --gpus 2 here the ranks must fail inside the runtime / RCCL -- not with
+    bench.py's own "WORLD_SIZE is 1" refusal.  Reference parallelism: nn.DataParallel, code/train.py:205-208."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'RD_FORCE_DDP')}
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-fp32-leg', '--no-ablation',
+            '--no-live-pmc', '--no-saturation']
+    r = subprocess.run(base + ['--gpus', '1', '--launch-ranks'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['config']['parallelism'] == 'dp1'
+    assert d['box']['copy_gbs'] > 1000 and d['box']['mfma_tflops'] > 500 and d['value_normalised'] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        r2 = subprocess.run(base + ['--gpus', '2', '--no-box'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        err = r2.stderr.decode()
+        assert r2.returncode != 0
+        assert 'runs one rank per GPU but WORLD_SIZE is' not in err, err[-2000:]
