@@ -5,6 +5,8 @@
 int rd_conv_small_dispatch(const rd_conv_t& p, int dtype, hipStream_t st);   // Cin <= one chunk, Cout <= 32
 int rd_conv_big_dispatch(const rd_conv_t& p, int dtype, hipStream_t st);     // everything else
 int rd_wgrad_dispatch(const rd_wgrad_t& p, int dtype, hipStream_t st);
+// wgrad_sym.hip: the 128 x 64-block kernel, grid (gx pixel splits, CoutPadW / 128, CinPadW / 64); partials in wgrad.hip's layout
+int rd_wgrad_sym_launch(const rd_wgrad_t& p, int gx, int CoutPadW, int CinPadW, hipStream_t st);
 int64_t rd_wgrad_ws_bytes(const rd_wgrad_t& p, int dtype);
 // split reduction of per-workgroup weight-gradient sums partial[nsplit][taps][CoutPadW][CinPadW] -> dW (wgrad.hip)
 int rd_wgrad_reduce_launch(const float* partial, float* dW, int nsplit, int taps, int Cout, int Cin, int CoutPadW, int CinPadW, float beta,

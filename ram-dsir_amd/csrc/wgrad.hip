@@ -3,6 +3,11 @@
 // channels); deterministic two-stage split reduction.
 #include "conv_device.h"
 #include "conv_dispatch.h"
+#include "wgrad_tr.h"
+
+#ifndef RD_WG_SYM_DEFAULT
+#define RD_WG_SYM_DEFAULT 1          // (A/B builds: -DRD_WG_SYM_DEFAULT=0 keeps the 64 x 64-block kernels for every layer)
+#endif
 
 namespace {
 
@@ -199,27 +204,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const rd_wgrad_t p, int Cout
 // SWAPPED where bit 1 of the pixel index is set -- of four consecutive pixels (any start) two then put the wanted half at 0 / 128 and
 // two at 64 / 192 (mod 256).  A padded pitch of 192 B is conflict-free too but costs 32 KB more LDS per workgroup, and that cost
 // 0.03 ms of step time (other lanes' workgroups no longer fit beside it; docs/experiments.md) for no gain of the kernel alone.
-constexpr int tr_pitch(int channels) { return channels == 32 ? 64 : 128; }
-// byte offset of 16-byte channel slot `slot` of pixel `pix` in a [pixel][C channels] tile
-template <int C>
-__device__ __forceinline__ int tr_off(int pix, int slot) {
-    if constexpr (C == 32) return pix * 64 + slot * 16;
-    else return pix * 128 + ((((slot >> 2) ^ (pix >> 1)) & 1) << 6) + (slot & 3) * 16;
-}
-// a lane's fragment base: pixel pix0 of the tile, 32-channel block blk, `sub` bytes into the block; flip = 1 where the pixels actually
-// read sit an odd multiple of 2 further on (halo rows of odd index at a row length of 34: +34 r)
-template <int C>
-__device__ __forceinline__ int tr_frag(int pix0, int blk, int sub, int flip) {
-    if constexpr (C == 32) return pix0 * 64 + sub;
-    else return pix0 * 128 + (((blk ^ (pix0 >> 1) ^ flip) & 1) << 6) + sub;
-}
-typedef __attribute__((ext_vector_type(4))) short tr_s4;
-typedef __attribute__((address_space(3))) tr_s4 tr_lds_s4;
-__device__ __forceinline__ uint2 lds_tr(const char* p) {
-    const tr_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_s4*)(p));
-    return __builtin_bit_cast(uint2, v);
-}
-
 template <int TAPS, int MB, int NB, int NQZ, bool PF>
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const rd_wgrad_t p, int CoutPadW, int CinPadW, int total_tiles, const rdfin::FinArg fa) {
     rdfin::prologue(fa);                               // BatchNorm-backward finalize folded into this launch (bn_fin.h)
@@ -903,12 +887,14 @@ bool wgrad_slots_ok(const rd_wgrad_t& p) {
 struct WgradGeom {
     int MB, NB, KS, CoutPadW, CinPadW, gx, total_tiles, nsplit;
     bool c16;
+    bool sym;              // wgrad_sym_kernel: 128 gradient channels x 64 input channels per workgroup
 };
 
 template <typename T>
 WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     WgradGeom g;
     g.c16 = false;
+    g.sym = false;
     // 16 x 16 blocks (v_mfma_f32_16x16x32_bf16, 3 workgroups/CU): the 16-channel layers, and -- a grid of such blocks,
     // transpose-read kernel only -- the layers with <= 16 output channels on 32 input channels (dec.out1 32->2,
     // dec.convu1.conv2 32->16, rec.convu1.conv1 32->16), which would leave half of every 32 x 32 block's rows empty
@@ -935,7 +921,14 @@ WgradGeom wgrad_geom(const rd_wgrad_t& p) {
     g.CoutPadW = cout32 * 32;
     g.CinPadW = cin32 * 32;
     g.total_tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
-    const int pairs = (g.CoutPadW / (g.MB * 32)) * (g.CinPadW / (g.NB * 32));
+    int pairs = (g.CoutPadW / (g.MB * 32)) * (g.CinPadW / (g.NB * 32));
+    // 3x3 layers with whole 128-channel blocks of gradient channels on plain sources: the symmetric eight-wave kernel, half as many
+    // workgroups per pixel split (each owns 128 x 64 channels), so twice the splits on the same compute-unit budget
+    if (sizeof(T) == 2 && p.taps == 9 && g.MB == 2 && g.NB == 2 && g.CoutPadW % 128 == 0 && wgrad_pf_ok(p) && p.G * (2 * 64 + 3 * 128) * 4 <= 16384 && (p.na == 1 || p.a[0].C % 64 == 0) &&
+        rd_switch("RD_WG_WS", 1) && rd_switch("RD_WG_SYM", RD_WG_SYM_DEFAULT) && rd_switch("RD_WG_TR_OFF", 0) == 0) {
+        g.sym = true;
+        pairs /= 2;
+    }
     // these kernels hold 144 accumulator registers per lane -> one workgroup per CU is resident: launching more
     // workgroups than CUs only multiplies the partial-sum traffic (147 KB per workgroup for a 64x64 tile)
     // cu_limit: a weight gradient launched on a side stream beside the dgrad chain takes only part of the GPU (its persistent
@@ -1000,6 +993,7 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
         attr_set = true;
     }
     if constexpr (TAPS == 9 && MB == 2 && NB == 2) {
+        if (g.sym) return rd_wgrad_sym_launch(p, g.gx, g.CoutPadW, g.CinPadW, st);
         // 64 x 64 blocks, plain sources: the warp-specialised kernel (4-row LDS tiles: twice the tile count)
         static const int ws = rd_switch("RD_WG_WS", 1);
         if (ws && wgrad_pf_ok(p)) {

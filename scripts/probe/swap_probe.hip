@@ -10,7 +10,11 @@
 // ds_bpermute exchanges per pair; a lane whose two results differ raises a flag, and the wave counts the 16-lane groups that hold a
 // flag (ballot).  Kernel shapes: 1 x 512 threads per CU (160 KB of LDS claimed) and 2 x 256 threads per CU (80 KB each) -- the
 // two-workgroups-per-CU shape is the one that failed alone on the GPU.  Modes: 0 = MFMA -> swap back to back; 1 = the epilogue's
-// neighbourhood as well (a global load in flight, LDS reads between the swaps, a global store behind them, one barrier per iteration).
+// neighbourhood as well (a global load in flight, LDS reads between the swaps, a global store behind them, one barrier per iteration);
+// 2 = the EXACT instruction sequence the compiler emitted in conv_small_fwd_kernel's epilogue (four v_mov, four v_permlane32_swap back
+// to back, then VALU reads of the swapped registers at once -- no LDS wait between the swap and its first consumer, unlike modes 0/1,
+// where the reference shuffles put an s_waitcnt in front of every comparison), pinned with inline assembly; the reference is formed
+// BEFORE the sequence from copies of the registers.
 // Counts are of WAVE-LEVEL swap instructions.  Exit status 0 whatever is found; the numbers go to stdout.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -54,6 +58,45 @@ __global__ __launch_bounds__(THREADS) void swap_kernel(unsigned long long* count
                                                       __builtin_bit_cast(bf16x8, make_uint4(bu[0], bu[1], bu[2], bu[3])), acc, 0, 0, 0);
         unsigned flag = 0;
         float sum = 0.f;
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                unsigned a[4], b[4], r0[4], r1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = __float_as_uint(acc[8 * v + j]);
+                    b[j] = __float_as_uint(acc[8 * v + 4 + j]);
+                    const unsigned oa = __shfl_xor(a[j], 32, 64), ob = __shfl_xor(b[j], 32, 64);
+                    r0[j] = h == 0 ? a[j] : ob;
+                    r1[j] = h == 0 ? oa : b[j];
+                }
+                unsigned t0, t1, t2, t3, e0, e1, e2, e3;
+                float s0, s1;
+                asm volatile(
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_mov_b32 %[t0], %[b0]\n"
+                    "v_mov_b32 %[t1], %[b1]\n"
+                    "v_mov_b32 %[t2], %[b2]\n"
+                    "v_mov_b32 %[t3], %[b3]\n"
+                    "v_permlane32_swap_b32 %[a0], %[t0]\n"
+                    "v_permlane32_swap_b32 %[a1], %[t1]\n"
+                    "v_permlane32_swap_b32 %[a2], %[t2]\n"
+                    "v_permlane32_swap_b32 %[a3], %[t3]\n"
+                    "v_mov_b32 %[e0], %[a1]\n"
+                    "v_mov_b32 %[e1], %[a0]\n"
+                    "v_mov_b32 %[e2], %[a3]\n"
+                    "v_mov_b32 %[e3], %[a2]\n"
+                    "v_add_f32 %[s0], %[t0], %[t1]\n"
+                    "v_add_f32 %[s1], %[t2], %[t3]\n"
+                    : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+                      [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2), [e3] "=&v"(e3), [s0] "=&v"(s0), [s1] "=&v"(s1)
+                    : [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]));
+                flag |= (a[0] != r0[0] || a[1] != r0[1] || a[2] != r0[2] || a[3] != r0[3]) ? 1u : 0u;        // the registers, read later
+                flag |= (t0 != r1[0] || t1 != r1[1] || t2 != r1[2] || t3 != r1[3]) ? 1u : 0u;
+                flag |= (e0 != r0[1] || e1 != r0[0] || e2 != r0[3] || e3 != r0[2]) ? 2u : 0u;                // the reads right behind the swaps
+                flag |= (s0 != __uint_as_float(r1[0]) + __uint_as_float(r1[1]) || s1 != __uint_as_float(r1[2]) + __uint_as_float(r1[3])) ? 2u : 0u;
+            }
+        } else
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
@@ -124,5 +167,7 @@ int main(int argc, char** argv) {
     run<256, 0>("2 x 256 threads per CU, MFMA -> swap", launches, iters, cus, d_counts, d_in, d_out);
     run<512, 1>("1 x 512 threads per CU, epilogue neighbourhood", launches, iters, cus, d_counts, d_in, d_out);
     run<256, 1>("2 x 256 threads per CU, epilogue neighbourhood", launches, iters, cus, d_counts, d_in, d_out);
+    run<512, 2>("1 x 512 threads per CU, the kernel's sequence", launches, iters, cus, d_counts, d_in, d_out);
+    run<256, 2>("2 x 256 threads per CU, the kernel's sequence", launches, iters, cus, d_counts, d_in, d_out);
     return 0;
 }

