@@ -401,6 +401,11 @@ WG_CASES = [
     ('sym_c64_128_many_tiles', 9, [(L.SRC_AFFACT, 64)], 128, 4, 50, 50, 1),
     ('sym_c128_120_ragged', 9, [(L.SRC_AFFACT, 128)], 120, 2, 13, 34, 1),
     ('sym_aff64_256_100wide', 9, [(L.SRC_AFF, 64)], 256, 2, 9, 100, 0),
+    # 64-wide layers (wgrad_ws_kernel; a 64 x 64 form of the symmetric kernel measured slower, docs/experiments.md): a block that straddles the two sources of a concatenated input (dec.convu2.conv3:
+    # 32 + 32), a raw source beside a BatchNorm + ReLU one, a ragged image
+    ('cat32_32_64_straddle', 9, [(L.SRC_AFFACT, 32), (L.SRC_AFF, 32)], 64, 3, 25, 25, 1, [0, 1, 2, 3]),
+    ('cat_raw32_affact32_64_rawdz', 9, [(L.SRC_RAW, 32), (L.SRC_AFFACT, 32)], 64, 2, 13, 70, 0),
+    ('c192_56_ragged', 9, [(L.SRC_AFFACT, 192)], 56, 2, 9, 34, 1),
     ('out32_2', 9, [(L.SRC_AFFACT, 32)], 2, 2, 16, 33, 0),
     ('k1_128_64', 1, [(L.SRC_AFFACT, 128)], 64, 2, 10, 34, 0),
     ('k1_16_16', 1, [(L.SRC_AFFACT, 16)], 16, 2, 20, 20, 0),
