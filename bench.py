@@ -529,8 +529,9 @@ def whole_step_roofline(B, Sz, ms_per_step, dtype):
     return out
 
 
-# reference box for `value_normalised`: what the round-5 profiling box measured on the two micro-kernels (profiles/r06_box_probe.txt)
-BOX_REF = {'copy_gbs': 4950.0, 'mfma_tflops': 2050.0}
+# reference box for `value_normalised`: the median of what the boxes of round 6 measured on the two micro-kernels (profiles/r06_box_probe.txt:
+# copy 4 873-4 908 GB/s, MFMA loop 2 416-2 430 TFLOP/s = 0.97 of the dense bf16 peak)
+BOX_REF = {'copy_gbs': 4900.0, 'mfma_tflops': 2425.0}
 
 
 def box_probe(dev):

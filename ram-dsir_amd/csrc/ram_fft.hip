@@ -25,6 +25,28 @@
 #include "../../include/ramdsir.h"
 #include "ram_dft.h"
 
+// THE STOCKHAM KERNELS (row pass, column pass, row inverse, column amplitude) CLAIM THE WHOLE LDS OF THEIR COMPUTE UNIT (round 6).  The
+// column and row-inverse kernels of the training path need 28.8 KB, and with that five of their
+// workgroups -- or workgroups of OTHER kernels -- share a CU.  Beside certain kernels of the step (conv_small_kernel forward, the 32-wide
+// conv_kernel, the small weight-gradient kernels; on another stream of the same process or in another process) they then produced slightly
+// wrong results: single elements of a transform off by a few per cent, i.e. whole columns / rows of the mixed image off by a bf16 ulp or
+// two -- in 44 % of the PIPELINED steps of one process (RAM beside the encoder backward: scripts/r6/pipelined_x_check.py) and in 2-6 % of
+// the steps under three-process load, never alone, never beside innocent kernels (profiles/r06_ram_coresidency.txt: LDS contents,
+// barriers, sqrt / division and the MFMA regroup all hold under the same load; padding the buffers by 16 KB on both sides does not help;
+// one workgroup per CU does).  No root cause: until there is one, nothing that uses LDS runs on a CU beside these two kernels.
+// RD_RAM_LDS_EXCLUSIVE=0 / RD_RAM_LDS_PAD builds are for the experiments only.
+#ifndef RD_RAM_LDS_EXCLUSIVE
+#define RD_RAM_LDS_EXCLUSIVE 1
+#endif
+#ifndef RD_RAM_LDS_PAD
+#define RD_RAM_LDS_PAD 0            // experiment builds: bytes of unused LDS in front of and behind the buffers
+#endif
+constexpr size_t RAM_CU_LDS = 160 * 1024;
+inline size_t ram_lds_request(size_t need) {
+    need += 2 * RD_RAM_LDS_PAD;
+    return (RD_RAM_LDS_EXCLUSIVE && need < RAM_CU_LDS) ? RAM_CU_LDS : need;
+}
+
 namespace {
 
 struct FftPlan {
@@ -203,8 +225,8 @@ __device__ __forceinline__ void put3(float2* buf, int W, int i, float v) {
 // z[n] = x[2n] + i x[2n+1] (transform c spans 2 halves x W/2 float2 = 2 W floats: channel c's pixel x is float c*2W + x), a
 // W/2-point transform, then X[k] = E[k] + W_N^k O[k] with E, O = (Z[k] +- conj Z[W/2-k]) / 2 (/ i) for the kept bins only --
 // which is zero for zero input and halves the butterflies and LDS traffic; the run-time plan transforms (x, 0).
-template <int NW, int ROWS>
-__global__ __launch_bounds__(256) void ram_row_fwd_kernel(const RamArgs a) {
+template <int NW, int ROWS, int NT>
+__global__ __launch_bounds__(NT) void ram_row_fwd_kernel(const RamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     constexpr bool REAL = NW != 0;
     const int W = a.W, H = a.H, nch = a.nch;
@@ -285,10 +307,10 @@ __global__ __launch_bounds__(256) void ram_row_fwd_kernel(const RamArgs a) {
 
 // B: grid (ceil((b+1)/KT), 3, B): KT bins per workgroup.  LDS transforms: [0,KT) the src columns, [KT,2KT) the trg
 // columns (forward), then [KT,2KT) again as the inverse inputs.
-template <int NH, int KT>
-__global__ __launch_bounds__(256) void ram_col_mix_kernel(const RamArgs a) {
+template <int NH, int KT, int NT>
+__global__ __launch_bounds__(NT) void ram_col_mix_kernel(const RamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    float2* buf = reinterpret_cast<float2*>(smem_);        // [2*KT][2][H], then the twiddle table [H]
+    float2* buf = reinterpret_cast<float2*>(smem_ + RD_RAM_LDS_PAD);        // [2*KT][2][H], then the twiddle table [H]
     const int kx0 = blockIdx.x * KT, c = blockIdx.y, n = blockIdx.z, H = a.H, KP = a.KP, b = a.b;
     const int nk = min(KT, a.nkeep - kx0);
     float2* s_tw = buf + 2 * KT * 2 * H;
@@ -306,12 +328,12 @@ __global__ __launch_bounds__(256) void ram_col_mix_kernel(const RamArgs a) {
     const int cur = fft_any<NH>(buf, have_trg ? 2 * KT : KT, a.ph, s_tw, false, threadIdx.x, blockDim.x);
     const float lam = a.lam[n];
     const int nwin = 2 * b + 1;
-    constexpr int MAXI = (KT * 1025 + 255) / 256;            // window items per thread (H <= 1024)
+    constexpr int MAXI = (KT * 1025 + NT - 1) / NT;          // window items per thread (H <= 1024)
     float2 dv[MAXI];
     int di[MAXI];
 #pragma unroll
     for (int m = 0; m < MAXI; ++m) {
-        const int i = threadIdx.x + m * 256;
+        const int i = threadIdx.x + m * NT;
         di[m] = -1;
         if (i < KT * nwin) {
             const int k = i / nwin, ky = i - k * nwin - b;
@@ -369,10 +391,10 @@ __global__ __launch_bounds__(256) void ram_col_amp_kernel(const RamArgs a) {
 }
 
 // C: grid (ceil(H/ROWS), B)
-template <typename T, int NW, int ROWS>
-__global__ __launch_bounds__(256) void ram_row_inv_kernel(const RamArgs a) {
+template <typename T, int NW, int ROWS, int NT>
+__global__ __launch_bounds__(NT) void ram_row_inv_kernel(const RamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    float2* buf = reinterpret_cast<float2*>(smem_);        // [ROWS * 2 transforms][2][W], then the twiddle table [W]
+    float2* buf = reinterpret_cast<float2*>(smem_ + RD_RAM_LDS_PAD);        // [ROWS * 2 transforms][2][W], then the twiddle table [W]
     const int y0 = blockIdx.x * ROWS, n = blockIdx.y, W = a.W, H = a.H, nb1 = a.b + 1, KP = a.KP;
     const int rows = min(ROWS, H - y0);
     float2* s_tw = buf + ROWS * 2 * 2 * W;
@@ -458,49 +480,70 @@ bool make_plan(int N, FftPlan& p) {
 
 int pad4(int v) { return (v + 3) / 4 * 4; }
 
-template <int NW, int ROWS>
+template <int NW, int ROWS, int NT>
 void launch_row_fwd_r(const RamArgs& a, int nimg, hipStream_t st) {
-    const size_t lds = (size_t)(ROWS * a.nch * 2 * (NW ? a.W / 2 : a.W) + a.W) * sizeof(float2);
-    hipLaunchKernelGGL((ram_row_fwd_kernel<NW, ROWS>), dim3((a.H + ROWS - 1) / ROWS, nimg), dim3(256), lds, st, a);
-}
-template <int NW>
-void launch_row_fwd(const RamArgs& a, int nimg, hipStream_t st) {
-    if (NW == 0 || rd_switch("RD_RAM_ROWS_FWD", 1) == 1) launch_row_fwd_r<NW, 1>(a, nimg, st);
-    else launch_row_fwd_r<NW, 2>(a, nimg, st);
-}
-
-template <int NH, int KT>
-int launch_col_mix_k(const RamArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)(2 * KT * 2 + 1) * a.H * sizeof(float2);
+    const size_t lds = ram_lds_request((size_t)(ROWS * a.nch * 2 * (NW ? a.W / 2 : a.W) + a.W) * sizeof(float2));
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ram_col_mix_kernel<NH, KT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ram_row_fwd_kernel<NW, ROWS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((ram_row_fwd_kernel<NW, ROWS, NT>), dim3((a.H + ROWS - 1) / ROWS, nimg), dim3(NT), lds, st, a);
+}
+// one workgroup per CU (ram_lds_request): 1024 threads on 8 image rows; the run-time plan (any side) keeps one row and 256 threads
+template <int NW>
+void launch_row_fwd(const RamArgs& a, int nimg, hipStream_t st) {
+    if (NW == 0) return launch_row_fwd_r<NW, 1, 256>(a, nimg, st);
+    const int rows = rd_switch("RD_RAM_ROWS_FWD", RD_RAM_LDS_EXCLUSIVE ? 8 : 1);
+    if (RD_RAM_LDS_EXCLUSIVE && rows == 8) return launch_row_fwd_r<NW, 8, 1024>(a, nimg, st);
+    if (rows == 1) launch_row_fwd_r<NW, 1, 256>(a, nimg, st);
+    else launch_row_fwd_r<NW, 2, 256>(a, nimg, st);
+}
+
+template <int NH, int KT, int NT>
+int launch_col_mix_k(const RamArgs& a, hipStream_t st) {
+    const size_t lds = ram_lds_request((size_t)(2 * KT * 2 + 1) * a.H * sizeof(float2));
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ram_col_mix_kernel<NH, KT, NT>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL((ram_col_mix_kernel<NH, KT>), dim3((a.nkeep + KT - 1) / KT, 3, a.B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((ram_col_mix_kernel<NH, KT, NT>), dim3((a.nkeep + KT - 1) / KT, 3, a.B), dim3(NT), lds, st, a);
     return 0;
 }
+// One workgroup per CU (ram_lds_request): 1024 threads on 4 bins (264 workgroups at 8 x 400 x 400: one round of the 256 CUs) instead of five
+// workgroups of 256 threads on 2 bins each
 template <int NH>
 int launch_col_mix(const RamArgs& a, hipStream_t st) {
-    const int kt = NH == 0 ? 1 : rd_switch("RD_RAM_KT", 2);
-    if (kt == 1) return launch_col_mix_k<NH, 1>(a, st);
-    if (kt == 2) return launch_col_mix_k<NH, 2>(a, st);
-    return launch_col_mix_k<NH, 4>(a, st);
+    if (NH == 0) return launch_col_mix_k<NH, 1, 256>(a, st);
+    const int kt = rd_switch("RD_RAM_KT", RD_RAM_LDS_EXCLUSIVE ? 4 : 2);
+    if (RD_RAM_LDS_EXCLUSIVE && kt == 4) return launch_col_mix_k<NH, 4, 1024>(a, st);
+    if (kt == 1) return launch_col_mix_k<NH, 1, 256>(a, st);
+    if (kt == 2) return launch_col_mix_k<NH, 2, 256>(a, st);
+    return launch_col_mix_k<NH, 4, 256>(a, st);
 }
 
-template <typename T, int NW, int ROWS>
+template <typename T, int NW, int ROWS, int NT>
 void launch_row_inv_r(const RamArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)(ROWS * 2 * 2 + 1) * a.W * sizeof(float2);
-    hipLaunchKernelGGL((ram_row_inv_kernel<T, NW, ROWS>), dim3((a.H + ROWS - 1) / ROWS, a.B), dim3(256), lds, st, a);
+    const size_t lds = ram_lds_request((size_t)(ROWS * 2 * 2 + 1) * a.W * sizeof(float2));
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ram_row_inv_kernel<T, NW, ROWS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((ram_row_inv_kernel<T, NW, ROWS, NT>), dim3((a.H + ROWS - 1) / ROWS, a.B), dim3(NT), lds, st, a);
 }
+// One workgroup per CU: 1024 threads on 8 output rows (400 workgroups at 8 x 400 x 400) instead of five workgroups of 256 threads on 2 rows
 template <typename T, int NW>
 void launch_row_inv(const RamArgs& a, hipStream_t st) {
-    const int rows = NW == 0 ? 1 : rd_switch("RD_RAM_ROWS_INV", 2);
-    if (rows == 1) launch_row_inv_r<T, NW, 1>(a, st);
-    else if (rows == 4) launch_row_inv_r<T, NW, 4>(a, st);
-    else launch_row_inv_r<T, NW, 2>(a, st);
+    if (NW == 0) return launch_row_inv_r<T, NW, 1, 256>(a, st);
+    const int rows = rd_switch("RD_RAM_ROWS_INV", RD_RAM_LDS_EXCLUSIVE ? 8 : 2);
+    if (RD_RAM_LDS_EXCLUSIVE && rows == 8) return launch_row_inv_r<T, NW, 8, 1024>(a, st);
+    if (rows == 1) launch_row_inv_r<T, NW, 1, 256>(a, st);
+    else if (rows == 4) launch_row_inv_r<T, NW, 4, 256>(a, st);
+    else launch_row_inv_r<T, NW, 2, 256>(a, st);
 }
 
 #define RD_BY_SIDE(side, CALL)            \
@@ -589,7 +632,15 @@ int rd_ram_amp(const float* img_chw, float* amp_chw, int C, int H, int W, void* 
     a.nch = 1; a.planar = 1;
     hipStream_t st = (hipStream_t)stream;
     launch_row_fwd<0>(a, C, st);
-    hipLaunchKernelGGL(ram_col_amp_kernel, dim3(a.nkeep, C), dim3(256), (size_t)3 * H * sizeof(float2), st, a);
+    {
+        const size_t lds = ram_lds_request((size_t)3 * H * sizeof(float2));
+        static bool attr = false;
+        if (!attr && lds > 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ram_col_amp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL(ram_col_amp_kernel, dim3(a.nkeep, C), dim3(256), lds, st, a);
+    }
     return (int)hipGetLastError();
 }
 

@@ -43,6 +43,12 @@ def run():
     out = dict(params=bank.params.clone(), grads=bank.grads.clone(), losses=ts.losses.clone(), rec=ts.rec_mse.clone(),
                seg_stats=ts.seg.stat_arena.clone(), rec_stats=ts.rec.stat_arena.clone(),
                buffers=torch.cat([v.flatten().double() for v in bank.buffers.values()]))
+    if DETAIL and not NORAM:                                 # the RAM workspace: kept row bins [2B][3][H][KP] and column results [B][3][H][KP] (complex64)
+        m = ts.rams[0]
+        KP = (m.b + 1 + 3) // 4 * 4
+        n1 = 2 * m.B * 3 * m.H * KP * 2
+        out['ram.rowspec [2B][3][H][%d][2]' % KP] = m.ws[:n1].clone()
+        out['ram.colout [B][3][H][%d][2]' % KP] = m.ws[n1:n1 + n1 // 2].clone()
     if DETAIL:                                               # every activation / gradient / coefficient tensor of the two plans, in allocation order
         for name, plan in (('seg', ts.seg), ('rec', ts.rec)):
             for i, t in enumerate(plan.keep):
@@ -78,6 +84,11 @@ for r in range(reps):
                 a, b = torch.nan_to_num(a, nan=1e30), torch.nan_to_num(b, nan=1e30)
                 idx = (a != b).nonzero().flatten()
                 msg.append('%s: %d of %d values, first at %d (%.9g vs %.9g)' % (k, idx.numel(), a.numel(), int(idx[0]), float(a[idx[0]]), float(b[idx[0]])))
+                if k.startswith('ram.'):                     # which (plane, row) pairs: index = ((plane * H + y) * KP + kx) * 2 + re/im
+                    KP_ = int(k.split('[')[-2].rstrip(']'))
+                    rows_ = sorted(set((int(i) // (2 * KP_ * Sz), (int(i) // (2 * KP_)) % Sz) for i in idx.tolist()[:200000]))
+                    kxs_ = sorted(set((int(i) // 2) % KP_ for i in idx.tolist()[:200000]))
+                    msg.append('    %s: %d (plane, y) pairs, first %s; bins kx %s' % (k.split()[0], len(rows_), rows_[:12], kxs_[:44]))
                 if k.startswith('seg.keep[1]') and cur[k].dim() == 4:
                     N_, H_, W_, C_ = cur[k].shape
                     pix = sorted(set((int(i) // (H_ * W_ * C_), (int(i) // (W_ * C_)) % H_, (int(i) // C_) % W_) for i in idx.tolist()))

@@ -68,7 +68,9 @@ def test_loss_bits_of_ten_steps_match_the_committed_golden():
         return
     ref = json.load(open(GOLDEN))
     if (ref['device'], ref['compute_units']) != (got['device'], got['compute_units']):
-        pytest.skip('golden recorded on %s with %d compute units, this is %s with %d: the lane budgets group the partial sums differently'
+        pytest.skip('ULP-LEVEL GATE OFF ON THIS DEVICE: the bitwise golden was recorded on %s with %d compute units, this is %s with %d (the lane '
+                    'budgets group the fp32 partial sums differently, so the bits legitimately differ); only the tolerance-based parity tests '
+                    'guard the arithmetic here -- regenerate with RD_REGEN_BITWISE=1 to arm the gate for this device'
                     % (ref['device'], ref['compute_units'], got['device'], got['compute_units']))
     for name in ('f32', 'bf16'):
         for it, (a, b) in enumerate(zip(got[name]['loss_bits'], ref[name]['loss_bits'])):

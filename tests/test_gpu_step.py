@@ -671,3 +671,33 @@ def test_step_repeats_bit_for_bit_while_other_processes_share_the_gpu(reps, side
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-1500:]
         assert '%d repetitions of one %dx%d step: 0 differ from the first' % (reps, side, side) in o, o[-1500:]
+
+
+def test_pipelined_ram_output_equals_ram_alone_bit_for_bit():
+    """The pipelined step mixes the next batch (RAM) on the restoration lane BESIDE the encoder backward.  Until round 6 the mixed input then
+    differed from RAM run alone in 44 % of the steps (single elements of a transform off by a few per cent = rows / columns of img_freq off
+    by a bf16 ulp or two): the Stockham kernels produced wrong results whenever workgroups of certain other kernels shared their CU
+    (profiles/r06_ram_coresidency.txt).  They claim the whole LDS of their CU now; 300 pipelined steps at the bench shape must give the
+    bits of RAM alone (scripts/r6/pipelined_x_check.py; reference: source_to_target_freq, code/dataset/fundus.py:41-61)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'r6', 'pipelined_x_check.py'), '300'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-1500:]
+    assert '300 pipelined steps: the mixed input differs from RAM alone in 0' in out, out[-1500:]
+
+
+@pytest.mark.parametrize('family', ['rd_conv conv_kernel', 'rd_conv conv_small_kernel'])
+def test_ram_beside_conv_launches_on_another_stream(family):
+    """rd_ram_mix repeated on one stream while the step's conv launches of one family run on a second stream of the same process
+    (scripts/r6/ram_stress.py): kept row bins, column results and both outputs bit-identical in every repetition (before the whole-CU LDS
+    claim: 477 / 553 of 600)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RAM_STRESS_INPROC=family, RAM_STRESS_AGG_REPEAT='2')
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'r6', 'ram_stress.py'), '150', '4'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-1500:]
+    assert '150 repetitions of rd_ram_mix (burst 4): 0 differ from the first' in out, out[-1500:]
