@@ -30,7 +30,8 @@ import torch
 # symbols rocprofv3 reports for them; `count` = the symbols that count as ONE launch where a launch is two kernels):
 #   bwd_fused  dgrad + weight gradient of the <= 32-channel 3x3 convs in one launch (csrc/conv_fused.hip), HBM-bound
 #   conv64     3x3 convs on 64-wide output-channel tiles (conv_ws_kernel + conv_pf_kernel<bf16,9,2,*> + conv_kernel<bf16,9,2> + conv_pp_kernel), MFMA-bound
-#   wgrad      the stand-alone weight gradients (>= 64-channel layers, 1x1 convs, the first conv): MFMA kernel + split reduce
+#   wgrad      the stand-alone weight gradients (>= 64-channel layers -- wgrad_sym_kernel for whole 128-channel gradient blocks, else wgrad_ws_kernel --,
+#              1x1 convs, the first conv): MFMA kernel + split reduce
 #   conv_small forward (and the few unfused gradient) launches of the <= 32-channel convs (conv_small_fwd_kernel / conv_small_kernel), HBM-bound
 #   ram        Random Amplitude Mixup: rd_ram_mix = kept row bins (matrix-core DFT for uint8 images, else row FFT) + column FFT / window mix /
 #              inverse column FFT + inverse row FFT with the output epilogue (3 kernels), HBM-bound
@@ -43,8 +44,8 @@ FAMILIES = {
     'conv64': dict(match=lambda m: m.get('kernel') == 'conv_kernel<bf16,9,2>',
                    symbols=('conv_ws_kernel', 'conv_pf_kernelIDF16bLi9ELi2E', '11conv_kernelIDF16bLi9ELi2E', 'conv_pp_kernel'), count=None),
     'wgrad': dict(match=lambda m: m.get('kernel') == 'wgrad',
-                  symbols=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel'),
-                  count=('wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel')),
+                  symbols=('wgrad_sym_kernel', 'wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel'),
+                  count=('wgrad_sym_kernel', 'wgrad_ws_kernel', 'wgrad_tr_kernel', 'wgrad_c16_tr_kernel', 'wgrad_kernel')),
     'conv_small': dict(match=lambda m: str(m.get('kernel', '')).startswith('conv_small_kernel'),
                        symbols=('conv_small_fwd_kernel', 'conv_small_kernel'), count=None),
     'ram': dict(match=lambda m: m.get('kernel') == 'ram', symbols=('ram_row_dft_kernel', 'ram_row_fwd_kernel', 'ram_col_mix_kernel', 'ram_row_inv_kernel'),
