@@ -638,22 +638,27 @@ __device__ __forceinline__ void grad_plain_finish(const GradPlainReq& q, const r
 }
 
 // The regroup of an accumulator between the two half-waves: r0 = (a of lanes 0-31 | b of lanes 0-31 in lanes 32-63), r1 = (a of lanes 32-63
-// in lanes 0-31 | b of lanes 32-63) -- what v_permlane32_swap a, b computes in one instruction.  NOT with that instruction: in
-// conv_small_fwd_kernel it left 16-lane groups unswapped in 1-2 % of the steps of a process that shares the GPU with other processes,
-// and with two workgroups per CU also alone on the GPU (profiles/r05_determinism.txt; scripts/probe/swap_probe.hip is the stand-alone
-// reproducer, profiles/r06_swap_probe.txt its result).  Round 6: NO kernel of the product library contains the instruction any more
-// (tests/test_cpu_host.py disassembles the library); every epilogue regroups through this function.  ONE 32-lane exchange does it: the
-// lower half-wave needs its partner's a and has its own b to give, the upper half-wave the other way round.  h = lane / 32.
-// -DRD_USE_PERMLANE32_SWAP builds the old form (the probe and A/B timing only).
+// in lanes 0-31 | b of lanes 32-63) -- one v_permlane32_swap.  h = lane / 32.
+// HISTORY (rounds 5-6).  Round 5 found wrong pixels in conv_small_fwd_kernel under GPU sharing (whole 16-lane groups holding exactly the
+// bias), blamed this instruction and replaced it by shuffles in that kernel; round 6 replaced it everywhere -- and then found the real
+// cause (profiles/r06_pk_opsel_erratum.txt): not the swap, but the PACKED fp32 add the SLP vectorizer formed right behind it for the bias
+// (`v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]`).  A packed fp32 instruction whose op_sel makes the low result read the HIGH dword of
+// a source reads 0 for it while a wave of another kernel executes MFMAs on the same SIMD (scripts/probe/pk_canary.hip beside
+// mfma_spin.hip: 0 alone, 5.7e8 wrong products in 8 s beside an MFMA loop) -- bias + 0 = the bias.  The shuffle form merely changed the
+// register allocation so that the vectorizer no longer paired the adds.  Evidence for the instruction: the stand-alone probe (7.9e10 swaps,
+// profiles/r06_swap_probe.txt) and round 5's own reproducer under three builds: swap + vectorizer 578-610 of 2 500 repetitions wrong in each
+// of three processes; swap WITHOUT the vectorizer 0 of 7 500; shuffles without 0 of 7 500 -- and the swap is 1.5 % of the step faster
+// (4.05 vs 4.11 ms).  The library is built with -fno-slp-vectorize -fno-vectorize and contains no packed fp32 instruction
+// (tests/test_cpu_host.py disassembles it).  -DRD_NO_PERMLANE32_SWAP builds the exchange form (one 32-lane ds_bpermute per pair).
 struct HalfSwap { unsigned r0, r1; };
 __device__ __forceinline__ HalfSwap rd_half_swap(unsigned a, unsigned b, int h) {
     HalfSwap r;
-#ifdef RD_USE_PERMLANE32_SWAP
+#ifndef RD_NO_PERMLANE32_SWAP
     const auto s = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     r.r0 = s[0];
     r.r1 = s[1];
 #else
-    const unsigned got = __shfl_xor(h == 0 ? b : a, 32, 64);
+    const unsigned got = __shfl_xor(h == 0 ? b : a, 32, 64);   // the lower half-wave needs its partner's a and gives its b; the upper the other way round
     r.r0 = h == 0 ? a : got;
     r.r1 = h == 0 ? got : b;
 #endif

@@ -58,8 +58,8 @@ __device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // their 72 registers of weights).  4 (inputs of <= 16 channels, the default there): TWO independent 256-thread workgroups per CU, wave w owns
 // rows w and w + 4 -- the phases of a tile (requests, transform, products, epilogue) are serial inside a workgroup (one barrier per tile),
 // two workgroups interleave theirs without one: 58 -> 45 us for the 16 -> 16 launches at 400 x 400, the step 4.19 -> 4.12 ms.
-// (When first measured this shape cost the step its run-to-run repeatability on some boxes; the reason was not the shape but the
-// v_permlane32_swap of the epilogue, see there.)
+// (When first measured this shape cost the step its run-to-run repeatability on some boxes; the reason was neither the shape nor the regroup
+// of the epilogue but a packed fp32 add with op_sel behind it: conv_device.h rd_half_swap, profiles/r06_pk_opsel_erratum.txt.)
 template <int NSL, int OUTV, int XP_, int NWV>
 __global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_small_fwd_kernel(const rd_conv_t p, int tiles_per_wg, const rdfin::FinArg fa) {
     typedef bf16_t T;
@@ -300,10 +300,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void conv_small_fwd_kernel(const
             for (int j = 0; j < 4; ++j) {
                 const unsigned ua = __float_as_uint(acc[8 * v + j]);
                 const unsigned ub = __float_as_uint(acc[8 * v + 4 + j]);
-                // The regroup between the two half-waves by a 32-lane shuffle (rd_half_swap), NOT by v_permlane32_swap: with that instruction here, 1-2 % of
-                // the steps of a process that SHARES the GPU with other processes came out with whole 16-lane groups of a tile row unswapped
-                // (for 16 output channels: the zero rows of the accumulator, i.e. exactly the bias) -- never alone on the GPU, never with the
-                // shuffles (profiles/r05_determinism.txt (6)-(8), scripts/load_stress_ab.sh); wait states in front of it did not help.
+                // (conv_device.h rd_half_swap: the wrong pixels of round 5 were the op_sel'd packed bias add behind this regroup, not the regroup)
                 const HalfSwap rs = rd_half_swap(ua, ub, h);
                 vec[j] = __uint_as_float(rs.r0);
                 vec[4 + j] = __uint_as_float(rs.r1);

@@ -114,10 +114,13 @@ def test_product_path_never_imports_the_oracle():
             assert 'oracle' not in open(os.path.join(pkg, fn)).read(), fn
 
 
-def test_product_library_contains_no_permlane32_swap(tmp_path):
-    """v_permlane32_swap produced wrong pixels under co-resident waves (profiles/r05_determinism.txt, profiles/r06_swap_probe.txt):
-    since round 6 every epilogue regroups through rd_half_swap (csrc/conv_device.h), and the DEVICE CODE of the shipped library --
-    not only the sources -- is checked for the instruction here."""
+def test_product_library_contains_no_packed_fp32(tmp_path):
+    """THE ERRATUM BEHIND BOTH WRONG-RESULT BUGS of rounds 5 and 6 (scripts/probe/pk_canary.hip + mfma_spin.hip,
+    profiles/r06_pk_opsel_erratum.txt): a packed fp32 instruction whose op_sel makes the LOW result read the HIGH dword of a source reads 0
+    for it while a wave of ANOTHER kernel executes MFMAs on the same SIMD.  The compiler forms such instructions from complex arithmetic
+    (the RAM butterflies) and from swapped bias adds (the conv epilogues) through the SLP vectorizer; the library is built with
+    -fno-slp-vectorize -fno-vectorize, and the DEVICE CODE of the shipped library -- not only the flags -- is checked here: no packed fp32
+    arithmetic, no packed instruction with op_sel at all.  (v_permlane32_swap, blamed in round 5, is exonerated and in use.)"""
     import shutil
     from ramdsir import _lib
     objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
@@ -127,13 +130,17 @@ def test_product_library_contains_no_permlane32_swap(tmp_path):
     subprocess.run([objdump, '--offloading', str(so)], cwd=tmp_path, check=True, capture_output=True)
     objs = [f for f in os.listdir(tmp_path) if f.endswith('gfx950')]
     assert objs, 'no gfx950 code objects found in the library'
-    n_inst, n_mfma = 0, 0
+    n_inst, n_mfma, n_pkf32, n_opsel = 0, 0, 0, 0
     for f in objs:
         dis = subprocess.run([objdump, '-d', str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
         n_inst += dis.count('v_permlane32_swap')
         n_mfma += dis.count('v_mfma_f32_32x32x16_bf16')
+        n_pkf32 += len(re.findall(r'v_pk_(?:fma|mul|add)_f32', dis))
+        n_opsel += len(re.findall(r'v_pk_\w+ [^\n]*op_sel', dis))
     assert n_mfma > 100                                     # the disassembly is the real thing
-    assert n_inst == 0, f'{n_inst} v_permlane32_swap instructions in the product library'
+    assert n_inst > 0                                       # the regroup instruction is back (exonerated: conv_device.h rd_half_swap)
+    assert n_pkf32 == 0, f'{n_pkf32} packed fp32 instructions in the product library (build flags lost?)'
+    assert n_opsel == 0, f'{n_opsel} packed instructions with op_sel in the product library'
 
 
 _WORKER = r'''
