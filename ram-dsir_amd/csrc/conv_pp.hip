@@ -114,6 +114,36 @@ __device__ __forceinline__ void pp_advance(PpStage& s, const PpGeo& q, const Gro
     }
 }
 
+// conv_ws_kernel's tile order (cb_slow: channel block, then image, then tile row, then tile column): the next tile is one carry chain
+// away.  The division form above is ~150 dependent scalar instructions per call -- three signed divisions by run-time values, a
+// 16-way group search, reciprocals parked in VGPR lanes -- and both roles ran it at EVERY tile end, in front of the barrier, with
+// nothing to overlap it: 1 000-2 000 cycles of a 12 000 (forward) / 20 000 (gradient) cycle tile (profiles/r06_ws_trace.txt, stamps
+// "advance" and "shift").  pp_decode remains for the first tile of a workgroup.
+__device__ __forceinline__ void ws_advance(PpStage& s, const PpGeo& q, const GroupMap& gm) {
+    if (s.c + 1 < q.nch) {
+        s.c += 1;
+    } else if (s.tile + 1 < q.tile_end) {
+        s.c = 0;
+        s.tile += 1;
+        s.txy += 1;
+        s.x0 += q.tw;
+        if (s.x0 >= q.tiles_x * q.tw) {
+            s.x0 = 0;
+            s.y0 += q.th;
+            if (s.txy == q.tiles_xy) {
+                s.txy = 0;
+                s.y0 = 0;
+                s.n += 1;
+                if (s.n == q.n_img) {
+                    s.n = 0;
+                    s.n0 += PP_NT;
+                }
+                s.g = group_of(gm, s.n);
+            }
+        }
+    }
+}
+
 // The epilogue is the LDS-staged one of conv_epilogue.h (any destination kind).  Launches that qualify for a register
 // epilogue (forward, gradient into plain tensors) go to conv_ws_kernel below instead.
 __global__ __launch_bounds__(256, 1) void conv_pp_kernel(const rd_conv_t p, int tiles_total, const rdfin::FinArg fa) {
@@ -353,8 +383,11 @@ static_assert(WsLds<0>::LDS <= 160 * 1024 && WsLds<1>::LDS <= 160 * 1024, "conv_
 #ifdef RD_DEBUG_SWITCHES
 __device__ unsigned long long ws_trace[2][64][4];          // [role][step][event] shader-clock stamps of workgroup 5 (debug build)
 #define WS_T(role, s, ev) do { if (trace_ && blockIdx.x == 5 && tid == 0 && (s) < 63) ws_trace[role][s][ev] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long ws_fine[2][16][16];         // [role][step][event]: stamps INSIDE a step (they cost a scalar-memory wait each)
+#define WS_F(role, s, ev) do { if (trace_ && blockIdx.x == 5 && tid == 0 && (s) < 16) ws_fine[role][s][ev] = __builtin_readcyclecounter(); } while (0)
 #else
 #define WS_T(role, s, ev) do { } while (0)
+#define WS_F(role, s, ev) do { } while (0)
 #endif
 #if defined(RD_DEBUG_SWITCHES) && defined(RD_WS_EXP)         // timing experiments (results wrong): -DRD_WS_EXP + RD_CONV_WS_EXP=bits
 #define WS_EXP(bit) ((exp_ & (bit)) != 0)
@@ -468,6 +501,8 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
 
     if (role == 1) {
         // =============================================================================== loader waves
+        // (s_setprio 1 for this half, the younger one of the workgroup: gradient launches +6 %, the step 3.998 -> 4.017 ms; for the
+        // MFMA half: no change -- docs/experiments.md, round 6)
         const int sw = tid & 3, nn_w = tid >> 2;
         int it_yx[PP_NIT], it_lds[PP_NIT];
 #pragma unroll
@@ -609,7 +644,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                 for (int b = 0; b < PP_NIT; ++b) offC[b] = offL[b];
             }
             const int tile0 = L.tile;
-            pp_advance(L, q, gm);
+            ws_advance(L, q, gm);
             if (L.tile != tile0) tile_geom();
         };
         // prologue: step 0 into buffer 0, step 1 requested
@@ -637,11 +672,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             const int nxt = (s & 1) ^ 1;
             if (WS_EXP(8)) { __syncthreads(); continue; }
             WS_T(1, s, 0);
+            WS_F(1, s, 0);
             begin_issue();
             begin_w();
+            WS_F(1, s, 1);
             if (__builtin_amdgcn_ballot_w64(!copyC) != 0) {
 #pragma unroll
-                for (int b = 0; b < PP_NIT; ++b) { consume_item(b, nxt, true); issue_item(b); }
+                for (int b = 0; b < PP_NIT; ++b) { consume_item(b, nxt, true); issue_item(b); WS_F(1, s, 2 + b); }
             } else {
 #pragma unroll
                 for (int b = 0; b < PP_NIT; ++b) { consume_item(b, nxt, false); issue_item(b); }
@@ -652,9 +689,12 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                 for (int t = 0; t < PP_WIT; ++t) { consume_w(t, nxt); issue_w(t); }
             }
             WS_T(1, s, 2);
+            WS_F(1, s, 8);
             shift_stages();
+            WS_F(1, s, 9);
             __syncthreads();
             WS_T(1, s, 3);
+            WS_F(1, s, 10);
         }
         return;
     }
@@ -688,7 +728,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         for (int t = 0; t < PP_WIT; ++t) w_issue(t);       // step 0
 #pragma unroll
         for (int t = 0; t < PP_WIT; ++t) w_store(t, 0);    // step 0 -> buffer 0
-        pp_advance(Lw, q, gm);                             // Lw = step 1: what the first loop iteration requests AND stores
+        ws_advance(Lw, q, gm);                             // Lw = step 1: what the first loop iteration requests AND stores
     }
 
     // operand fragments of one (tap, k-step) group: A = 2 x (32 pixels x 16 channels), B = 2 x (32 outputs x 16 channels);
@@ -764,30 +804,49 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int v = 0; v < 2; ++v) zq[mb][nb][v] = make_uint4(0, 0, 0, 0);
-    auto dst_index = [&](const rd_dst_t& d, int di, int nb, int v, int y, int x) -> size_t {
-        const int cd = M.n0 + nb * 32 + 16 * v - (di ? p.c_split : 0) + 8 * h;
-        return ((size_t)((M.n + d.n_off) * H + y) * W + x) * d.Cd + cd;
-    };
+    // Where a lane's vectors of the destination tensors sit: 32-BIT byte offsets from the (wave-uniform) tensor base, one multiply of
+    // 24-bit operands each (rd_conv_ws_takes: the images of a destination number < 2^24 pixels and < 4 GB).  Written with size_t
+    // indices, each of the sixteen addresses of a tile -- eight producer-tensor requests, eight gradient stores -- was ~35
+    // instructions with two 64-bit multiply-adds and two quarter-rate 32-bit multiplies: ~2 000 cycles in front of the last K step's
+    // MFMAs and ~2 000 more inside the epilogue of a 20 000-cycle tile (profiles/r06_ws_trace.txt, stamp "pref+g0").  The gradient
+    // and the producer tensor of a destination share shape and index, so the epilogue reuses the prefetch's offsets.
+    unsigned zoff[2][2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) zoff[mb][nb][v] = 0u;
     // The eight requests are UNCONDITIONAL (a vector without a producer tensor reads a dummy line): written as `if (d.z) zq = load`, every
     // load sat in its own conditional block and the compiler put `s_waitcnt vmcnt(0)` in front of each one -- eight dependent HBM round
     // trips in front of the last K step's MFMAs (scripts/ws_trace.py on dec.convu2.conv3's gradient: 9 000-10 700 cycles for that step
     // against 3 300 for the others)
     auto dgrad_prefetch = [&]() {
-        const T* dummy = reinterpret_cast<const T*>(p.w);
+        const char* dummy = reinterpret_cast<const char*>(p.w);
+        unsigned pixl[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int y = min(M.y0 + px_r[mb], H - 1), x = min(M.x0 + px_c[mb], W - 1);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    const int di = (M.n0 + nb * 32 + 16 * v) >= p.c_split ? 1 : 0;
-                    const rd_dst_t d = select_dst(p, di);
-                    const bool has = d.kind != RD_DST_NONE && d.z != nullptr;
-                    const size_t idx = has ? dst_index(d, di, nb, v, y, x) : 0;
-                    zq[mb][nb][v] = ld16(has ? reinterpret_cast<const T*>(d.z) + idx : dummy);
-                }
+            pixl[mb] = __umul24((unsigned)y, (unsigned)W) + (unsigned)x;
         }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int c0 = M.n0 + nb * 32 + 16 * v;
+                const int di = c0 >= p.c_split ? 1 : 0;
+                const rd_dst_t d = select_dst(p, di);
+                const bool has = d.kind != RD_DST_NONE && d.z != nullptr;
+                const unsigned nbase = (unsigned)((M.n + d.n_off) * H * W);
+                const unsigned cd = (unsigned)(c0 - (di ? p.c_split : 0)) + 8u * h;
+                const char* zb = has ? reinterpret_cast<const char*>(d.z) : dummy;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const unsigned off = (__umul24(nbase + pixl[mb], (unsigned)d.Cd) + cd) * (unsigned)sizeof(T);
+                    zoff[mb][nb][v] = off;
+                    zq[mb][nb][v] = ld16(zb + (has ? off : 0u));
+                }
+            }
     };
     // one accumulator block's 16 channels of a lane's pixel as two 8-channel NHWC vectors
     auto regroup = [&](const f32x16& a, int v, float* o) {
@@ -814,10 +873,12 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     for (int s = 0; s < nsteps; ++s) {
         const int par = s & 1;
         WS_T(0, s, 0);
+        WS_F(0, s, 0);
         if constexpr (MODE == 2) {
             if (M.c == q.nch - 1) dgrad_prefetch();
         }
         load_group(0, par, fr[0]);
+        WS_F(0, s, 1);
 #pragma unroll
         for (int grp = 0; grp < 18; ++grp) {
             if constexpr (WMFMA) {
@@ -856,8 +917,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if (grp == 5) WS_F(0, s, 2);
+            if (grp == 11) WS_F(0, s, 3);
         }
         WS_T(0, s, 1);
+        WS_F(0, s, 4);
         if (M.c == q.nch - 1) {
             if (M.n0 != cur_n0 || M.g != cur_g) {
                 flush_stats();
@@ -872,8 +936,16 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                 pxx[mb] = M.x0 + px_c[mb];
                 pin[mb] = px_live[mb] && py[mb] < H && pxx[mb] < W;
             }
+            WS_F(0, s, 5);
             if constexpr (MODE == 1) {
-                T* out = reinterpret_cast<T*>(p.out) + (size_t)M.n * H * W * p.Cout + M.n0 + 8 * h;
+                // 32-bit byte offsets from the uniform tensor base (see zoff above): one per tile row of the wave, the eight stores differ by
+                // an immediate
+                char* outb = reinterpret_cast<char*>(p.out);
+                unsigned ob[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    ob[mb] = (__umul24((unsigned)(M.n * H * W) + __umul24((unsigned)py[mb], (unsigned)W) + (unsigned)pxx[mb], (unsigned)p.Cout) +
+                              (unsigned)(M.n0 + 8 * h)) * (unsigned)sizeof(T);
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -895,9 +967,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                                     }
                                     o[e] += bs[e];
                                 }
-                                if (!WS_EXP(16)) *reinterpret_cast<uint4*>(out + (size_t)(py[mb] * W + pxx[mb]) * p.Cout + nb * 32 + 16 * v) = Slot<T>::pack(o);
+                                if (!WS_EXP(16)) *reinterpret_cast<uint4*>(outb + ob[mb] + (nb * 32 + 16 * v) * (int)sizeof(T)) = Slot<T>::pack(o);
                             }
                         }
+                        WS_F(0, s, 6 + nb * 2 + v);
                     }
             } else {
 #pragma unroll
@@ -922,7 +995,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                             // gradient read here (`d.accumulate ? ld16(gp) : 0`), every vector waited vmcnt(0) -- i.e. for the previous
                             // vector's STORE to be acknowledged -- before its own arithmetic: eight serialized round trips per tile
                             // (6 500-11 000 cycles of epilogue against the forward mode's 2 000-3 000)
-                            T* gp = reinterpret_cast<T*>(d.g) + dst_index(d, di, nb, v, py[mb], pxx[mb]);
+                            T* gp = reinterpret_cast<T*>(reinterpret_cast<char*>(d.g) + zoff[mb][nb][v]);   // a live pixel: the prefetch's clamp was the identity
                             float z[S], gw[S];
                             Slot<T>::unpack(zq[mb][nb][v], z);
 #pragma unroll
@@ -935,6 +1008,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                             }
                             *reinterpret_cast<uint4*>(gp) = Slot<T>::pack(gw);
                         }
+                        WS_F(0, s, 6 + nb * 2 + v);
                     }
             }
 #pragma unroll
@@ -943,12 +1017,15 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+            WS_F(0, s, 10);
         }
         WS_T(0, s, 2);
-        pp_advance(M, q, gm);
-        if constexpr (WMFMA) pp_advance(Lw, q, gm);
+        ws_advance(M, q, gm);
+        if constexpr (WMFMA) ws_advance(Lw, q, gm);
+        WS_F(0, s, 11);
         __syncthreads();
         WS_T(0, s, 3);
+        WS_F(0, s, 12);
     }
 #ifdef RD_DEBUG_SWITCHES
     if (trace_ && blockIdx.x == 5 && tid == 0) { ws_trace[0][63][2] = __builtin_readcyclecounter(); ws_trace[0][63][3] = wall_clock64(); }
@@ -975,6 +1052,9 @@ int pp_sources_kind(const rd_conv_t& p) {
 }  // namespace
 
 #ifdef RD_DEBUG_SWITCHES
+extern "C" int rd_debug_ws_fine(unsigned long long* out) {              // debug library only: 2 x 16 x 16 stamps inside the steps
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_fine), sizeof(unsigned long long) * 2 * 16 * 16);
+}
 extern "C" int rd_debug_ws_trace(unsigned long long* out) {             // debug library only: 2 x 64 x 4 stamps
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(unsigned long long) * 2 * 64 * 4);
 }
@@ -993,6 +1073,15 @@ bool rd_conv_ws_takes(const rd_conv_t& p) {
     if (mode == 2)
         for (int i = 0; i < 2; ++i) accumulates = accumulates || (p.dst[i].kind != RD_DST_NONE && p.dst[i].accumulate);
     if (skind == 2 && mode != 2) return false;
+    // the epilogues address their destinations with 32-bit byte offsets built from 24-bit multiplies (conv_ws_kernel, zoff / ob)
+    auto fits32 = [&](long long images, long long C) {
+        const long long px = images * p.H * p.W;
+        return px < (1ll << 24) && px * C * (long long)sizeof(bf16_t) < (1ll << 32);
+    };
+    if (mode == 1 && !fits32(p.N, p.Cout)) return false;
+    if (mode == 2)
+        for (int i = 0; i < 2; ++i)
+            if (p.dst[i].kind != RD_DST_NONE && !fits32((long long)p.N + p.dst[i].n_off, p.dst[i].Cd)) return false;
     return mode && (ws & mode) && (mode == 1 || (tiles >= ws_min2 && !accumulates)) && tab <= (size_t)WsLds<0>::TAB_BYTES;
 }
 

@@ -36,3 +36,22 @@ for s in range(show):
     print('%3d  | %8d %6d %6d %6d | %8d %6d %6d %6d' % (s, c[0] - t0, c[1] - c[0], c[2] - c[1], c[3] - c[2], l[0] - t0, l[1] - l[0], l[2] - l[1], l[3] - l[2]))
 k = t[0, 63]
 print('kernel body: %d shader ticks, %d realtime ticks (100 MHz) -> %.1f us, shader clock %.2f GHz' % (k[2] - k[0], k[3] - k[1], (k[3] - k[1]) / 100.0, (k[2] - k[0]) / max(k[3] - k[1], 1) / 10.0))
+if hasattr(raw, 'rd_debug_ws_fine'):
+    fb = (ctypes.c_ulonglong * (2 * 16 * 16))()
+    assert raw.rd_debug_ws_fine(fb) == 0
+    f = np.array(fb, dtype=np.uint64).reshape(2, 16, 16).astype(np.int64)
+    names = (['start', 'pref+g0', 'grp5', 'grp11', 'grp17', 'flush?', 'nb0v0', 'nb0v1', 'nb1v0', 'nb1v1', 'zero', 'advance', 'barrier'],
+             ['start', 'begin', 'item0', 'item1', 'item2', 'item3', 'item4', 'item5', 'weights', 'shift', 'barrier'])
+    for role, nm in ((0, 'MFMA wave'), (1, 'loader wave')):
+        print('%s, stamps inside a step (cycles since the previous stamp; each stamp costs a scalar-memory wait)' % nm)
+        print('step | ' + ' '.join('%7s' % n for n in names[role]))
+        for s in range(min(show, 12)):
+            row, prev = [], None
+            for k in range(len(names[role])):
+                v = f[role, s, k]
+                if v == 0 or (prev is not None and v < prev):
+                    row.append('      -')
+                    continue
+                row.append('%7d' % (v - (prev if prev is not None else t0)))
+                prev = v
+            print('%3d  | ' % s + ' '.join(row))

@@ -321,6 +321,13 @@ def test_conv_forward_also_stores_its_staged_sources(case):
     o32 = torch.zeros((N, H, W, 32), dtype=torch.bfloat16, device=U.dev())
     q.emode, q.out, q.stats = 0, o32.data_ptr(), None
     assert L.lib().rd_conv_honours_src_out(C.byref(q), L.RD_BF16) == 0
+    # the 64-wide kernel addresses its destinations with 32-bit offsets built from 24-bit multiplies: a destination of 2^24 pixels or
+    # more is routed elsewhere by the same function (descriptor only, nothing is launched)
+    n_keep = p.N
+    p.N = (1 << 24) // (H * W) + 1
+    assert L.lib().rd_conv_honours_src_out(C.byref(p), L.RD_BF16) == 0
+    p.N = n_keep
+    assert L.lib().rd_conv_honours_src_out(C.byref(p), L.RD_BF16) == 1
 
 
 def test_conv_gradient_also_stores_the_dz_it_forms():
