@@ -535,6 +535,47 @@ def whole_step_roofline(B, Sz, ms_per_step, dtype):
 BOX_REF = {'copy_gbs': 4900.0, 'mfma_tflops': 2425.0}
 
 
+def shader_clock(dev, step):
+    """Average shader clock (GHz) over 20 complete steps and over each box micro-kernel: two stamps of rd_box_probe(2) -- the
+    shader-clock counter and the constant 100 MHz counter -- in stream order around the work, after the timed region.  A single
+    launch on an idle device runs at 1.9-2.4 GHz depending on its instruction mix (docs/experiments.md, round 6); this says what the
+    clock is in the steady state the bench times, i.e. whether the peaks the roofline quotes (at the 2.4 GHz boost clock) apply."""
+    from ramdsir import _lib as L
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    stamps = torch.zeros(2, 2, dtype=torch.int64, device=dev)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def ghz(work):
+        work()                                                        # warm
+        torch.cuda.synchronize()
+        assert lib.rd_box_probe(2, stamps[0].data_ptr(), None, 0, st) == 0
+        work()
+        assert lib.rd_box_probe(2, stamps[1].data_ptr(), None, 0, st) == 0
+        torch.cuda.synchronize()
+        d = (stamps[1] - stamps[0]).tolist()
+        return round(0.1 * d[0] / max(d[1], 1), 3)
+
+    def steps():
+        for _ in range(20):
+            step()
+
+    def mfma():
+        for _ in range(2):
+            assert lib.rd_box_probe(1, sink.data_ptr(), None, 40000, st) == 0
+
+    def copy():
+        for _ in range(40):
+            assert lib.rd_box_probe(0, a.data_ptr(), b.data_ptr(), n, st) == 0
+    out = dict(step=ghz(steps), mfma_probe=ghz(mfma), copy_probe=ghz(copy),
+               how='100 MHz x d(shader-clock counter) / d(100 MHz counter) between two stamps on the main stream: 20 steps; 2 MFMA probe launches; 40 copies of 256 MiB')
+    del a, b
+    return out
+
+
 def box_probe(dev):
     """What THIS box's GPU sustains on two fixed ~50 ms micro-kernels (csrc/box.hip through rd_box_probe): a 1 GiB streaming copy and a
     dependent-free v_mfma_f32_32x32x16_bf16 loop on every CU.  Boxes of the pool differ by a few per cent (round 5: +-3 %, more than
@@ -729,6 +770,8 @@ def main():
             try:
                 out['box'] = box_probe(dev)
                 out['value_normalised'] = round(out['value'] / out['box']['speed_vs_ref'], 2)
+                if world == 1:
+                    out['box']['shader_ghz'] = shader_clock(dev, step)
             except Exception as e:                                    # diagnostic: never lose the line over it
                 out['box'] = {'error': repr(e)[:200]}
         # HBM traffic measured by this run (a rocprofv3 child of the same command, after the timed region); single process only: under

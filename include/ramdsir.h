@@ -464,6 +464,8 @@ int rd_run_list_threads(int enable);
  *   which 0: streaming copy of n bytes (n % 16 == 0) from a to b, 16 B per lane, 8 workgroups of 256 threads per CU;
  *   which 1: n iterations of four independent v_mfma_f32_32x32x16_bf16 per wave, 8 waves on every CU (a: >= 4 bytes of device scratch, b unused):
  *            flops = CUs x 8 x n x 4 x 32768.
+ *   which 2: one stamp {shader-clock counter, 100 MHz counter} into a[0..1] (two 8-byte words), in stream order (b, n unused): two
+ *            stamps around a stretch of work on one stream give its average shader clock = 100 MHz x d(a[0]) / d(a[1]).
  * The caller times the launch with events on `stream`. */
 int rd_box_probe(int which, void* a, void* b, int64_t n, void* stream);
 

@@ -34,6 +34,15 @@ __global__ __launch_bounds__(512, 1) void box_mfma_kernel(float* sink, int iters
     if (s == 12345.678f) sink[0] = s;                      // keeps the loop alive; never true
 }
 
+// one stamp of the shader-clock counter (s_memtime) and of the constant 100 MHz counter: two stamps around any stretch of work on the
+// same stream give the AVERAGE SHADER CLOCK of that stretch (bench.py `box.shader_ghz`: is the step clock-throttled?)
+__global__ void box_clock_kernel(unsigned long long* out) {
+    if (threadIdx.x == 0) {
+        out[0] = __builtin_readcyclecounter();
+        out[1] = wall_clock64();
+    }
+}
+
 }  // namespace
 
 extern "C" int rd_box_probe(int which, void* a, void* b, int64_t n, void* stream) {
@@ -44,6 +53,9 @@ extern "C" int rd_box_probe(int which, void* a, void* b, int64_t n, void* stream
     } else if (which == 1) {                               // n iterations of 4 MFMAs per wave, 8 waves per CU; a: 4 bytes of scratch
         if (!a || n < 1 || n > (1ll << 30)) return -1;
         hipLaunchKernelGGL(box_mfma_kernel, dim3(rd_num_cus()), dim3(512), 0, st, (float*)a, (int)n);
+    } else if (which == 2) {                               // a: two 8-byte counters (shader clock, 100 MHz clock) stamped in stream order
+        if (!a) return -1;
+        hipLaunchKernelGGL(box_clock_kernel, dim3(1), dim3(64), 0, st, (unsigned long long*)a);
     } else {
         return -1;
     }

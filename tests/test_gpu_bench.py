@@ -67,6 +67,7 @@ def test_bench_launches_its_own_ranks_when_no_launcher_did():
     d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
     assert d['n_gpus'] == 1 and d['value'] > 0 and d['config']['parallelism'] == 'dp1'
     assert d['box']['copy_gbs'] > 1000 and d['box']['mfma_tflops'] > 500 and d['value_normalised'] > 0
+    assert all(1.0 < d['box']['shader_ghz'][k] < 3.0 for k in ('step', 'mfma_probe', 'copy_probe')), d['box']['shader_ghz']
     import torch
     if torch.cuda.device_count() < 2:
         r2 = subprocess.run(base + ['--gpus', '2', '--no-box'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
