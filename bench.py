@@ -543,7 +543,7 @@ def shader_clock(dev, step):
     from ramdsir import _lib as L
     lib = L.lib()
     st = torch.cuda.current_stream().cuda_stream
-    stamps = torch.zeros(2, 2, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(2, 2048, 2, dtype=torch.int64, device=dev)   # [before / after][unit][shader clock, 100 MHz clock]
     sink = torch.zeros(4, dtype=torch.float32, device=dev)
     n = 1 << 28
     a = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1)
@@ -556,8 +556,10 @@ def shader_clock(dev, step):
         work()
         assert lib.rd_box_probe(2, stamps[1].data_ptr(), None, 0, st) == 0
         torch.cuda.synchronize()
-        d = (stamps[1] - stamps[0]).tolist()
-        return round(0.1 * d[0] / max(d[1], 1), 3)
+        both = (stamps[0, :, 1] != 0) & (stamps[1, :, 1] != 0)        # units stamped both times (counters of different XCDs are not aligned)
+        d = (stamps[1] - stamps[0])[both].double()
+        stamps.zero_()
+        return round(float((0.1 * d[:, 0] / d[:, 1].clamp_min(1)).median()), 3) if int(both.sum()) else None
 
     def steps():
         for _ in range(20):
@@ -571,7 +573,7 @@ def shader_clock(dev, step):
         for _ in range(40):
             assert lib.rd_box_probe(0, a.data_ptr(), b.data_ptr(), n, st) == 0
     out = dict(step=ghz(steps), mfma_probe=ghz(mfma), copy_probe=ghz(copy),
-               how='100 MHz x d(shader-clock counter) / d(100 MHz counter) between two stamps on the main stream: 20 steps; 2 MFMA probe launches; 40 copies of 256 MiB')
+               how='median over the compute units of 100 MHz x d(shader-clock counter) / d(100 MHz counter) between two per-unit stamps on the main stream: 20 steps; 2 MFMA probe launches; 40 copies of 256 MiB')
     del a, b
     return out
 

@@ -464,8 +464,10 @@ int rd_run_list_threads(int enable);
  *   which 0: streaming copy of n bytes (n % 16 == 0) from a to b, 16 B per lane, 8 workgroups of 256 threads per CU;
  *   which 1: n iterations of four independent v_mfma_f32_32x32x16_bf16 per wave, 8 waves on every CU (a: >= 4 bytes of device scratch, b unused):
  *            flops = CUs x 8 x n x 4 x 32768.
- *   which 2: one stamp {shader-clock counter, 100 MHz counter} into a[0..1] (two 8-byte words), in stream order (b, n unused): two
- *            stamps around a stretch of work on one stream give its average shader clock = 100 MHz x d(a[0]) / d(a[1]).
+ *   which 2: stamps {shader-clock counter, 100 MHz counter} of every compute unit that one of 4096 small workgroups lands on, into
+ *            a[2 * unit + 0..1] (2048 units x two 8-byte words, unit = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4 | CU_ID; untouched slots
+ *            keep their contents), in stream order (b, n unused): two launches around a stretch of work on one stream give its
+ *            average shader clock per unit = 100 MHz x d(a[2u]) / d(a[2u + 1]) (counters of different XCDs are not aligned).
  * The caller times the launch with events on `stream`. */
 int rd_box_probe(int which, void* a, void* b, int64_t n, void* stream);
 

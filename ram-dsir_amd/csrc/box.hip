@@ -34,12 +34,19 @@ __global__ __launch_bounds__(512, 1) void box_mfma_kernel(float* sink, int iters
     if (s == 12345.678f) sink[0] = s;                      // keeps the loop alive; never true
 }
 
-// one stamp of the shader-clock counter (s_memtime) and of the constant 100 MHz counter: two stamps around any stretch of work on the
-// same stream give the AVERAGE SHADER CLOCK of that stretch (bench.py `box.shader_ghz`: is the step clock-throttled?)
-__global__ void box_clock_kernel(unsigned long long* out) {
+// stamps of the shader-clock counter (s_memtime) and of the constant 100 MHz counter, ONE PAIR PER COMPUTE UNIT (the shader-clock
+// counters of different XCDs are not aligned: a difference is only meaningful between two stamps taken on the same unit).  4096 small
+// workgroups reach every unit; each writes the slot of the unit it runs on: out[unit][0..1], unit = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4
+// | CU_ID (2048 slots).  Two launches around a stretch of work on one stream give its AVERAGE SHADER CLOCK per unit (bench.py
+// `box.shader_ghz`: is the step clock-throttled?)
+__global__ __launch_bounds__(64) void box_clock_kernel(unsigned long long* out) {
     if (threadIdx.x == 0) {
-        out[0] = __builtin_readcyclecounter();
-        out[1] = wall_clock64();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned unit = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+        out[2 * unit + 0] = __builtin_readcyclecounter();
+        out[2 * unit + 1] = wall_clock64();
     }
 }
 
@@ -53,9 +60,9 @@ extern "C" int rd_box_probe(int which, void* a, void* b, int64_t n, void* stream
     } else if (which == 1) {                               // n iterations of 4 MFMAs per wave, 8 waves per CU; a: 4 bytes of scratch
         if (!a || n < 1 || n > (1ll << 30)) return -1;
         hipLaunchKernelGGL(box_mfma_kernel, dim3(rd_num_cus()), dim3(512), 0, st, (float*)a, (int)n);
-    } else if (which == 2) {                               // a: two 8-byte counters (shader clock, 100 MHz clock) stamped in stream order
+    } else if (which == 2) {                               // a: 2048 x two 8-byte counters (shader clock, 100 MHz clock), one pair per unit
         if (!a) return -1;
-        hipLaunchKernelGGL(box_clock_kernel, dim3(1), dim3(64), 0, st, (unsigned long long*)a);
+        hipLaunchKernelGGL(box_clock_kernel, dim3(4096), dim3(64), 0, st, (unsigned long long*)a);
     } else {
         return -1;
     }

@@ -408,7 +408,13 @@ template <int MODE, int TS, bool BWD2 = false, bool SOUT = false>
 __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int tiles_total, const rdfin::FinArg fa) {
     // BatchNorm finalize folded into this launch (bn_fin.h), global path: the loader waves fetch the coefficients with global loads
     // every step (ldf4g below: not flat loads, which would tie up the LDS counter), so the vectors must be in memory
+#ifdef RD_DEBUG_SWITCHES
+    const unsigned long long t_entry_ = __builtin_readcyclecounter();
+#endif
     rdfin::prologue(fa);
+#ifdef RD_DEBUG_SWITCHES
+    const unsigned long long t_fin_ = __builtin_readcyclecounter();
+#endif
     typedef bf16_t T;
     constexpr int S = 8;
     static_assert(MODE == 1 || MODE == 2, "register epilogues only");
@@ -859,9 +865,15 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     };
 
 #ifdef RD_DEBUG_SWITCHES
-    if (trace_ && blockIdx.x == 5 && tid == 0) { ws_trace[0][63][0] = __builtin_readcyclecounter(); ws_trace[0][63][1] = wall_clock64(); }
+    if (trace_ && blockIdx.x == 5 && tid == 0) {
+        ws_trace[0][63][0] = __builtin_readcyclecounter(); ws_trace[0][63][1] = wall_clock64();
+        ws_fine[0][15][0] = t_entry_; ws_fine[0][15][1] = t_fin_; ws_fine[0][15][2] = ws_trace[0][63][0];      // kernel entry, folded finalize done, tables built
+    }
 #endif
     __syncthreads();                     // buffer 0 filled (the loader waves' prologue)
+#ifdef RD_DEBUG_SWITCHES
+    if (trace_ && blockIdx.x == 5 && tid == 0) ws_fine[0][15][3] = __builtin_readcyclecounter();                   // first buffer filled
+#endif
     // the accumulators are cleared BEHIND each tile's epilogue (and here for the first tile), not at the head of a tile: the compiler then
     // sees them dead across the epilogue and regroups them in place instead of copying 64 registers per tile first
 #pragma unroll

@@ -9,6 +9,9 @@ for c in C3 C5 F256; do timeout 600 python3 bench.py --config $c --no-cpu-baseli
 timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-leg --no-ablation --no-live-pmc --no-saturation > $O/bench_driver_form.json 2>/dev/null
 timeout 300 python3 scripts/layer_bench.py bf16 400 250 > $O/layer_bench.txt 2>&1
 timeout 300 python3 scripts/contended_ops.py 30 > $O/contended_ops.txt 2>&1
+# stamps inside conv_ws_kernel's steps (debug library), forward and gradient launch of one layer; the gradient launches on the whole device
+for w in fwd dgrad; do RAMDSIR_DEBUG_LIB=1 RD_CONV_WS_TRACE_MIN=1 timeout 300 python3 scripts/r6/ws_trace2.py $w dec.convu2.conv3 10 > $O/ws_fine_$w.txt 2>&1; done
+RAMDSIR_DEBUG_LIB=1 RD_DGRAD_CUS=0 timeout 300 python3 scripts/layer_bench.py bf16 400 250 2>/dev/null | grep "conv_kernel<bf16,9" > $O/layer_bench_dgrad256.txt
 python3 -c "
 import json
 for f in ('bench', 'bench_C3', 'bench_C5', 'bench_F256', 'bench_driver_form'):

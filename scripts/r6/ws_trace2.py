@@ -55,3 +55,6 @@ if hasattr(raw, 'rd_debug_ws_fine'):
                 row.append('%7d' % (v - (prev if prev is not None else t0)))
                 prev = v
             print('%3d  | ' % s + ' '.join(row))
+    e = f[0, 15]
+    print('before the first step: folded finalize %d cycles, tables %d, first buffer (loader prologue) %d; first step starts %d cycles after kernel entry'
+          % (e[1] - e[0], e[2] - e[1], e[3] - e[2], t0 - e[0]))
