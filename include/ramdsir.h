@@ -458,6 +458,14 @@ int rd_join_lanes(void* const* streams, int n_streams, uint32_t mask);
  * GPU executes the same graph.  Not used while the main stream is being captured.  Returns the previous setting.  Process-wide;
  * rd_run_list itself must still be called from one thread at a time. */
 int rd_run_list_threads(int enable);
+/* enable != 0 (the default): a lane fork that directly follows a launch of the main stream takes its event from that launch's own
+ * dispatch packet (hipExtLaunchKernelGGL stop event) instead of a hipEventRecord behind it: a record is a packet of its own between two
+ * dependent kernels and costs the main stream ~3 us per fork (scripts/probe/ext_event.hip), ~40 times per training step.  The
+ * dependency is the same one -- the lane waits for that launch and everything before it on the main stream.  Never under stream
+ * capture, never for RD_OP_ZERO (no kernel), single-threaded walk only.  Returns the previous setting.  Process-wide. */
+int rd_run_list_bind_fork_events(int enable);
+/* forks of the single-threaded walk since the library was loaded: served by a bound event / by a recorded one (tests, diagnostics) */
+void rd_run_list_fork_counts(long long* bound, long long* recorded);
 
 /* Measurement only (bench.py `box`): what this box's GPU sustains on two fixed micro-kernels, so that a bench line can be compared across
  * boxes of a pool whose clocks differ by a few per cent.  No reference counterpart (the reference publishes no throughput: BASELINE.md).

@@ -738,25 +738,25 @@ extern "C" {
 
 int rd_bn_finalize_fwd(const rd_bn_fwd_t* p, void* stream) {
     if (!p || p->G < 1 || p->G > RD_MAX_GROUPS) return -1;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(p->C), dim3(64 * p->G), 0, (hipStream_t)stream, *p);
+    rd_launch(bn_finalize_fwd_kernel, dim3(p->C), dim3(64 * p->G), 0, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 
 int rd_bn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
     if (!p || p->G < 1 || p->G > RD_MAX_GROUPS) return -1;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(p->C), dim3(64 * p->G), 0, (hipStream_t)stream, *p);
+    rd_launch(bn_finalize_bwd_kernel, dim3(p->C), dim3(64 * p->G), 0, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 
 int rd_gn_finalize_fwd(const rd_bn_fwd_t* p, void* stream) {
     if (!p || p->G < 1 || p->G > RD_MAX_GROUPS || p->C < 1) return -1;
-    hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3(p->G), dim3(256), 0, (hipStream_t)stream, *p);
+    rd_launch(gn_finalize_fwd_kernel, dim3(p->G), dim3(256), 0, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 
 int rd_gn_finalize_bwd(const rd_bn_bwd_t* p, void* stream) {
     if (!p || p->G < 1 || p->G > RD_MAX_GROUPS || p->C < 1 || p->C > 1024) return -1;
-    hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *p);
+    rd_launch(gn_finalize_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *p);
     return (int)hipGetLastError();
 }
 
@@ -771,10 +771,10 @@ int rd_up_stats(const void* t, double* stats, void* y_out, int N, int h, int w, 
     int bx = grid_for(items, 256 * us_per, 4096);
     dim3 grid(bx, N);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(up_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream,
+        rd_launch(up_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream,
                            (const bf16_t*)t, stats, (bf16_t*)y_out, h, w, C, gm, nslots);
     else
-        hipLaunchKernelGGL(up_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream,
+        rd_launch(up_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream,
                            (const float*)t, stats, (float*)y_out, h, w, C, gm, nslots);
     return (int)hipGetLastError();
 }
@@ -787,9 +787,9 @@ int rd_bn_stats(const void* x, double* stats, int N, int H, int W, int C, int G,
     const int bx = grid_for(H * W, ppb * 16, 2048);
     dim3 grid(bx, N);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, (const bf16_t*)x, stats, H * W, C, gm);
+        rd_launch(bn_stats_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, (const bf16_t*)x, stats, H * W, C, gm);
     else
-        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, (const float*)x, stats, H * W, C, gm);
+        rd_launch(bn_stats_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, (const float*)x, stats, H * W, C, gm);
     return (int)hipGetLastError();
 }
 
@@ -812,10 +812,10 @@ int rd_pool_fwd(const void* z, const float* scale, const float* shift, float slo
     const GroupMap gm = host_gm(G, gstart_host);
     dim3 grid(grid_for((size_t)Ho * Wo * (C / S), 256 * 4, 2048), N);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(pool_fwd_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const bf16_t*)z, scale, shift,
+        rd_launch(pool_fwd_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const bf16_t*)z, scale, shift,
                            slope, (bf16_t*)out, Ho, Wo, C, gm, fa);
     else
-        hipLaunchKernelGGL(pool_fwd_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const float*)z, scale, shift,
+        rd_launch(pool_fwd_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, (const float*)z, scale, shift,
                            slope, (float*)out, Ho, Wo, C, gm, fa);
     return (int)hipGetLastError();
 }
@@ -831,17 +831,17 @@ int rd_pool_bwd(const void* gp, const void* z, const float* scale, const float* 
     const size_t lds = 2 * C * sizeof(double) + 2 * C * sizeof(float);
     if (dtype == RD_BF16) {
         if (accumulate)
-            hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, true>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale,
+            rd_launch((pool_bwd_kernel<bf16_t, true>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale,
                                shift, slope, act, (bf16_t*)g, bstats, Ho, Wo, C, gm, nslots);
         else
-            hipLaunchKernelGGL((pool_bwd_kernel<bf16_t, false>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale,
+            rd_launch((pool_bwd_kernel<bf16_t, false>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)gp, (const bf16_t*)z, scale,
                                shift, slope, act, (bf16_t*)g, bstats, Ho, Wo, C, gm, nslots);
     } else {
         if (accumulate)
-            hipLaunchKernelGGL((pool_bwd_kernel<float, true>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
+            rd_launch((pool_bwd_kernel<float, true>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
                                slope, act, (float*)g, bstats, Ho, Wo, C, gm, nslots);
         else
-            hipLaunchKernelGGL((pool_bwd_kernel<float, false>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
+            rd_launch((pool_bwd_kernel<float, false>), grid, dim3(256), lds, (hipStream_t)stream, (const float*)gp, (const float*)z, scale, shift,
                                slope, act, (float*)g, bstats, Ho, Wo, C, gm, nslots);
     }
     return (int)hipGetLastError();
@@ -856,7 +856,7 @@ int rd_bn_apply(const void* x, const void* x2, void* out, const float* a, const 
     const int items = H * W * (C / S);
     dim3 grid(grid_for(items, 256 * 4, 1024), N);
     hipStream_t st = (hipStream_t)stream;
-#define RD_APPLY(T_, TWO_) hipLaunchKernelGGL((bn_apply_kernel<T_, TWO_>), grid, dim3(256), 0, st, (const T_*)x, (const T_*)x2, (T_*)out, \
+#define RD_APPLY(T_, TWO_) rd_launch((bn_apply_kernel<T_, TWO_>), grid, dim3(256), 0, st, (const T_*)x, (const T_*)x2, (T_*)out, \
                                               a, b, c, slope, H * W, C, gm)
     if (dtype == RD_BF16) { if (x2) RD_APPLY(bf16_t, true); else RD_APPLY(bf16_t, false); }
     else { if (x2) RD_APPLY(float, true); else RD_APPLY(float, false); }
@@ -882,10 +882,10 @@ int rd_up_bwd(const void* g, const void* t, void* dt, const float* P, const floa
     const GroupMap gm = host_gm(G, gstart_host);
     dim3 grid(grid_for((size_t)h * w * (C / S), 256, 1024), N);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(up_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)t,
+        rd_launch(up_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)t,
                            (bf16_t*)dt, P, Q, R, h, w, C, gm, fa);
     else
-        hipLaunchKernelGGL(up_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)t,
+        rd_launch(up_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)t,
                            (float*)dt, P, Q, R, h, w, C, gm, fa);
     return (int)hipGetLastError();
 }
@@ -895,9 +895,9 @@ int rd_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int cst
     if (Cs < C) return -1;
     const size_t total = (size_t)N * C * H * W;
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, N, C, H, W, Cs);
+        rd_launch(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, N, C, H, W, Cs);
     else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (float*)y, N, C, H, W, Cs);
+        rd_launch(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (float*)y, N, C, H, W, Cs);
     return (int)hipGetLastError();
 }
 
@@ -906,10 +906,10 @@ int rd_nhwc_to_nchw(const void* z, float* y, const float* scale, const float* sh
     const size_t total = (size_t)N * C * H * W;
     const GroupMap gm = host_gm(G, gstart_host);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, y,
+        rd_launch(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, y,
                            scale, shift, act, slope, N, C, H, W, gm);
     else
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)z, y,
+        rd_launch(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)z, y,
                            scale, shift, act, slope, N, C, H, W, gm);
     return (int)hipGetLastError();
 }
@@ -920,10 +920,10 @@ int rd_grad_in(const float* dy, const void* z, void* g, const float* scale, cons
     const GroupMap gm = host_gm(G, gstart_host);
     dim3 grid((H * W + 63) / 64, N);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(grad_in_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, dy, (const bf16_t*)z,
+        rd_launch(grad_in_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, dy, (const bf16_t*)z,
                            (bf16_t*)g, scale, shift, bstats, act, slope, accumulate, C, H, W, gm);
     else
-        hipLaunchKernelGGL(grad_in_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, dy, (const float*)z,
+        rd_launch(grad_in_kernel<float>, grid, dim3(256), 2 * C * sizeof(double), (hipStream_t)stream, dy, (const float*)z,
                            (float*)g, scale, shift, bstats, act, slope, accumulate, C, H, W, gm);
     return (int)hipGetLastError();
 }
@@ -933,10 +933,10 @@ int rd_colsum(const void* x, float* out, float* partial_ws, int64_t npix, int C,
     if (C > 8) return -2;
     const int nb = grid_for((size_t)npix, 256 * 4, 1024);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial_ws, npix, C, Cs);
+        rd_launch(colsum_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial_ws, npix, C, Cs);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, partial_ws, npix, C, Cs);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial_ws, out, nb, C, beta);
+        rd_launch(colsum_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, partial_ws, npix, C, Cs);
+    rd_launch(colsum_final_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial_ws, out, nb, C, beta);
     return (int)hipGetLastError();
 }
 

@@ -56,13 +56,13 @@ extern "C" int rd_box_probe(int which, void* a, void* b, int64_t n, void* stream
     hipStream_t st = (hipStream_t)stream;
     if (which == 0) {                                      // copy n bytes from a to b (n % 16 == 0)
         if (!a || !b || n < 16 || n % 16) return -1;
-        hipLaunchKernelGGL(box_copy_kernel, dim3(rd_num_cus() * 8), dim3(256), 0, st, (const uint4*)a, (uint4*)b, (size_t)(n / 16));
+        rd_launch(box_copy_kernel, dim3(rd_num_cus() * 8), dim3(256), 0, st, (const uint4*)a, (uint4*)b, (size_t)(n / 16));
     } else if (which == 1) {                               // n iterations of 4 MFMAs per wave, 8 waves per CU; a: 4 bytes of scratch
         if (!a || n < 1 || n > (1ll << 30)) return -1;
-        hipLaunchKernelGGL(box_mfma_kernel, dim3(rd_num_cus()), dim3(512), 0, st, (float*)a, (int)n);
+        rd_launch(box_mfma_kernel, dim3(rd_num_cus()), dim3(512), 0, st, (float*)a, (int)n);
     } else if (which == 2) {                               // a: 2048 x two 8-byte counters (shader clock, 100 MHz clock), one pair per unit
         if (!a) return -1;
-        hipLaunchKernelGGL(box_clock_kernel, dim3(4096), dim3(64), 0, st, (unsigned long long*)a);
+        rd_launch(box_clock_kernel, dim3(4096), dim3(64), 0, st, (unsigned long long*)a);
     } else {
         return -1;
     }

@@ -1,8 +1,28 @@
 // common.h -- device-side helpers shared by every kernel file (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <utility>
 #include <stdint.h>
 #include <stdio.h>
+
+// ---- every kernel launch of the library goes through rd_launch.  A lane fork of the launch list (runlist.hip) normally costs the
+// producing stream an event RECORD -- a barrier packet of its own between two dependent kernels: +3.0 us per fork on a chain of
+// dependent kernels, +5.5 us with the waiting stream's first kernel starting beside it (scripts/probe/ext_event.hip), ~40 forks in a
+// training step.  When the launch list knows that a fork follows a launch it sets rd_tls_stop_event, and the launch binds that event
+// to the kernel's OWN dispatch packet (hipExtLaunchKernelGGL stopEvent: +0.06 us): the waiting stream's hipStreamWaitEvent then needs
+// no record.  An entry point with several launches binds the event to each in turn; the last binding is the one a later wait sees.
+extern thread_local hipEvent_t rd_tls_stop_event;           // runlist.hip; null outside a launch the list has marked
+extern thread_local int rd_tls_stop_used;                   // set when a launch has bound the event
+template <typename F, typename... A>
+inline void rd_launch(F kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, A&&... args) {
+    if (hipEvent_t e = rd_tls_stop_event) {
+        rd_tls_stop_used = 1;
+        hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)shmem, st, nullptr, e, 0, std::forward<A>(args)...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, std::forward<A>(args)...);
+    }
+}
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -93,10 +93,10 @@ int rd_pack_weights(const float* w_oihw, void* packed, int Cout, int Cin, int ta
     if (blocks > 1024) blocks = 1024;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, w_oihw, (bf16_t*)packed, Cout, Cin, taps,
+        rd_launch(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, w_oihw, (bf16_t*)packed, Cout, Cin, taps,
                            transpose, RowPad, ColPad);
     else
-        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w_oihw, (float*)packed, Cout, Cin, taps,
+        rd_launch(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, w_oihw, (float*)packed, Cout, Cin, taps,
                            transpose, RowPad, ColPad);
     return (int)hipGetLastError();
 }
@@ -110,10 +110,10 @@ int rd_pack_weights_batched(const float* params, void* packed, const rd_pack_ent
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3((int)blocks), dim3(256), n_entries * sizeof(int), st, params, (bf16_t*)packed, table_dev,
+        rd_launch(pack_weights_batched_kernel<bf16_t>, dim3((int)blocks), dim3(256), n_entries * sizeof(int), st, params, (bf16_t*)packed, table_dev,
                            n_entries, total);
     else
-        hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3((int)blocks), dim3(256), n_entries * sizeof(int), st, params, (float*)packed, table_dev,
+        rd_launch(pack_weights_batched_kernel<float>, dim3((int)blocks), dim3(256), n_entries * sizeof(int), st, params, (float*)packed, table_dev,
                            n_entries, total);
     return (int)hipGetLastError();
 }

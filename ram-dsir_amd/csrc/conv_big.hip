@@ -138,12 +138,12 @@ int launch_conv(const rd_conv_t& p, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
                 attr_pf = true;
             }
-            if (nq == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1>), grid, dim3(256), lds, st, p, rdfin::current());
-            else hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 2>), grid, dim3(256), lds, st, p, rdfin::current());
+            if (nq == 1) rd_launch((conv_pf_kernel<T, TAPS, NB, 1>), grid, dim3(256), lds, st, p, rdfin::current());
+            else rd_launch((conv_pf_kernel<T, TAPS, NB, 2>), grid, dim3(256), lds, st, p, rdfin::current());
             return (int)hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((conv_kernel<T, TAPS, NB>), grid, dim3(256), lds, st, p, rdfin::current());
+    rd_launch((conv_kernel<T, TAPS, NB>), grid, dim3(256), lds, st, p, rdfin::current());
     return (int)hipGetLastError();
 }
 

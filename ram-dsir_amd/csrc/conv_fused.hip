@@ -448,7 +448,7 @@ int fused_launch_one(dim3 grid, hipStream_t st, const rd_conv_t& p, const FusedW
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_bwd_fused_kernel<NSL, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_small_bwd_fused_kernel<NSL, NQ>), grid, dim3(512), FZ_LDS, st, p, fw, tpw, rdfin::current());
+    rd_launch((conv_small_bwd_fused_kernel<NSL, NQ>), grid, dim3(512), FZ_LDS, st, p, fw, tpw, rdfin::current());
     return (int)hipGetLastError();
 }
 int fused_launch(int nsl, int nq, dim3 grid, hipStream_t st, const rd_conv_t& p, const FusedWg& fw, int tpw) {

@@ -35,9 +35,9 @@ int launch_lean(const rd_conv_t& p, int ep, int nq, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pf_kernel<T, TAPS, NB, 2, 2, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         attr = true;
     }
-    if (ep == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1, 1, TS>), grid, dim3(256), lds, st, p, rdfin::current());
-    else if (nq == 1) hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 1, 2, TS>), grid, dim3(256), lds, st, p, rdfin::current());
-    else hipLaunchKernelGGL((conv_pf_kernel<T, TAPS, NB, 2, 2, TS>), grid, dim3(256), lds, st, p, rdfin::current());
+    if (ep == 1) rd_launch((conv_pf_kernel<T, TAPS, NB, 1, 1, TS>), grid, dim3(256), lds, st, p, rdfin::current());
+    else if (nq == 1) rd_launch((conv_pf_kernel<T, TAPS, NB, 1, 2, TS>), grid, dim3(256), lds, st, p, rdfin::current());
+    else rd_launch((conv_pf_kernel<T, TAPS, NB, 2, 2, TS>), grid, dim3(256), lds, st, p, rdfin::current());
     return (int)hipGetLastError();
 }
 

@@ -1167,20 +1167,20 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         for (int i = 0; i < p.nsrc; ++i) sout = sout || p.src[i].out != nullptr;
         sout = sout && rd_conv_ws_stores_sources(p);
         if (mode == 1 && sout) {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1, false, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
-            else hipLaunchKernelGGL((conv_ws_kernel<1, 0, false, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
+            if (flat) rd_launch((conv_ws_kernel<1, 1, false, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else rd_launch((conv_ws_kernel<1, 0, false, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         } else if (mode == 1) {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<1, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
-            else hipLaunchKernelGGL((conv_ws_kernel<1, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
+            if (flat) rd_launch((conv_ws_kernel<1, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else rd_launch((conv_ws_kernel<1, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         } else if (skind == 2 && sout) {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1, true, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
-            else hipLaunchKernelGGL((conv_ws_kernel<2, 0, true, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
+            if (flat) rd_launch((conv_ws_kernel<2, 1, true, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else rd_launch((conv_ws_kernel<2, 0, true, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         } else if (skind == 2) {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
-            else hipLaunchKernelGGL((conv_ws_kernel<2, 0, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
+            if (flat) rd_launch((conv_ws_kernel<2, 1, true>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else rd_launch((conv_ws_kernel<2, 0, true>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         } else {
-            if (flat) hipLaunchKernelGGL((conv_ws_kernel<2, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
-            else hipLaunchKernelGGL((conv_ws_kernel<2, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
+            if (flat) rd_launch((conv_ws_kernel<2, 1>), dim3(grid_ws), dim3(512), WsLds<1>::LDS, st, p, arg, rdfin::current());
+            else rd_launch((conv_ws_kernel<2, 0>), dim3(grid_ws), dim3(512), WsLds<0>::LDS, st, p, arg, rdfin::current());
         }
         return (int)hipGetLastError();
     }
@@ -1189,6 +1189,6 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
     // epilogue (2100 VALU per tile and wave at one workgroup per CU) costs more than the pipelined K loop gains.
     static const bool pp_all = rd_switch("RD_CONV_PP_ALL", 0) != 0;
     if (tiles > n_cu && !pp_all) return RD_CONV_PP_NA;
-    hipLaunchKernelGGL(conv_pp_kernel, dim3(grid), dim3(256), PP_LDS, st, p, tiles, rdfin::current());
+    rd_launch(conv_pp_kernel, dim3(grid), dim3(256), PP_LDS, st, p, tiles, rdfin::current());
     return (int)hipGetLastError();
 }

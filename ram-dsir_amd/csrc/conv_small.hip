@@ -521,14 +521,14 @@ int launch_conv_small(const rd_conv_t& p, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_small_kernel<T, TAPS, SRCG, EPI>), grid, dim3(256), lds, st, p, tpw, rdfin::current());
+        rd_launch((conv_small_kernel<T, TAPS, SRCG, EPI>), grid, dim3(256), lds, st, p, tpw, rdfin::current());
     } else {
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_stage_kernel<T, TAPS, SRCG, EPI>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_small_stage_kernel<T, TAPS, SRCG, EPI>), grid, dim3(256), lds, st, p, tpw, rdfin::current());
+        rd_launch((conv_small_stage_kernel<T, TAPS, SRCG, EPI>), grid, dim3(256), lds, st, p, tpw, rdfin::current());
     }
     return (int)hipGetLastError();
 }

@@ -515,8 +515,8 @@ int rd_conv_small_fwd_dispatch(const rd_conv_t& p, int dtype, hipStream_t st) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_fwd_kernel<NSL, OUTV, XP, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS); \
             attr_set = true; \
         } \
-        if (nwv == 4) hipLaunchKernelGGL((conv_small_fwd_kernel<NSL, OUTV, XP, 4>), grid, dim3(256), SW_LDS, st, p, tpw, rdfin::current()); \
-        else hipLaunchKernelGGL((conv_small_fwd_kernel<NSL, OUTV, XP, 8>), grid, dim3(512), SW_LDS, st, p, tpw, rdfin::current()); \
+        if (nwv == 4) rd_launch((conv_small_fwd_kernel<NSL, OUTV, XP, 4>), grid, dim3(256), SW_LDS, st, p, tpw, rdfin::current()); \
+        else rd_launch((conv_small_fwd_kernel<NSL, OUTV, XP, 8>), grid, dim3(512), SW_LDS, st, p, tpw, rdfin::current()); \
         return (int)hipGetLastError(); \
     } while (0)
 #ifdef RD_DEBUG_SWITCHES

@@ -415,12 +415,12 @@ int rd_seg_loss(const rd_seg_loss_t* p, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int nb = seg_blocks(p);
     const int NS = p->kind == 0 ? 8 : 3 + 5 * (p->K - 1);
-    if (dtype == RD_BF16) hipLaunchKernelGGL(seg_loss_sums_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, *p, NS);
-    else hipLaunchKernelGGL(seg_loss_sums_kernel<float>, dim3(nb), dim3(256), 0, st, *p, NS);
-    hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(1024), 0, st, *p, nb);
+    if (dtype == RD_BF16) rd_launch(seg_loss_sums_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, *p, NS);
+    else rd_launch(seg_loss_sums_kernel<float>, dim3(nb), dim3(256), 0, st, *p, NS);
+    rd_launch(seg_loss_final_kernel, dim3(1), dim3(1024), 0, st, *p, nb);
     if (p->dlogits) {
-        if (dtype == RD_BF16) hipLaunchKernelGGL(seg_loss_grad_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, *p, nb);
-        else hipLaunchKernelGGL(seg_loss_grad_kernel<float>, dim3(nb), dim3(256), 0, st, *p, nb);
+        if (dtype == RD_BF16) rd_launch(seg_loss_grad_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, *p, nb);
+        else rd_launch(seg_loss_grad_kernel<float>, dim3(nb), dim3(256), 0, st, *p, nb);
     }
     return (int)hipGetLastError();
 }
@@ -440,22 +440,22 @@ int rd_rec_loss(const void* lg, const void* tgt, void* dl, float* mse_out, float
     const int bx = rec_bx(per_img);
     const GroupMap gm = host_gm2(G, gstart_host);
     if (dtype == RD_BF16)
-        hipLaunchKernelGGL(rec_loss_kernel<bf16_t>, dim3(bx, B), dim3(256), 0, st, (const bf16_t*)lg, (const bf16_t*)tgt, (bf16_t*)dl,
+        rd_launch(rec_loss_kernel<bf16_t>, dim3(bx, B), dim3(256), 0, st, (const bf16_t*)lg, (const bf16_t*)tgt, (bf16_t*)dl,
                            partial_ws, per_img, gm, lambda_rec, C, Ts, Ds);
     else
-        hipLaunchKernelGGL(rec_loss_kernel<float>, dim3(bx, B), dim3(256), 0, st, (const float*)lg, (const float*)tgt, (float*)dl,
+        rd_launch(rec_loss_kernel<float>, dim3(bx, B), dim3(256), 0, st, (const float*)lg, (const float*)tgt, (float*)dl,
                            partial_ws, per_img, gm, lambda_rec, C, Ts, Ds);
-    hipLaunchKernelGGL(rec_loss_final_kernel, dim3(1), dim3(64 * G), 0, st, partial_ws, mse_out, bx, per_img, gm);
+    rd_launch(rec_loss_final_kernel, dim3(1), dim3(64 * G), 0, st, partial_ws, mse_out, bx, per_img, gm);
     return (int)hipGetLastError();
 }
 
 int rd_adam_step(const rd_adam_t* p, void* stream) {
     if (!p || p->n < 1) return -1;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, *p);
+    rd_launch(adam_prepare_kernel, dim3(1), dim3(1), 0, st, *p);
     int64_t nb = (p->n + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(adam_update_kernel, dim3((int)nb), dim3(256), 0, st, *p);
+    rd_launch(adam_update_kernel, dim3((int)nb), dim3(256), 0, st, *p);
     return (int)hipGetLastError();
 }
 

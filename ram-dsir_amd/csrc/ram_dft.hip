@@ -140,7 +140,7 @@ int ram_dft_row_fwd(const void* src, const void* trg, int B, int nimg, int H, in
     a.B = B; a.nimg = nimg; a.H = H; a.W = W; a.KP = KP; a.ntile = g.ntile; a.nblk = (H + 31) / 32; a.nks = g.nks_w;
     const int tasks = nimg * a.nblk * a.ntile;
     const int nj = (a.nks + 3) / 4;
-#define RD_RF(NJ) hipLaunchKernelGGL((ram_row_dft_kernel<NJ>), dim3(tasks), dim3(256), 0, st, a)
+#define RD_RF(NJ) rd_launch((ram_row_dft_kernel<NJ>), dim3(tasks), dim3(256), 0, st, a)
     if (nj <= 4) RD_RF(4);
     else if (nj <= 6) RD_RF(6);
     else if (nj == 7) RD_RF(7);
@@ -162,7 +162,7 @@ int rd_ram_dft_tables(void* tables, int H, int W, int b, void* stream) {
     const RamDftLayout l = ram_dft_layout(g);
     hipStream_t st = (hipStream_t)stream;
     const int n = g.ntile * g.nks_w * 64;
-    hipLaunchKernelGGL(ram_dft_row_fwd_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
+    rd_launch(ram_dft_row_fwd_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
                        reinterpret_cast<uint4*>(reinterpret_cast<char*>(tables) + l.row_fwd), W, g.ntile, g.nks_w);
     return (int)hipGetLastError();
 }

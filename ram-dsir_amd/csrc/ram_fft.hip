@@ -491,7 +491,7 @@ void launch_row_fwd_r(const RamArgs& a, int nimg, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ram_row_fwd_kernel<NW, ROWS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((ram_row_fwd_kernel<NW, ROWS, NT>), dim3((a.H + ROWS - 1) / ROWS, nimg), dim3(NT), lds, st, a);
+    rd_launch((ram_row_fwd_kernel<NW, ROWS, NT>), dim3((a.H + ROWS - 1) / ROWS, nimg), dim3(NT), lds, st, a);
 }
 // one workgroup per CU (ram_lds_request): 1024 threads on 8 image rows; the run-time plan (any side) keeps one row and 256 threads
 template <int NW>
@@ -513,7 +513,7 @@ int launch_col_mix_k(const RamArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL((ram_col_mix_kernel<NH, KT, NT>), dim3((a.nkeep + KT - 1) / KT, 3, a.B), dim3(NT), lds, st, a);
+    rd_launch((ram_col_mix_kernel<NH, KT, NT>), dim3((a.nkeep + KT - 1) / KT, 3, a.B), dim3(NT), lds, st, a);
     return 0;
 }
 // One workgroup per CU (ram_lds_request): 1024 threads on 4 bins (264 workgroups at 8 x 400 x 400: one round of the 256 CUs) instead of five
@@ -536,7 +536,7 @@ void launch_row_inv_r(const RamArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ram_row_inv_kernel<T, NW, ROWS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((ram_row_inv_kernel<T, NW, ROWS, NT>), dim3((a.H + ROWS - 1) / ROWS, a.B), dim3(NT), lds, st, a);
+    rd_launch((ram_row_inv_kernel<T, NW, ROWS, NT>), dim3((a.H + ROWS - 1) / ROWS, a.B), dim3(NT), lds, st, a);
 }
 // One workgroup per CU: 1024 threads on 8 output rows (400 workgroups at 8 x 400 x 400) instead of five workgroups of 256 threads on 2 rows
 template <typename T, int NW>
@@ -642,7 +642,7 @@ int rd_ram_amp(const float* img_chw, float* amp_chw, int C, int H, int W, void* 
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ram_col_amp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        hipLaunchKernelGGL(ram_col_amp_kernel, dim3(a.nkeep, C), dim3(256), lds, st, a);
+        rd_launch(ram_col_amp_kernel, dim3(a.nkeep, C), dim3(256), lds, st, a);
     }
     return (int)hipGetLastError();
 }
@@ -652,7 +652,7 @@ int rd_ram_mutate(const float* amp_src, const float* amp_trg, float* out, int C,
     const size_t total = (size_t)C * H * W;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(ram_mutate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, amp_src, amp_trg, out, C, H, W, b, lam);
+    rd_launch(ram_mutate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, amp_src, amp_trg, out, C, H, W, b, lam);
     return (int)hipGetLastError();
 }
 

@@ -11,6 +11,9 @@
 #include "common.h"
 #include "../../include/ramdsir.h"
 
+thread_local hipEvent_t rd_tls_stop_event = nullptr;        // common.h rd_launch
+thread_local int rd_tls_stop_used = 0;
+
 namespace {
 
 // Events for the cross-stream edges of the SINGLE-THREADED walk (record and wait are issued back to back by the caller).  An event can
@@ -92,7 +95,7 @@ void poison_lds(void* st) {
     }
     if (on != 1) return;
     // one 160 KB workgroup per CU (x2 so that every CU gets one even if some run two 80 KB... the second wave of workgroups overwrites again)
-    hipLaunchKernelGGL(rd_poison_lds_kernel, dim3(2 * cus), dim3(1024), 160 * 1024, (hipStream_t)st, 160 * 1024 / 4);
+    rd_launch(rd_poison_lds_kernel, dim3(2 * cus), dim3(1024), 160 * 1024, (hipStream_t)st, 160 * 1024 / 4);
 }
 #endif
 
@@ -186,6 +189,8 @@ struct Worker {
 Worker* g_workers[EV_MAX_DEV][32] = {};          // keyed by (device, lane): two devices never share a single-producer ring
 std::mutex g_workers_mutex;
 std::atomic<int> g_threads_enabled{0};
+std::atomic<int> g_bind_fork_events{1};                     // rd_run_list_bind_fork_events
+std::atomic<long long> g_forks_bound{0}, g_forks_recorded{0};   // rd_run_list_fork_counts
 
 void worker_main(Worker* w) {
     const rd_launch_t* ops = nullptr;
@@ -282,6 +287,30 @@ int drain(Worker* w) {
     return w->err.exchange(0);
 }
 
+// Does an entry that makes a lane wait for the main stream follow main-lane launch i before the main stream is given anything else?
+// Then launch i carries the event of that fork on its own dispatch packet (common.h rd_launch) and the fork needs no record.
+bool fork_follows(const rd_launch_t* ops, int n, int i) {
+    for (int j = i + 1; j < n; ++j) {
+        const rd_launch_t& q = ops[j];
+        if (q.op == RD_OP_FORK) {
+            if (q.lane > 0) return true;
+            continue;
+        }
+        if (q.op == RD_OP_JOIN || q.lane == 0) return false;    // the main stream's position changes first
+        if (q.wait_main) return true;
+    }
+    return false;
+}
+// main-lane launch with the fork's event bound to its (last) kernel; *bound = the event if a launch took it, else null
+int call_with_stop_event(const rd_launch_t& o, void* st, hipEvent_t e, hipEvent_t* bound) {
+    rd_tls_stop_event = e;
+    rd_tls_stop_used = 0;
+    const int rc = call(o, st);
+    rd_tls_stop_event = nullptr;
+    *bound = rd_tls_stop_used ? e : nullptr;
+    return rc;
+}
+
 int run_list_threaded(const rd_launch_t* ops, int n, void* const* streams, int n_streams, uint32_t* open_lanes, int* bad_index) {
     uint32_t open = open_lanes ? *open_lanes : 0u;
     hipStream_t main_s = (hipStream_t)streams[0];
@@ -360,6 +389,16 @@ int run_list_threaded(const rd_launch_t* ops, int n, void* const* streams, int n
 
 }  // namespace
 
+extern "C" void rd_run_list_fork_counts(long long* bound, long long* recorded) {
+    if (bound) *bound = g_forks_bound.load();
+    if (recorded) *recorded = g_forks_recorded.load();
+}
+
+extern "C" int rd_run_list_bind_fork_events(int enable) {
+    const int old = g_bind_fork_events.exchange(enable ? 1 : 0);
+    return old;
+}
+
 extern "C" int rd_run_list_threads(int enable) {
     const int old = g_threads_enabled.exchange(enable ? 1 : 0);
     return old;
@@ -385,24 +424,50 @@ extern "C" int rd_run_list(const rd_launch_t* ops, int n, void* const* streams, 
     }
     uint32_t open = open_lanes ? *open_lanes : 0u;
     int rc = 0, i = 0;
+    // at_main: an event bound to the LAST launch of the main stream (its dispatch packet's completion), valid until the main stream is
+    // given anything else: forks at this position wait for it instead of recording one.  Not under stream capture (a captured graph
+    // takes its edges from recorded events) and not for RD_OP_ZERO (copy-engine fills, no kernel to bind to).
+    hipEvent_t at_main = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool bind = n_streams > 1 && g_bind_fork_events.load() && hipStreamIsCapturing(main_s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    auto fork_edge = [&](hipStream_t to) -> int {
+        if (to == main_s) return 0;
+        if (at_main) {
+            g_forks_bound.fetch_add(1, std::memory_order_relaxed);
+            return (int)hipStreamWaitEvent(to, at_main, 0);
+        }
+        g_forks_recorded.fetch_add(1, std::memory_order_relaxed);
+        return edge(main_s, to);
+    };
     for (; i < n && rc == 0; ++i) {
         const rd_launch_t& o = ops[i];
         if (o.lane < 0 || o.lane >= n_streams || o.nargs < 0 || o.nargs > RD_LAUNCH_MAX_ARGS) { rc = -1; break; }
         hipStream_t st = (hipStream_t)streams[o.lane];
         if (o.op == RD_OP_FORK) {
-            if (o.lane > 0) { rc = edge(main_s, st); open |= 1u << o.lane; }
+            if (o.lane > 0) { rc = fork_edge(st); open |= 1u << o.lane; }
             continue;
         }
         if (o.op == RD_OP_JOIN) {
-            if (o.lane > 0 && (open & (1u << o.lane))) { rc = edge(st, main_s); open &= ~(1u << o.lane); }
+            if (o.lane > 0 && (open & (1u << o.lane))) {
+                rc = edge(st, main_s);
+                open &= ~(1u << o.lane);
+                if (st != main_s) at_main = nullptr;              // the main stream now also waits for the lane
+            }
             continue;
         }
         if (o.lane > 0 && o.wait_main) {
-            rc = edge(main_s, st);
+            rc = fork_edge(st);
             open |= 1u << o.lane;
             if (rc) break;
         }
-        rc = call(o, (void*)st);
+        if (st == main_s) {
+            at_main = nullptr;
+            hipEvent_t e;
+            if (bind && o.op != RD_OP_ZERO && fork_follows(ops, n, i) && next_event(&e) == 0) rc = call_with_stop_event(o, (void*)st, e, &at_main);
+            else rc = call(o, (void*)st);
+        } else {
+            rc = call(o, (void*)st);
+        }
         if (rc) break;
     }
     if (rc && bad_index) *bad_index = i;

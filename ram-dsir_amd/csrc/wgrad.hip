@@ -956,7 +956,7 @@ int launch_wgrad(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
+    rd_launch((wgrad_kernel<T, TAPS, MB, NB>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     return (int)hipGetLastError();
 }
 
@@ -968,9 +968,9 @@ int launch_wgrad_c16(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
     const size_t lds_red = (size_t)3 * TAPS * 4 * 64 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
     if (p.dz.mode == RD_SRC_BNBWD)
-        hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 2>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
+        rd_launch((wgrad_c16_tr_kernel<TAPS, 2>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     else
-        hipLaunchKernelGGL((wgrad_c16_tr_kernel<TAPS, 1>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
+        rd_launch((wgrad_c16_tr_kernel<TAPS, 1>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     return (int)hipGetLastError();
 }
 
@@ -1005,7 +1005,7 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ws_kernel<NQZ, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds); \
                     attr_lds = ws_lds; \
                 } \
-                hipLaunchKernelGGL((wgrad_ws_kernel<NQZ, XP>), grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws, rdfin::current()); \
+                rd_launch((wgrad_ws_kernel<NQZ, XP>), grid, dim3(512), ws_lds, st, p, g.CoutPadW, g.CinPadW, tiles_ws, rdfin::current()); \
                 return (int)hipGetLastError(); \
             } while (0)
 #ifdef RD_DEBUG_SWITCHES
@@ -1028,11 +1028,11 @@ int launch_wgrad_tr(const rd_wgrad_t& p, const WgradGeom& g, hipStream_t st) {
         }
     }
     if (!wgrad_pf_ok(p))
-        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
+        rd_launch((wgrad_tr_kernel<TAPS, MB, NB, 1, false>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     else if (p.dz.mode == RD_SRC_BNBWD)
-        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 2, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
+        rd_launch((wgrad_tr_kernel<TAPS, MB, NB, 2, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     else
-        hipLaunchKernelGGL((wgrad_tr_kernel<TAPS, MB, NB, 1, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
+        rd_launch((wgrad_tr_kernel<TAPS, MB, NB, 1, true>), grid, dim3(256), lds, st, p, g.CoutPadW, g.CinPadW, g.total_tiles, rdfin::current());
     return (int)hipGetLastError();
 }
 
@@ -1073,11 +1073,11 @@ int rd_wgrad_reduce_launch(const float* partial, float* dW, int nsplit, int taps
     const int total = taps * Cout * Cin;
     // many splits of a small filter (the 16/32-channel layers): 8 outputs x 32 split lanes per block
     if (nsplit >= 128 && total <= 16384) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((total + 7) / 8), dim3(256), 0, st, partial, dW, nsplit, taps, Cout, Cin, CoutPadW, CinPadW, beta);
+        rd_launch(wgrad_reduce_kernel<8>, dim3((total + 7) / 8), dim3(256), 0, st, partial, dW, nsplit, taps, Cout, Cin, CoutPadW, CinPadW, beta);
     } else {
         int blocks = (total + 31) / 32;
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, st, partial, dW, nsplit, taps, Cout, Cin, CoutPadW, CinPadW, beta);
+        rd_launch(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, st, partial, dW, nsplit, taps, Cout, Cin, CoutPadW, CinPadW, beta);
     }
     return (int)hipGetLastError();
 }

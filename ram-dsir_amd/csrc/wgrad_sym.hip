@@ -367,8 +367,8 @@ int rd_wgrad_sym_launch(const rd_wgrad_t& p, int gx, int CoutPadW, int CinPadW, 
         sym_attr = sym_lds;
     }
     if (p.dz.mode == RD_SRC_BNBWD)
-        hipLaunchKernelGGL((wgrad_sym_kernel<2>), sgrid, dim3(512), sym_lds, st, p, CoutPadW, CinPadW, tiles_sym, rdfin::current());
+        rd_launch((wgrad_sym_kernel<2>), sgrid, dim3(512), sym_lds, st, p, CoutPadW, CinPadW, tiles_sym, rdfin::current());
     else
-        hipLaunchKernelGGL((wgrad_sym_kernel<1>), sgrid, dim3(512), sym_lds, st, p, CoutPadW, CinPadW, tiles_sym, rdfin::current());
+        rd_launch((wgrad_sym_kernel<1>), sgrid, dim3(512), sym_lds, st, p, CoutPadW, CinPadW, tiles_sym, rdfin::current());
     return (int)hipGetLastError();
 }

@@ -140,6 +140,8 @@ _SIGS = {
     'rd_run_list': (C.c_int, [C.POINTER(RdLaunch), C.c_int, C.POINTER(vp), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     'rd_join_lanes': (C.c_int, [C.POINTER(vp), C.c_int, C.c_uint32]),
     'rd_run_list_threads': (C.c_int, [C.c_int]),
+    'rd_run_list_bind_fork_events': (C.c_int, [C.c_int]),
+    'rd_run_list_fork_counts': (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     'rd_box_probe': (C.c_int, [C.c_int, vp, vp, i64, vp]),
 }
 

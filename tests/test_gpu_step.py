@@ -653,6 +653,54 @@ def test_data_parallel_step_matches_plain_step_on_one_rank(golden_dir):
             dist.destroy_process_group()
 
 
+def test_lane_forks_take_their_event_from_the_producing_launch():
+    """rd_run_list_bind_fork_events (include/ramdsir.h): a lane fork that directly follows a launch of the main stream waits for an
+    event bound to that launch's own dispatch packet (hipExtLaunchKernelGGL stop event) instead of a hipEventRecord behind it -- the
+    same dependency without a packet of its own on the main stream (scripts/probe/ext_event.hip: 3 us per fork; the 128 x 128 step
+    1.69 -> 1.63 ms).  The step's forks are served that way, and the step gives the bits of the recorded-event walk."""
+    import ctypes
+    from ramdsir import _lib as L_
+    lib = L_.lib()
+
+    def counts():
+        b, r = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        lib.rd_run_list_fork_counts(ctypes.byref(b), ctypes.byref(r))
+        return b.value, r.value
+
+    out = {}
+    try:
+        for mode in (0, 1):
+            lib.rd_run_list_bind_fork_events(mode)
+            torch.manual_seed(0)
+            bank, mods = S_.make_bank(DEV, 3, 16, 2, 3)
+            g = torch.Generator().manual_seed(1)
+            for (m, k), (off, shape) in bank.index.items():
+                v = bank.p(m, k)
+                if len(shape) == 4:
+                    v.copy_((torch.randn(shape, generator=g) * (2.0 / (shape[0] * shape[2] * shape[3])) ** 0.5).to(DEV))
+                elif '.bn' in k and k.endswith('weight'):
+                    v.fill_(1.0)
+            ts = S_.TrainStep(bank, mods, torch.bfloat16, [2, 3, 3], 64, 64, dataset='fundus', consistency='kd', lr=2e-3, total_iters=100, ram='u8')
+            ts.wpack.refresh()
+            gen = torch.Generator(device=DEV).manual_seed(5)
+            src = (torch.rand(8, 64, 64, 3, device=DEV, generator=gen) * 255).to(torch.uint8)
+            trg = (torch.rand(8, 64, 64, 3, device=DEV, generator=gen) * 255).to(torch.uint8)
+            ts.load_raw(src, trg, torch.tensor([0.1 * (1 + j) for j in range(8)], device=DEV))
+            ts.load_target((torch.rand(8, 2, 64, 64, device=DEV, generator=gen) > 0.5).float())
+            c0 = counts()
+            for _ in range(4):
+                ts.step()
+            torch.cuda.synchronize()
+            c1 = counts()
+            out[mode] = (bank.params.clone(), bank.grads.clone(), ts.losses.clone(), c1[0] - c0[0], c1[1] - c0[1])
+    finally:
+        lib.rd_run_list_bind_fork_events(1)
+    assert out[0][3] == 0 and out[0][4] > 0, out[0][3:]                  # recorded events only
+    assert out[1][3] > 0 and out[1][3] >= 0.9 * out[0][4], (out[1][3:], out[0][3:])   # (nearly) every fork follows a launch directly
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert torch.equal(a.reshape(-1).view(torch.uint8), b.reshape(-1).view(torch.uint8))
+
+
 @pytest.mark.parametrize('reps,side', [(300, 64), (100, 400)])
 def test_step_repeats_bit_for_bit_while_other_processes_share_the_gpu(reps, side):
     """Three processes at once, each repeating ONE step `reps` times from the same saved state (scripts/step_repeat_stress.py) and
