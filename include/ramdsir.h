@@ -366,7 +366,8 @@ int rd_adam_step(const rd_adam_t* p, void* stream);
 
 /* optimizer.zero_grad() (code/train.py:285,454) and the per-step reset of the BatchNorm sum buffers (stats / bstats arenas,
  * which the conv epilogues add into): n device ranges [ptrs_host[i], +bytes_host[i]) := 0, asynchronously on `stream`.
- * The two arrays are HOST arrays (read before the call returns). */
+ * The two arrays are HOST arrays (read before the call returns).  Up to 8 ranges with 16-byte-aligned starts are cleared by ONE
+ * kernel launch; otherwise one hipMemsetAsync per range. */
 int rd_zero(void* const* ptrs_host, const int64_t* bytes_host, int n, void* stream);
 
 
@@ -462,7 +463,7 @@ int rd_run_list_threads(int enable);
  * dispatch packet (hipExtLaunchKernelGGL stop event) instead of a hipEventRecord behind it: a record is a packet of its own between two
  * dependent kernels and costs the main stream ~3 us per fork (scripts/probe/ext_event.hip), ~40 times per training step.  The
  * dependency is the same one -- the lane waits for that launch and everything before it on the main stream.  Never under stream
- * capture, never for RD_OP_ZERO (no kernel), single-threaded walk only.  Returns the previous setting.  Process-wide. */
+ * capture, single-threaded walk only (an entry that launches no kernel of the library leaves the fork to a record).  Returns the previous setting.  Process-wide. */
 int rd_run_list_bind_fork_events(int enable);
 /* forks of the single-threaded walk since the library was loaded: served by a bound event / by a recorded one (tests, diagnostics) */
 void rd_run_list_fork_counts(long long* bound, long long* recorded);

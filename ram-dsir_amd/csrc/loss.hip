@@ -384,6 +384,26 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const rd_adam_t p) {
     }
 }
 
+// rd_zero: every range in one launch (16-byte stores; the last bytes of a range whose size is not a multiple of 16 one by one)
+constexpr int ZERO_MAX_RANGES = 8;
+struct ZeroArgs {
+    void* p[ZERO_MAX_RANGES];
+    unsigned long long bytes[ZERO_MAX_RANGES];
+    int n;
+};
+__global__ __launch_bounds__(256) void zero_ranges_kernel(const ZeroArgs a) {
+    const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (int r = 0; r < a.n; ++r) {
+        uint4* q = reinterpret_cast<uint4*>(a.p[r]);
+        const size_t nv = a.bytes[r] / 16;
+        for (size_t i = t0; i < nv; i += stride) q[i] = make_uint4(0, 0, 0, 0);
+        if (blockIdx.x == 0) {
+            unsigned char* b = reinterpret_cast<unsigned char*>(a.p[r]);
+            for (size_t i = nv * 16 + threadIdx.x; i < a.bytes[r]; i += 256) b[i] = 0;
+        }
+    }
+}
+
 GroupMap host_gm2(int G, const int32_t* gs) {
     GroupMap gm;
     gm.G = G;
@@ -459,10 +479,27 @@ int rd_adam_step(const rd_adam_t* p, void* stream) {
     return (int)hipGetLastError();
 }
 
-// optimizer.zero_grad() (train.py:285,454) + the per-step reset of the BatchNorm sum buffers: n device ranges set to zero bytes
-// by the copy engine / blit path of the runtime on `stream` (no tensor-library operator on the step path)
+// optimizer.zero_grad() (train.py:285,454) + the per-step reset of the BatchNorm sum buffers: n device ranges set to zero bytes on
+// `stream`.  Up to ZERO_MAX_RANGES 16-byte-aligned ranges go in ONE kernel launch (the range table travels in the kernel arguments); as
+// one hipMemsetAsync per range the step began with three fill kernels of the runtime back to back, 5 us each for 10 MB, on the
+// critical lane (scripts/r6/lane_gaps.py).  More ranges, or an unaligned pointer: the runtime's fills as before.
 int rd_zero(void* const* ptrs_host, const int64_t* bytes_host, int n, void* stream) {
     if (n < 0 || (n > 0 && (!ptrs_host || !bytes_host))) return -1;
+    ZeroArgs a;
+    a.n = 0;
+    bool one_launch = true;
+    for (int i = 0; i < n && one_launch; ++i) {
+        if (!ptrs_host[i] || bytes_host[i] <= 0) continue;
+        if (a.n == ZERO_MAX_RANGES || ((uintptr_t)ptrs_host[i] & 15)) { one_launch = false; break; }
+        a.p[a.n] = ptrs_host[i];
+        a.bytes[a.n] = (unsigned long long)bytes_host[i];
+        ++a.n;
+    }
+    if (one_launch) {
+        if (a.n == 0) return 0;
+        rd_launch(zero_ranges_kernel, dim3(rd_num_cus() * 8), dim3(256), 0, (hipStream_t)stream, a);
+        return (int)hipGetLastError();
+    }
     for (int i = 0; i < n; ++i) {
         if (!ptrs_host[i] || bytes_host[i] <= 0) continue;
         RD_CHECK(hipMemsetAsync(ptrs_host[i], 0, (size_t)bytes_host[i], (hipStream_t)stream));

@@ -426,7 +426,7 @@ extern "C" int rd_run_list(const rd_launch_t* ops, int n, void* const* streams, 
     int rc = 0, i = 0;
     // at_main: an event bound to the LAST launch of the main stream (its dispatch packet's completion), valid until the main stream is
     // given anything else: forks at this position wait for it instead of recording one.  Not under stream capture (a captured graph
-    // takes its edges from recorded events) and not for RD_OP_ZERO (copy-engine fills, no kernel to bind to).
+    // takes its edges from recorded events).
     hipEvent_t at_main = nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool bind = n_streams > 1 && g_bind_fork_events.load() && hipStreamIsCapturing(main_s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
@@ -463,7 +463,8 @@ extern "C" int rd_run_list(const rd_launch_t* ops, int n, void* const* streams, 
         if (st == main_s) {
             at_main = nullptr;
             hipEvent_t e;
-            if (bind && o.op != RD_OP_ZERO && fork_follows(ops, n, i) && next_event(&e) == 0) rc = call_with_stop_event(o, (void*)st, e, &at_main);
+            if (bind && fork_follows(ops, n, i) && next_event(&e) == 0) rc = call_with_stop_event(o, (void*)st, e, &at_main);   // (an entry that
+            // launched no kernel -- rd_zero's fallback to the runtime's fills -- leaves at_main null: the fork records)
             else rc = call(o, (void*)st);
         } else {
             rc = call(o, (void*)st);

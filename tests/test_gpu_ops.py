@@ -987,3 +987,26 @@ def test_conv_kernels_under_forced_dispatch(env):
     tail = r.stdout.decode()[-2500:]
     assert r.returncode == 0, tail
     assert ' passed' in tail and 'failed' not in tail, tail
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['three_aligned', 'ragged_sizes', 'nine_ranges', 'unaligned_start'])
+def test_rd_zero_clears_exactly_its_ranges(case):
+    """rd_zero (include/ramdsir.h; optimizer.zero_grad() of code/train.py:285,454 + the per-step reset of the BatchNorm sum arenas): up to
+    8 ranges with 16-byte-aligned starts in one kernel launch, anything else through the runtime's fills -- every byte of every range
+    zero, every byte outside untouched."""
+    buf = torch.full((1 << 20,), 0x5a, dtype=torch.uint8, device=U.dev())
+    spans = dict(three_aligned=[(0, 4096), (65536, 300000), (524288, 16)],
+                 ragged_sizes=[(16, 1), (1024, 17), (4096, 100003), (262144, 15)],
+                 nine_ranges=[(4096 * i, 1000 + i) for i in range(9)],
+                 unaligned_start=[(3, 1000), (8192, 4096)])[case]
+    base = buf.data_ptr()
+    assert base % 16 == 0
+    ptrs = (L.vp * len(spans))(*[base + o for o, _ in spans])
+    sizes = (L.i64 * len(spans))(*[n for _, n in spans])
+    L.check(L.lib().rd_zero(ptrs, sizes, len(spans), None), case)
+    torch.cuda.synchronize()
+    want = torch.full((1 << 20,), 0x5a, dtype=torch.uint8)
+    for o, n in spans:
+        want[o:o + n] = 0
+    assert torch.equal(buf.cpu(), want)
