@@ -467,6 +467,9 @@ int rd_run_list_threads(int enable);
 int rd_run_list_bind_fork_events(int enable);
 /* forks of the single-threaded walk since the library was loaded: served by a bound event / by a recorded one (tests, diagnostics) */
 void rd_run_list_fork_counts(long long* bound, long long* recorded);
+/* carries[i] = 1 for the entries of lane 0 that rd_run_list would launch with a fork's event bound to them (a RD_OP_FORK of a lane > 0,
+ * or a lane entry with wait_main, follows before the main stream is given anything else or joins a lane).  Host logic only. */
+int rd_run_list_fork_plan(const rd_launch_t* ops, int n, unsigned char* carries);
 
 /* Measurement only (bench.py `box`): what this box's GPU sustains on two fixed micro-kernels, so that a bench line can be compared across
  * boxes of a pool whose clocks differ by a few per cent.  No reference counterpart (the reference publishes no throughput: BASELINE.md).

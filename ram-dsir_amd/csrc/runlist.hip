@@ -389,6 +389,16 @@ int run_list_threaded(const rd_launch_t* ops, int n, void* const* streams, int n
 
 }  // namespace
 
+// which main-lane entries of a list would carry a fork's event on their own dispatch packet (host logic only: no stream, no launch)
+extern "C" int rd_run_list_fork_plan(const rd_launch_t* ops, int n, unsigned char* carries) {
+    if (n < 0 || (n > 0 && (!ops || !carries))) return -1;
+    for (int i = 0; i < n; ++i) {
+        const rd_launch_t& o = ops[i];
+        carries[i] = (o.op != RD_OP_FORK && o.op != RD_OP_JOIN && o.lane == 0 && fork_follows(ops, n, i)) ? 1 : 0;
+    }
+    return 0;
+}
+
 extern "C" void rd_run_list_fork_counts(long long* bound, long long* recorded) {
     if (bound) *bound = g_forks_bound.load();
     if (recorded) *recorded = g_forks_recorded.load();

@@ -142,6 +142,7 @@ _SIGS = {
     'rd_run_list_threads': (C.c_int, [C.c_int]),
     'rd_run_list_bind_fork_events': (C.c_int, [C.c_int]),
     'rd_run_list_fork_counts': (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    'rd_run_list_fork_plan': (C.c_int, [C.POINTER(RdLaunch), C.c_int, C.POINTER(C.c_ubyte)]),
     'rd_box_probe': (C.c_int, [C.c_int, vp, vp, i64, vp]),
 }
 

@@ -78,6 +78,23 @@ def test_launch_list_packing_and_lanes():
     l0 = E.LaunchList(ops, ())
     assert [(e.op, e.lane, e.wait_main) for e in l0.arr[:l0.n]] == [(oc['rd_conv'], 0, 0), (oc['rd_pool_fwd'], 0, 0), (oc['rd_wgrad'], 0, 0),
                                                                     (oc['rd_adam_step'], 0, 0)]
+    # which main-lane launches carry the event of the fork behind them on their own dispatch packet (rd_run_list_bind_fork_events):
+    # the conv (a fork of `rec` and a lane entry with wait_main follow before the main stream moves on), not Adam (nothing follows)
+    carries = (ctypes.c_ubyte * ll.n)()
+    assert lib.rd_run_list_fork_plan(ll.arr, ll.n, carries) == 0
+    assert list(carries) == [1, 0, 0, 0, 0, 0]
+    ops2 = [(lib.rd_conv, (ctypes.byref(p), 1), dict(kernel='a')),                           # followed by another main-lane launch: no
+            (lib.rd_conv, (ctypes.byref(p), 1), dict(kernel='b')),                           # followed by a weight gradient on the side lane: yes
+            (lib.rd_wgrad, (ctypes.byref(L.RdWgrad()), 1), dict(side=True, side_idx=0)),
+            (lib.rd_wgrad, (ctypes.byref(L.RdWgrad()), 1), dict(side=True, side_idx=0)),     # same position of the main stream: served by b's event
+            (lib.rd_conv, (ctypes.byref(p), 1), dict(kernel='c')),                           # a join first: the main stream's position changes: no
+            E.sync_op('join', 'side0'),
+            (lib.rd_wgrad, (ctypes.byref(L.RdWgrad()), 1), dict(side=True, side_idx=0)),
+            (lib.rd_adam_step, (ctypes.byref(L.RdAdam()),))]
+    l2 = E.LaunchList(ops2, ('side0', 'rec'))
+    c2 = (ctypes.c_ubyte * l2.n)()
+    assert lib.rd_run_list_fork_plan(l2.arr, l2.n, c2) == 0
+    assert list(c2) == [0, 1, 0, 0, 0, 0, 0, 0]
     # the op codes of the binding are the header's enum
     txt = open(os.path.join(ROOT, 'include', 'ramdsir.h')).read()
     enum = re.search(r'enum \{\s*RD_OP_FORK = 1, RD_OP_JOIN = 2,(.*?)\};', txt, re.S).group(1)
