@@ -160,6 +160,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libramdsir_hip.so is not built: run `make -C ram-dsir_amd/csrc` '
                                '(or __graft_entry__.build()); there is no CPU fallback')
+        # ONE HIP runtime per process: the library's libamdhip64.so.7 must be the copy PyTorch ships and has initialised (the streams and
+        # device pointers handed to the entry points are that runtime's).  Loaded before torch, the dynamic linker would bind it to
+        # /opt/rocm/lib's copy and the first launch on a torch stream fails with hipErrorNoDevice (__graft_entry__.build() followed by
+        # smoke() in one process did) -- so torch comes first, whatever the caller's import order.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
