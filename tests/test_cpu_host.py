@@ -196,6 +196,26 @@ print('ok')
 '''
 
 
+def test_every_kernel_launch_goes_through_rd_launch():
+    """csrc/common.h rd_launch is the ONE launch site of the library: the launch list binds a lane fork's event to the producing launch's
+    own dispatch packet through it (rd_run_list_bind_fork_events).  Behind a raw hipLaunchKernelGGL / <<< >>> elsewhere in a
+    multi-launch entry point, a bound fork would wait for the launch BEFORE it only.  (rd_zero's hipMemsetAsync fallback reports
+    that it bound nothing, and the fork records.)"""
+    import glob
+    csrc = os.path.join(ROOT, 'ram-dsir_amd', 'csrc')
+    offenders = []
+    for f in sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h'))):
+        if os.path.basename(f) == 'common.h':
+            continue
+        for n, line in enumerate(open(f), 1):
+            code = line.split('//')[0]
+            if 'hipLaunchKernelGGL' in code or '<<<' in code or 'hipExtLaunchKernelGGL' in code or 'hipModuleLaunchKernel' in code:
+                offenders.append('%s:%d' % (os.path.basename(f), n))
+    assert not offenders, offenders
+    txt = open(os.path.join(csrc, 'common.h')).read()
+    assert 'hipExtLaunchKernelGGL(kernel, grid, block' in txt and 'rd_tls_stop_used = 1' in txt
+
+
 @pytest.mark.parametrize('world', [2, 8])
 def test_gradient_buckets_average_over_gloo_ranks(tmp_path, world):
     """ramdsir.ddp.GradBuckets (three buckets, asynchronous + synchronous reduce), the loss-scalar mean and the DistributedSampler
