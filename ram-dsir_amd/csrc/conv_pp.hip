@@ -383,6 +383,7 @@ static_assert(WsLds<0>::LDS <= 160 * 1024 && WsLds<1>::LDS <= 160 * 1024, "conv_
 #ifdef RD_DEBUG_SWITCHES
 __device__ unsigned long long ws_trace[2][64][4];          // [role][step][event] shader-clock stamps of workgroup 5 (debug build)
 #define WS_T(role, s, ev) do { if (trace_ && blockIdx.x == 5 && tid == 0 && (s) < 63) ws_trace[role][s][ev] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long ws_wg[256][2];               // [workgroup][entry, exit] on the 100 MHz clock: who starts late when the lanes share the device
 __device__ unsigned long long ws_fine[2][16][16];         // [role][step][event]: stamps INSIDE a step (they cost a scalar-memory wait each)
 #define WS_F(role, s, ev) do { if (trace_ && blockIdx.x == 5 && tid == 0 && (s) < 16) ws_fine[role][s][ev] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     // every step (ldf4g below: not flat loads, which would tie up the LDS counter), so the vectors must be in memory
 #ifdef RD_DEBUG_SWITCHES
     const unsigned long long t_entry_ = __builtin_readcyclecounter();
+    const unsigned long long w_entry_ = wall_clock64();
 #endif
     rdfin::prologue(fa);
 #ifdef RD_DEBUG_SWITCHES
@@ -1043,6 +1045,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const rd_conv_t p, int 
     if (trace_ && blockIdx.x == 5 && tid == 0) { ws_trace[0][63][2] = __builtin_readcyclecounter(); ws_trace[0][63][3] = wall_clock64(); }
 #endif
     flush_stats();
+#ifdef RD_DEBUG_SWITCHES
+    if (trace_ && tid == 0 && blockIdx.x < 256) { ws_wg[blockIdx.x][0] = w_entry_; ws_wg[blockIdx.x][1] = wall_clock64(); }
+#endif
 }
 
 // plain per-pixel single-operand sources made of whole 16-byte channel slots (the fill above is branch-free)
@@ -1064,6 +1069,9 @@ int pp_sources_kind(const rd_conv_t& p) {
 }  // namespace
 
 #ifdef RD_DEBUG_SWITCHES
+extern "C" int rd_debug_ws_wg(unsigned long long* out) {                // debug library only: 256 x {entry, exit} of the last traced launch
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_wg), sizeof(unsigned long long) * 256 * 2);
+}
 extern "C" int rd_debug_ws_fine(unsigned long long* out) {              // debug library only: 2 x 16 x 16 stamps inside the steps
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_fine), sizeof(unsigned long long) * 2 * 16 * 16);
 }
@@ -1162,7 +1170,10 @@ int rd_conv_pp_dispatch(const rd_conv_t& p, hipStream_t st) {
         const int tiles1 = ((p.W + TileGeo<1>::W - 1) / TileGeo<1>::W) * ((p.H + TileGeo<1>::H - 1) / TileGeo<1>::H) * p.N * (p.CoutPad / PP_NT);
         const bool flat = ws_flat && tiles1 * 1.04 < tiles;
         const int nt = flat ? tiles1 : tiles, grid_ws = nt < cus ? nt : cus;
-        const int arg = nt | (ws_exp << 26) | (tiles >= ws_trace_min ? 1 << 25 : 0);
+        // RD_CONV_WS_TRACE_MODE (0 any / 1 forward / 2 gradient) and RD_CONV_WS_TRACE_CIN (0 any) narrow the traced launches inside a whole step
+        static const int ws_trace_mode = rd_switch("RD_CONV_WS_TRACE_MODE", 0), ws_trace_cin = rd_switch("RD_CONV_WS_TRACE_CIN", 0);
+        const bool traced = tiles >= ws_trace_min && (!ws_trace_mode || ws_trace_mode == mode) && (!ws_trace_cin || ws_trace_cin == p.Cin);
+        const int arg = nt | (ws_exp << 26) | (traced ? 1 << 25 : 0);
         bool sout = false;                                     // a source asks for its staged values to be stored as well (ramdsir.h)
         for (int i = 0; i < p.nsrc; ++i) sout = sout || p.src[i].out != nullptr;
         sout = sout && rd_conv_ws_stores_sources(p);
